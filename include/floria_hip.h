@@ -1,0 +1,178 @@
+/*
+ * floria_hip.h — C ABI of libfloria_hip.so: the MI355X (gfx950) replacement for
+ * floria's per-SNP-block read->haplotype clustering path.
+ *
+ * The reference (bluenote-1577/floria, Rust) has no FFI/plugin interface; this header cuts the
+ * seam at the two Rust call sites a drop-in must satisfy:
+ *
+ *   S1  graph_processing.rs:345-362  the rayon par-for over blocks calling
+ *       get_local_hap_blocks(all_frags, snp_to_genome_pos, dir, j, snp_range_vec, options)
+ *       (graph_processing.rs:103-110)            -> floria_hip_phase_blocks()
+ *   S2  floria.rs:359-366 calling part_block_manip::process_reads_for_final_parts(parts,
+ *       short_frags, ranges, options, snp_to_gn) (part_block_manip.rs:174-180)
+ *                                                -> floria_hip_reassign()
+ *   plus utils_frags::get_range_with_lengths (utils_frags.rs:405-463), the host-side function
+ *   that defines the work units (blocks)        -> floria_hip_block_ranges()
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every input is caller-owned and only read during the call;
+ *   - outputs are library-owned and released with the matching *_free();
+ *   - every entry point returns 0 on success, <0 on error (FLORIA_E_*); the message of the last
+ *     error on the calling thread is floria_hip_last_error(); nothing throws across the ABI;
+ *   - a context is bound to one device; one host thread at a time per context;
+ *   - there is NO CPU fallback: if no gfx950 device / HIP runtime is usable, create() fails.
+ *
+ * SNP positions are floria's 1-based SNP indices (types_structs.rs:12 `SnpPosition = u32`),
+ * reads are `Frag`s (types_structs.rs:68-85) flattened to CSR and sorted by `Frag::cmp`
+ * (types_structs.rs:87-93: first_position asc, last_position desc, counter_id asc) with
+ * counter_id == index (floria.rs:289-293).
+ */
+#ifndef FLORIA_HIP_H
+#define FLORIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLORIA_OK            0
+#define FLORIA_E_INVALID    -1   /* malformed argument / pileup violates an invariant            */
+#define FLORIA_E_DEVICE     -2   /* HIP runtime / device error (message has the hipError string) */
+#define FLORIA_E_NOMEM      -3   /* host or device allocation failed                             */
+#define FLORIA_E_UNSUPPORTED -4  /* input outside the supported envelope (e.g. allele index > 3) */
+
+#define FLORIA_MAX_ALLELES   4   /* 2-bit allele codes: 0 = ref, 1..3 = alt (file_reader.rs:702-710) */
+#define FLORIA_MAX_PLOIDY    16
+
+/* One contig's reads as a sparse reads x SNPs pileup (CSR).  Replaces `&Vec<Frag>`
+ * (types_structs.rs:68-85): seq_dict -> (snp, allele), qual_dict -> qual, first/last_position.
+ * Cells of a read are sorted by ascending snp; snp[read_off[r]] == first[r] and
+ * snp[read_off[r+1]-1] == last[r]; every read has >= 1 cell. */
+typedef struct {
+    const uint32_t* read_off;  /* [n_reads+1] cell offsets                      */
+    const uint32_t* snp;       /* [n_cells]   1-based SNP index of the cell     */
+    const uint8_t*  allele;    /* [n_cells]   allele index 0..3                 */
+    const uint8_t*  qual;      /* [n_cells]   base quality (phred, 0..255)      */
+    const uint32_t* first;     /* [n_reads]   first_position                    */
+    const uint32_t* last;      /* [n_reads]   last_position                     */
+    uint32_t        n_reads;
+} floria_pileup;
+
+/* The fields of `Options` (types_structs.rs:20-51) the hot path reads
+ * (graph_processing.rs:111-113,198-226,234). */
+typedef struct {
+    double   epsilon;             /* -e  */
+    uint32_t max_ploidy;          /* -p  (default 5)  */
+    uint32_t beam;                /* -n  max_number_solns (default 10) */
+    uint32_t ploidy_sensitivity;  /* -s  1|2|3 (default 2) */
+    int32_t  stopping_heuristic;  /* !--no-stop-heuristic (default 1) */
+} floria_params;
+
+/* Result of S1 for a batch of blocks (what get_local_hap_blocks returns, minus the HapNode
+ * wrappers the host rebuilds with HapNode::new, types_structs.rs:169).  Block b has
+ * n_b = read_off[b+1]-read_off[b] reads (0 <=> the reference returns None); read_id is ascending;
+ * part[i] in [0,best_ploidy) is the partition (haplotype) of read_id[i] at the chosen ploidy;
+ * mec[b*max_ploidy + p-1] is mec_vector[p-1] (graph_processing.rs:156-162), 0 for untried p. */
+typedef struct {
+    uint32_t  n_blocks;
+    uint32_t  max_ploidy;
+    uint32_t* best_ploidy;     /* [n_blocks]  0 if the block holds no reads */
+    uint32_t* ploidies_tried;  /* [n_blocks]  last ploidy evaluated before the stop rule fired */
+    uint64_t* read_off;        /* [n_blocks+1] */
+    uint32_t* read_id;         /* [read_off[n_blocks]] */
+    uint8_t*  part;            /* [read_off[n_blocks]] */
+    double*   mec;             /* [n_blocks*max_ploidy] */
+    double    min_prune_margin;/* min |p_k - lse - ln(PROB_CUTOFF)| over all pruning decisions
+                                  (global_clustering.rs:98); parity certificate, see DESIGN.md */
+} floria_block_result;
+
+/* Haplogroups (S2 in/out): group g holds reads grp_read[grp_off[g]..grp_off[g+1]) and spans the
+ * inclusive SNP range (range[2g], range[2g+1]).  Output groups are sorted by range
+ * (part_block_manip.rs:276-288) and read ids ascend within a group. */
+typedef struct {
+    uint32_t  n_groups;
+    uint64_t* grp_off;         /* [n_groups+1] */
+    uint32_t* grp_read;        /* [grp_off[n_groups]] */
+    uint32_t* range;           /* [2*n_groups] */
+} floria_groups;
+
+typedef struct {
+    uint32_t  n;
+    uint32_t* start;           /* [n] 1-based inclusive */
+    uint32_t* end;             /* [n] 1-based inclusive */
+} floria_ranges;
+
+/* Per-kernel timing of the last phase_blocks / reassign call, measured with hipEvents on the
+ * context's stream (bench.py's roofline leg reads this). */
+typedef struct {
+    double   beam_ms;          /* sum over launches of the beam-search kernel     */
+    double   optimize_ms;      /* sum over launches of the optimise/MEC kernel    */
+    double   select_ms;        /* stop-rule + gather kernels                      */
+    double   reassign_ms;      /* S2 kernel                                       */
+    double   h2d_ms, d2h_ms;   /* copies issued by the call                       */
+    double   total_ms;         /* first launch -> last completion on the stream   */
+    uint32_t beam_launches, optimize_launches;
+    uint64_t algorithmic_bytes;/* SURVEY.md §8(d) bytes(block) summed over the call's blocks */
+    uint64_t beam_steps;       /* reads consumed by beam search, summed over (block, ploidy) jobs */
+} floria_timing;
+
+typedef struct floria_hip_ctx floria_hip_ctx;
+typedef struct floria_hip_contig floria_hip_contig;   /* a pileup resident in HBM */
+
+int  floria_hip_create(int device, floria_hip_ctx** out);
+void floria_hip_destroy(floria_hip_ctx* ctx);
+const char* floria_hip_last_error(void);
+const char* floria_hip_version(void);
+
+/* utils_frags::get_range_with_lengths (utils_frags.rs:405-463), host side, exact restatement.
+ * snp_to_genome_pos has n_snps entries (0-based SNP index -> bp).  Fails (FLORIA_E_INVALID) where
+ * the reference exits (positions not increasing, utils_frags.rs:424-427). */
+int  floria_hip_block_ranges(const uint64_t* snp_to_genome_pos, uint32_t n_snps,
+                             uint64_t block_length, uint64_t overlap_len, double minimal_density,
+                             floria_ranges** out);
+void floria_hip_ranges_free(floria_ranges* r);
+
+/* Upload one contig's pileup to HBM (validates the invariants above).  The handle can be phased
+ * any number of times; bench.py times phase_blocks_resident so that inputs are resident in HBM. */
+int  floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* pileup, floria_hip_contig** out);
+void floria_hip_contig_free(floria_hip_contig* c);
+
+/* S1: phase n_blocks SNP ranges of one resident contig. */
+int  floria_hip_phase_blocks_resident(floria_hip_ctx* ctx, const floria_hip_contig* contig,
+                                      const uint32_t* blk_start, const uint32_t* blk_end,
+                                      uint32_t n_blocks, const floria_params* params,
+                                      floria_block_result** out);
+/* S1 convenience: upload + phase + free. */
+int  floria_hip_phase_blocks(floria_hip_ctx* ctx, const floria_pileup* pileup,
+                             const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
+                             const floria_params* params, floria_block_result** out);
+void floria_hip_block_result_free(floria_block_result* r);
+
+/* S1 over MANY contigs in one launch sequence (the unit bench.py times: all blocks of all
+ * contigs a rank owns are phased together so the device sees >> 256 concurrent jobs).
+ * blk_contig[b] indexes `contigs`; results are in block order. */
+int  floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs,
+                                   uint32_t n_contigs, const uint32_t* blk_contig,
+                                   const uint32_t* blk_start, const uint32_t* blk_end,
+                                   uint32_t n_blocks, const floria_params* params,
+                                   floria_block_result** out);
+
+/* S2: process_reads_for_final_parts (part_block_manip.rs:174-274) with reassign_short = false
+ * (the CLI default; the short-read branch :235-270 sits behind a hidden flag). */
+int  floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* contig,
+                         const uint64_t* grp_off, const uint32_t* grp_read,
+                         const uint32_t* grp_range, uint32_t n_groups, double epsilon,
+                         floria_groups** out);
+void floria_hip_groups_free(floria_groups* g);
+
+int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
+
+/* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */
+int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLORIA_HIP_H */

@@ -1,0 +1,830 @@
+// floria_oracle.cpp — CPU restatement of floria's per-block read->haplotype clustering path.
+//
+// *** TEST INFRASTRUCTURE ONLY. ***  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load this library; nothing under floria_amd/ (the product) may.
+//
+// PARITY UNPINNED: the reference (Rust) cannot be built in this environment (no rustc/cargo, no
+// vendored crates) and ships no tests, golden vectors or fixtures for this path.
+// This file follows the reference source function by function (citations are file:line under
+// /root/reference/src) and is pinned only by hand-derived known-answer tests (tests/test_kat.py).
+//
+// Faithful-mode data structures: haplotypes are hash maps position -> allele counts that are
+// deep-cloned per beam child and deep-compared for duplicate suppression, like the reference's
+// `Haplotype = FxHashMap<SnpPosition, FxHashMap<Genotype, GenotypeCount>>` (types_structs.rs:15).
+//
+// Two documented canonicalisations (DESIGN.md "Oracle"):
+//  (1) Weighted sums.  Every quality weight w(q) (utils_frags.rs:702-711) is an exact multiple of
+//      2^-24, so `same`/`diff`/histogram sums are carried as Q24 integers plus a count m of
+//      "+epsilon" terms and converted once: value = Q*2^-24 + m*epsilon.  For dyadic epsilon this is
+//      bit-identical to the reference's f64 running sums in any order; for other epsilon the
+//      reference's own sums depend on FxHash iteration order at the ulp level.
+//  (2) Iteration order.  At the three sites where the reference's *result* depends on
+//      FxHashSet/FxHashMap iteration order (local_clustering.rs:304, part_block_manip.rs:195-222,
+//      part_block_manip.rs:34-35,62-63) this restatement iterates in ascending counter_id.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../include/floria_hip.h"
+
+namespace {
+
+// ---- constants.rs ------------------------------------------------------------------------------
+constexpr int    NUM_ITER_OPTIMIZE = 20;      // constants.rs:3
+constexpr double DIV_FACTOR        = 0.25;    // constants.rs:5
+constexpr double PROB_CUTOFF       = 0.01;    // constants.rs:6
+// USE_QUAL_SCORES = true (:15), SEPARATE_BROKEN_HAPLOGROUPS = true (:17), WEIRD_SPLIT = false (:18),
+// MERGE_SIMILAR_HAPLOGROUPS = false (:16)
+
+thread_local std::string g_err;
+
+// ---- phred_scale (utils_frags.rs:702-711) ---------------------------------------------------------
+// prob = 1f32 - 10f32.powf(q as f32 / -10.), widened to f64.  Always k * 2^-24 (checked below).
+struct WeightLut {
+    uint32_t q24[256];
+    WeightLut() {
+        for (int q = 0; q < 256; ++q) {
+            float x    = (float)q / -10.0f;
+            float prob = 1.0f - powf(10.0f, x);
+            double s   = (double)prob * 16777216.0;
+            uint32_t k = (uint32_t)s;
+            if ((double)k != s) { fprintf(stderr, "oracle: w(%d) is not a multiple of 2^-24\n", q); abort(); }
+            q24[q] = k;
+        }
+    }
+};
+const WeightLut g_w;
+
+// value = Q*2^-24 + m*eps  (canonicalisation (1))
+inline double qm_to_f64(uint64_t q, uint64_t m, double eps) {
+    return (double)q * 0x1p-24 + (double)m * eps;
+}
+
+// ---- Frag (types_structs.rs:68-112) as a view into the CSR pileup -----------------------------------
+struct Pile {
+    const floria_pileup* p;
+    uint32_t n() const { return p->n_reads; }
+    uint32_t beg(uint32_t r) const { return p->read_off[r]; }
+    uint32_t end(uint32_t r) const { return p->read_off[r + 1]; }
+};
+
+// ---- Haplotype: pos -> {allele -> count} (types_structs.rs:15) ----------------------------------------
+struct Site {
+    uint64_t q[FLORIA_MAX_ALLELES];   // Q24 sum (or unit count when !use_qual)
+    uint8_t  present;                 // bitmask of allele keys that exist in the inner map
+    bool operator==(const Site& o) const {
+        if (present != o.present) return false;
+        for (int a = 0; a < FLORIA_MAX_ALLELES; ++a)
+            if (((present >> a) & 1) && q[a] != o.q[a]) return false;
+        return true;
+    }
+};
+
+// open-addressing hash map u32 -> Site (FxHash multiplier; linear probing; tombstone-free because
+// the only removal pattern is "drop every key < x", done by rebuild)
+class Hap {
+public:
+    Hap() : mask_(0), len_(0) {}
+    size_t len() const { return len_; }
+    Site* find(uint32_t pos) {
+        if (!len_) return nullptr;
+        size_t i = slot(pos);
+        while (keys_[i] != EMPTY) {
+            if (keys_[i] == pos) return &vals_[i];
+            i = (i + 1) & mask_;
+        }
+        return nullptr;
+    }
+    const Site* find(uint32_t pos) const { return const_cast<Hap*>(this)->find(pos); }
+    Site& entry(uint32_t pos) {              // entry(pos).or_insert(default)
+        if ((len_ + 1) * 8 > (mask_ + 1) * 7 || keys_.empty()) grow();
+        size_t i = slot(pos);
+        while (keys_[i] != EMPTY) {
+            if (keys_[i] == pos) return vals_[i];
+            i = (i + 1) & mask_;
+        }
+        keys_[i] = pos;
+        memset(&vals_[i], 0, sizeof(Site));
+        ++len_;
+        return vals_[i];
+    }
+    template <class F> void for_each(F f) const {
+        for (size_t i = 0; i < keys_.size(); ++i)
+            if (keys_[i] != EMPTY) f(keys_[i], vals_[i]);
+    }
+    // block_vec[i].remove(pos) for every pos < cut (types_structs.rs:346-360)
+    void drop_below(uint32_t cut) {
+        bool any = false;
+        for (size_t i = 0; i < keys_.size(); ++i)
+            if (keys_[i] != EMPTY && keys_[i] < cut) { any = true; break; }
+        if (!any) return;
+        std::vector<uint32_t> k; std::vector<Site> v;
+        k.swap(keys_); v.swap(vals_);
+        size_t cap = k.size();
+        keys_.assign(cap, EMPTY); vals_.resize(cap); len_ = 0;
+        for (size_t i = 0; i < cap; ++i)
+            if (k[i] != EMPTY && k[i] >= cut) { entry(k[i]) = v[i]; }
+    }
+    bool operator==(const Hap& o) const {     // deep map equality (global_clustering.rs:124)
+        if (len_ != o.len_) return false;
+        bool eq = true;
+        for_each([&](uint32_t pos, const Site& s) {
+            if (!eq) return;
+            const Site* t = o.find(pos);
+            if (!t || !(*t == s)) eq = false;
+        });
+        return eq;
+    }
+private:
+    static constexpr uint32_t EMPTY = 0xffffffffu;
+    size_t slot(uint32_t pos) const { return (size_t)(((uint64_t)pos * 0x517cc1b727220a95ull) >> 32) & mask_; }
+    void grow() {
+        size_t ncap = keys_.empty() ? 8 : keys_.size() * 2;
+        std::vector<uint32_t> k; std::vector<Site> v;
+        k.swap(keys_); v.swap(vals_);
+        keys_.assign(ncap, EMPTY); vals_.resize(ncap); mask_ = ncap - 1; len_ = 0;
+        for (size_t i = 0; i < k.size(); ++i)
+            if (k[i] != EMPTY) entry(k[i]) = v[i];
+    }
+    std::vector<uint32_t> keys_;
+    std::vector<Site>     vals_;
+    size_t mask_, len_;
+};
+
+struct HapBlock {                              // types_structs.rs:253-256
+    std::vector<Hap> blocks;
+    bool operator==(const HapBlock& o) const { return blocks == o.blocks; }
+};
+
+// sites.entry(allele).or_insert(0.) += w   (utils_frags.rs:166-172, types_structs.rs:368-373)
+inline void site_add(Site& s, uint8_t allele, uint64_t w) {
+    s.present |= (uint8_t)(1u << allele);
+    s.q[allele] += w;
+}
+
+// ---- set_to_seq_dict / hap_block_from_partition (utils_frags.rs:160-184) ------------------------------
+Hap set_to_seq_dict(const Pile& P, const std::vector<uint32_t>& frag_set, bool use_phred) {
+    Hap h;
+    for (uint32_t r : frag_set)
+        for (uint32_t c = P.beg(r); c < P.end(r); ++c)
+            site_add(h.entry(P.p->snp[c]), P.p->allele[c], use_phred ? g_w.q24[P.p->qual[c]] : 1);
+    return h;
+}
+HapBlock hap_block_from_partition(const Pile& P, const std::vector<std::vector<uint32_t>>& part, bool use_qual) {
+    HapBlock b;
+    for (auto& s : part) b.blocks.push_back(set_to_seq_dict(P, s, use_qual));
+    return b;
+}
+
+// ---- distance_read_haplo_epsilon_empty (utils_frags.rs:32-75) ------------------------------------------
+struct SD { uint64_t same, diff, m; };   // same = Q24, diff = Q24 + m*eps
+inline SD distance_read_haplo_epsilon_empty(const Pile& P, uint32_t r, const Hap& hap) {
+    SD d{0, 0, 0};
+    for (uint32_t c = P.beg(r); c < P.end(r); ++c) {
+        const Site* s = hap.find(P.p->snp[c]);
+        uint64_t mx = 0;                                   // :36-44 empty_pos <=> no non-zero count
+        if (s) for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) mx = std::max(mx, s->q[a]);
+        if (mx == 0) { d.m += 1; continue; }               // :45-48 diff += epsilon
+        uint8_t a = P.p->allele[c];
+        uint64_t w = g_w.q24[P.p->qual[c]];
+        // :52-71  same if the read's allele is (tied for) the consensus, else diff
+        bool has = (s->present >> a) & 1;
+        if (has && s->q[a] == mx) d.same += w; else d.diff += w;
+    }
+    return d;
+}
+
+// ---- stable_binom_cdf_p_rev / log_sum_exp (utils_frags.rs:211-258) ---------------------------------------
+double stable_binom_cdf_p_rev(uint64_t n, uint64_t k, double p, double div_factor) {
+    if (n == 0) return 0.0;
+    double n64 = (double)n, k64 = (double)k;
+    double a = k64 / n64;
+    if (a == 1.0) a = 0.9999999;
+    if (a == 0.0) a = 0.0000001;
+    double rel_ent = a * std::log(a / p) + (1.0 - a) * std::log((1.0 - a) / (1.0 - p));
+    if (a < p) rel_ent = -rel_ent;
+    return -1.0 * n64 / div_factor * rel_ent;
+}
+double log_sum_exp(const std::vector<double>& probs) {
+    double mx = std::numeric_limits<double>::quiet_NaN();
+    for (double v : probs) mx = std::isnan(mx) ? v : (std::isnan(v) ? mx : std::max(mx, v));   // f64::max ignores NaN
+    double sum = 0.0;
+    for (double v : probs) sum += std::exp(v - mx);
+    return mx + std::log(sum);
+}
+inline uint64_t f64_as_usize(double x) {           // Rust `as usize`: truncating, saturating, NaN -> 0
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551615.0) return UINT64_MAX;
+    return (uint64_t)x;
+}
+
+// ---- std::collections::BinaryHeap on (score, payload) ------------------------------
+// Ordering of (Rc<SearchNode>, HapBlock): SearchNode::cmp = score (types_structs.rs:127-131), then
+// HapBlock::cmp = blocks.len() (:258-262, always equal) => ties compare Equal.
+struct HeapItem {
+    double   score;
+    int      node;       // index into the node arena
+    HapBlock block;
+};
+struct BinaryHeap {
+    std::vector<HeapItem> data;
+    static bool le(const HeapItem& a, const HeapItem& b) { return a.score <= b.score; }
+    static bool lt(const HeapItem& a, const HeapItem& b) { return a.score <  b.score; }
+    static bool ge(const HeapItem& a, const HeapItem& b) { return a.score >= b.score; }
+    size_t len() const { return data.size(); }
+    size_t sift_up(size_t start, size_t pos) {
+        HeapItem hole = std::move(data[pos]);
+        while (pos > start) {
+            size_t parent = (pos - 1) / 2;
+            if (le(hole, data[parent])) break;
+            data[pos] = std::move(data[parent]);
+            pos = parent;
+        }
+        data[pos] = std::move(hole);
+        return pos;
+    }
+    void push(HeapItem&& it) {
+        size_t old_len = data.size();
+        data.push_back(std::move(it));
+        sift_up(0, old_len);
+    }
+    void sift_down_to_bottom(size_t pos) {
+        size_t end = data.size(), start = pos;
+        HeapItem hole = std::move(data[pos]);
+        size_t child = 2 * pos + 1;
+        while (child <= (end >= 2 ? end - 2 : 0)) {
+            child += le(data[child], data[child + 1]) ? 1 : 0;
+            data[pos] = std::move(data[child]);
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) { data[pos] = std::move(data[child]); pos = child; }
+        data[pos] = std::move(hole);
+        sift_up(start, pos);
+    }
+    void pop() {                                  // discards the max (worst MEC) element
+        HeapItem item = std::move(data.back());
+        data.pop_back();
+        if (!data.empty()) { std::swap(item, data[0]); sift_down_to_bottom(0); }
+    }
+    void sift_down_range(size_t pos, size_t end) {
+        HeapItem hole = std::move(data[pos]);
+        size_t child = 2 * pos + 1;
+        while (child <= (end >= 2 ? end - 2 : 0)) {
+            child += le(data[child], data[child + 1]) ? 1 : 0;
+            if (ge(hole, data[child])) { data[pos] = std::move(hole); return; }
+            data[pos] = std::move(data[child]);
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1 && lt(hole, data[child])) { data[pos] = std::move(data[child]); pos = child; }
+        data[pos] = std::move(hole);
+    }
+    void into_sorted_vec() {
+        size_t end = data.size();
+        while (end > 1) { --end; std::swap(data[0], data[end]); sift_down_range(0, end); }
+    }
+};
+
+// ---- SearchNode (types_structs.rs:114-125) -------------------------------------------------------------
+struct SearchNode {
+    uint32_t read; int part; int parent;
+    uint64_t diff_q, diff_m;       // sum over partitions of error_vec[k].1 ("mec", global_clustering.rs:202)
+    double   score;
+};
+
+// ---- build_truncated_hap_block (types_structs.rs:326-376); broken_blocks bookkeeping (:340-366) is dead
+// w.r.t. results because WEIRD_SPLIT=false (graph_processing.rs:166-181) -------------------------------------
+HapBlock build_truncated_hap_block(const Pile& P, const HapBlock& block, uint32_t r, int part, uint32_t current_startpos) {
+    HapBlock nb; nb.blocks = block.blocks;                       // manual deepcopy :337
+    for (auto& h : nb.blocks) h.drop_below(current_startpos);    // :356-358
+    for (uint32_t c = P.beg(r); c < P.end(r); ++c)               // :368-373
+        site_add(nb.blocks[part].entry(P.p->snp[c]), P.p->allele[c], g_w.q24[P.p->qual[c]]);
+    return nb;
+}
+
+// ---- beam_search_phasing (global_clustering.rs:10-179) with read_to_node_value (:181-208) --------------------
+// clique = vec![FxHashSet::default(); ploidy] (graph_processing.rs:141) => frag_in_clique is always false.
+void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, int ploidy, double epsilon,
+                         double div_factor, double cutoff_value, size_t max_number_solns,
+                         std::vector<std::vector<uint32_t>>& partition, double* min_margin) {
+    partition.assign(ploidy, {});
+    if (all_reads.empty()) return;                                                    // :24-26
+    std::vector<SearchNode> arena;
+    arena.push_back(SearchNode{all_reads[0], -1, -1, 0, 0, 0.0});                     // first_node :34-44
+    BinaryHeap heap;
+    { HeapItem it; it.score = 0.0; it.node = 0; it.block.blocks.assign(ploidy, Hap()); heap.push(std::move(it)); }
+    std::vector<double> p_value_list(ploidy);
+    std::vector<SD> sd(ploidy);
+    for (size_t i = 0; i < all_reads.size(); ++i) {
+        size_t max_num_soln_mut = max_number_solns;
+        if (i < 25) max_num_soln_mut = (size_t)ploidy * max_number_solns;              // :50-53
+        BinaryHeap next;
+        uint32_t frag = all_reads[i];
+        uint32_t current_startpos = P.p->first[frag];
+        for (size_t h = 0; h < heap.data.size(); ++h) {                                // heap.iter() = Vec order :71
+            const HeapItem& cur = heap.data[h];
+            for (int k = 0; k < ploidy; ++k) {                                         // :74-91
+                sd[k] = distance_read_haplo_epsilon_empty(P, frag, cur.block.blocks[k]);
+                double same = qm_to_f64(sd[k].same, 0, epsilon);
+                double diff = qm_to_f64(sd[k].diff, sd[k].m, epsilon);
+                p_value_list[k] = 1.0 * stable_binom_cdf_p_rev(f64_as_usize(same + diff), f64_as_usize(diff), epsilon, div_factor);
+            }
+            double lse = log_sum_exp(p_value_list);                                    // :93
+            for (int j = 0; j < ploidy; ++j) {
+                double margin = (p_value_list[j] - lse) - cutoff_value;
+                if (min_margin && std::fabs(margin) < *min_margin) *min_margin = std::fabs(margin);
+                if (p_value_list[j] - lse > cutoff_value) {                            // :98
+                    // read_to_node_value :181-208 (recomputes the same distance :193)
+                    const SearchNode& pn = arena[cur.node];
+                    SearchNode nn;
+                    nn.read = frag; nn.part = j; nn.parent = cur.node;
+                    nn.diff_q = pn.diff_q + sd[j].diff;
+                    nn.diff_m = pn.diff_m + sd[j].m;
+                    nn.score  = qm_to_f64(nn.diff_q, nn.diff_m, epsilon);               // new_node_score = -(-mec) :105
+                    HapBlock new_block = build_truncated_hap_block(P, cur.block, frag, j, current_startpos);   // :118
+                    bool project_exists = false;                                       // :122-127
+                    for (const HeapItem& e : next.data)
+                        if (e.block == new_block && e.score >= nn.score) project_exists = true;
+                    if (!project_exists) {
+                        arena.push_back(nn);
+                        HeapItem it; it.score = nn.score; it.node = (int)arena.size() - 1; it.block = std::move(new_block);
+                        next.push(std::move(it));                                      // :130
+                        if (next.len() > max_num_soln_mut) next.pop();                 // :132-134
+                    }
+                }
+            }
+        }
+        heap.data.swap(next.data);                                                     // :145
+    }
+    heap.into_sorted_vec();                                                            // :149
+    int np = heap.data[0].node;                                                        // :150
+    while (arena[np].parent >= 0) {                                                    // :155-176
+        partition[arena[np].part].push_back(arena[np].read);
+        np = arena[np].parent;
+    }
+    for (auto& s : partition) std::sort(s.begin(), s.end());                            // canonical set order
+}
+
+// ---- get_mec_stats_epsilon (local_clustering.rs:218-260, use_gaps=true) and _no_phred (:187-215) ---------
+struct QM { uint64_t bases, errors, m; };
+std::vector<QM> mec_stats_of_block(const HapBlock& hb, uint64_t one) {
+    std::vector<QM> v;
+    for (const Hap& hap : hb.blocks) {
+        QM s{0, 0, 0};
+        hap.for_each([&](uint32_t, const Site& site) {
+            if (!site.present) return;                           // allele_counts.is_empty() -> continue
+            uint64_t mx = 0, tot = 0;
+            for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((site.present >> a) & 1) { mx = std::max(mx, site.q[a]); tot += site.q[a]; }
+            s.bases += mx;                                       // cons_bases = last after sort
+            s.errors += tot - mx;                                // all but the last
+            if (mx <= one) s.m += 1;                             // cons_bases <= 1. -> errors += epsilon
+        });
+        v.push_back(s);
+    }
+    return v;
+}
+
+// ---- opt_iterate (local_clustering.rs:292-358) -------------------------------------------------------------
+struct Move { double gain; int i; uint32_t read; int j; };
+std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<std::vector<uint32_t>>& partition,
+                                               const HapBlock& hap_block, double epsilon) {
+    int ploidy = (int)partition.size();
+    std::vector<Move> best_moves;
+    for (int i = 0; i < ploidy; ++i) {
+        if (partition[i].size() <= 1) continue;                                          // :300-302
+        for (uint32_t read : partition[i]) {                                             // canonical: ascending id (2)
+            SD own = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[i]);
+            double errors_read = qm_to_f64(own.diff, own.m, epsilon);
+            for (int j = 0; j < ploidy; ++j) {
+                if (j == i) continue;
+                SD oth = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[j]);
+                double read_errors_movej = qm_to_f64(oth.diff, oth.m, epsilon);
+                double diff_score = errors_read - read_errors_movej;                     // :320
+                if (diff_score > 0.0) best_moves.push_back(Move{diff_score, i, read, j});
+            }
+        }
+    }
+    std::vector<std::vector<uint32_t>> new_part = partition;                               // :329
+    std::vector<size_t> sizes(ploidy);
+    for (int i = 0; i < ploidy; ++i) sizes[i] = partition[i].size();
+    std::stable_sort(best_moves.begin(), best_moves.end(), [](const Move& a, const Move& b) { return a.gain > b.gain; });   // :330
+    size_t number_of_moves = best_moves.size() / 10;                                       // :336
+    if (number_of_moves == 0 && !best_moves.empty()) number_of_moves = best_moves.size() / 3 + 1;
+    std::vector<uint8_t> moved(P.n(), 0);   // moved_reads
+    std::vector<std::pair<uint32_t, std::pair<int, int>>> applied;
+    for (size_t mv_num = 0; mv_num < best_moves.size(); ++mv_num) {                         // :342-356
+        const Move& mv = best_moves[mv_num];
+        if (moved[mv.read]) continue;
+        if (sizes[mv.i] == 1) continue;
+        applied.push_back({mv.read, {mv.i, mv.j}});
+        sizes[mv.j] += 1; sizes[mv.i] -= 1;
+        moved[mv.read] = 1;
+        if (mv_num > number_of_moves) break;
+    }
+    for (auto& a : applied) {
+        auto& src = new_part[a.second.first];
+        src.erase(std::lower_bound(src.begin(), src.end(), a.first));
+        auto& dst = new_part[a.second.second];
+        dst.insert(std::lower_bound(dst.begin(), dst.end(), a.first), a.first);
+    }
+    return new_part;
+}
+
+// ---- optimize_clustering (local_clustering.rs:71-130) -------------------------------------------------------
+double mec_score_of(const std::vector<QM>& v, double epsilon) {
+    double s = 0.0;                                   // binom_vec.iter().map(|x| x.1).sum()
+    for (const QM& x : v) s += qm_to_f64(x.errors, x.m, epsilon);
+    return s * -1.0;
+}
+std::vector<std::vector<uint32_t>> optimize_clustering(const Pile& P, std::vector<std::vector<uint32_t>> partition,
+                                                       double epsilon, int max_iters, int* iters_done) {
+    bool not_empty = false;
+    for (auto& p : partition) if (!p.empty()) not_empty = true;
+    if (iters_done) *iters_done = 0;
+    if (!not_empty) return partition;                                                    // :82-85
+    HapBlock prev_hap_block = hap_block_from_partition(P, partition, true);
+    double prev_score = mec_score_of(mec_stats_of_block(prev_hap_block, 1u << 24), epsilon);   // :97-99
+    std::vector<std::vector<uint32_t>> best_part = std::move(partition);
+    for (int i = 0; i < max_iters; ++i) {                                                // :105-127
+        auto new_part = opt_iterate(P, best_part, prev_hap_block, epsilon);
+        HapBlock new_block = hap_block_from_partition(P, new_part, true);
+        double new_score = mec_score_of(mec_stats_of_block(new_block, 1u << 24), epsilon);
+        if (iters_done) *iters_done = i + 1;
+        if (new_score > prev_score) { prev_score = new_score; best_part = std::move(new_part); prev_hap_block = std::move(new_block); }
+        else return best_part;
+    }
+    return best_part;
+}
+
+// ---- find_reads_in_interval (local_clustering.rs:12-59, max_num_reads = usize::MAX) --------------------------
+std::vector<uint32_t> find_reads_in_interval(const Pile& P, uint32_t start, uint32_t end) {
+    std::vector<uint32_t> out;
+    for (uint32_t r = 0; r < P.n(); ++r) {
+        if (P.p->last[r] < start) continue;                        // :36-38
+        if (P.p->first[r] > end) break;                            // :39-41
+        if (P.p->last[r] - P.p->first[r] > 10000) continue;        // :44-46
+        out.push_back(r);
+    }
+    return out;   // ascending counter_id == Frag::cmp order (reads.sort(), graph_processing.rs:139)
+}
+
+// ---- get_local_hap_blocks (graph_processing.rs:103-304) -------------------------------------------------------
+struct BlockOut { uint32_t best_ploidy = 0, tried = 0; std::vector<uint32_t> reads; std::vector<uint8_t> part; std::vector<double> mec; double min_margin; };
+
+void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const floria_params& o, BlockOut& out) {
+    const int max_ploidy = (int)o.max_ploidy;
+    const double epsilon = o.epsilon;
+    out.mec.assign(max_ploidy, 0.0);
+    out.min_margin = std::numeric_limits<double>::infinity();
+    std::vector<double> expected_errors_ref;
+    std::vector<std::vector<std::vector<uint32_t>>> parts_vector;
+    std::vector<uint32_t> reads = find_reads_in_interval(P, start, end);                  // :121-126
+    out.reads = reads;
+    if (reads.empty()) { out.best_ploidy = 0; return; }                                   // :129-131 -> None
+    int best_ploidy = 1;
+    const double cutoff = std::log(PROB_CUTOFF);                                          // :146
+    for (int ploidy = 1; ploidy <= max_ploidy; ++ploidy) {                                // :132
+        best_ploidy = ploidy;
+        out.tried = ploidy;
+        double num_alleles = 0.0;
+        std::vector<std::vector<uint32_t>> part;
+        beam_search_phasing(P, reads, ploidy, epsilon, DIV_FACTOR, cutoff, o.beam, part, &out.min_margin);   // :140-151
+        auto optimized_part = optimize_clustering(P, std::move(part), epsilon, NUM_ITER_OPTIMIZE, nullptr);  // :153-154
+        HapBlock np = hap_block_from_partition(P, optimized_part, false);                   // :156 (_no_phred)
+        for (const QM& s : mec_stats_of_block(np, 1)) {                                     // :158-162
+            double good = (double)s.bases;
+            double bad  = (double)s.errors + (double)s.m * epsilon;
+            out.mec[ploidy - 1] += bad;
+            num_alleles += good;
+            num_alleles += bad;
+        }
+        parts_vector.push_back(optimized_part);
+        expected_errors_ref.push_back(num_alleles * epsilon);                               // :196
+        if (ploidy > 1) {                                                                   // :198-246
+            double mec_threshold;
+            if (o.ploidy_sensitivity == 1)      mec_threshold = 1.0 / (1.0 - epsilon) / (1.0 + 1.0 / (std::pow((double)ploidy, 0.50) + 1.00));
+            else if (o.ploidy_sensitivity == 2) mec_threshold = 1.0 / (1.0 - epsilon) / (1.0 + 1.0 / (std::pow((double)ploidy, 1.00) + 1. / 3.));
+            else                                mec_threshold = 1.0 / (1.0 - epsilon) / (1.0 + 1.0 / (std::pow((double)ploidy, 1.00) + 1.00));
+            if ((out.mec[ploidy - 1] / out.mec[ploidy - 2]) < mec_threshold) { /* do nothing */ }
+            else if (o.stopping_heuristic) { best_ploidy -= 1; break; }
+            if (out.mec[ploidy - 1] < expected_errors_ref[ploidy - 1]) break;
+        } else {
+            if (out.mec[ploidy - 1] < expected_errors_ref[ploidy - 1]) break;               // :247-250
+        }
+    }
+    out.best_ploidy = best_ploidy;
+    const auto& bp = parts_vector[best_ploidy - 1];                                         // :268
+    out.part.assign(reads.size(), 0);
+    for (int k = 0; k < (int)bp.size(); ++k)
+        for (uint32_t r : bp[k]) {
+            size_t idx = std::lower_bound(reads.begin(), reads.end(), r) - reads.begin();
+            out.part[idx] = (uint8_t)k;
+        }
+}
+
+// ---- get_range_with_lengths (utils_frags.rs:405-463) ----------------------------------------------------------
+int range_with_lengths(const uint64_t* g, uint32_t n, uint64_t block_length, uint64_t overlap_len, double minimal_density,
+                       std::vector<std::pair<uint32_t, uint32_t>>& ret) {
+    ret.clear();
+    if (n == 0) { g_err = "empty snp_to_genome_pos (reference panics on index 0)"; return FLORIA_E_INVALID; }
+    uint64_t cum_pos = 0, last_pos = g[0];
+    uint32_t left_endpoint = 0, new_left_end = 0;
+    bool hit_new_left = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t pos = g[i];
+        if (i == n - 1) { ret.push_back({left_endpoint, i}); break; }
+        if (pos < last_pos) { g_err = "VCF malformed. Positions are not increasing"; return FLORIA_E_INVALID; }
+        cum_pos += pos - last_pos;
+        last_pos = pos;
+        if (cum_pos > block_length - overlap_len && !hit_new_left) { new_left_end = i; hit_new_left = true; }
+        if (cum_pos > block_length) {
+            cum_pos = 0;
+            double snp_density = (double)(i - left_endpoint) / (double)block_length;
+            if (snp_density > minimal_density) ret.push_back({left_endpoint, i - 1});
+            if (g[new_left_end] + block_length < g[new_left_end + 1]) left_endpoint = new_left_end;
+            else left_endpoint = new_left_end + 1;
+            last_pos = g[left_endpoint];
+            hit_new_left = false;
+        }
+    }
+    for (auto& x : ret) { x.first += 1; x.second += 1; }
+    return 0;
+}
+
+// ---- process_reads_for_final_parts (part_block_manip.rs:174-274), reassign_short=false -----------------------------
+void add_read_to_block(const Pile& P, Hap& h, uint32_t r) {                              // utils_frags.rs:465-474
+    for (uint32_t c = P.beg(r); c < P.end(r); ++c)
+        site_add(h.entry(P.p->snp[c]), P.p->allele[c], g_w.q24[P.p->qual[c]]);
+}
+void remove_read_from_block(const Pile& P, Hap& h, uint32_t r) {                         // utils_frags.rs:476-490
+    for (uint32_t c = P.beg(r); c < P.end(r); ++c) {
+        Site& s = h.entry(P.p->snp[c]);
+        uint8_t a = P.p->allele[c];
+        if (!((s.present >> a) & 1)) { s.present |= (uint8_t)(1u << a); s.q[a] = 0; }    // or_insert(0.)
+        if (s.q[a] != 0) s.q[a] -= g_w.q24[P.p->qual[c]];
+        if (s.q[a] == 0) { s.present &= (uint8_t)~(1u << a); }                           // <= 0 -> remove key (exact arithmetic: never negative)
+    }
+}
+
+void separate_broken_haplogroups(const Pile& P, std::vector<std::vector<uint32_t>>& parts,
+                                 std::vector<std::pair<uint32_t, uint32_t>>& ranges) {     // part_block_manip.rs:27-98
+    std::vector<std::pair<size_t, std::vector<uint32_t>>> all_breaks;
+    for (size_t i = 0; i < ranges.size(); ++i) {
+        // ascending id is already sorted by first_position (Frag::cmp); stable sort keeps it (canonical (2))
+        uint32_t current_lastest_pos = 0;
+        std::vector<uint32_t> breaks;
+        for (uint32_t r : parts[i]) {
+            if (current_lastest_pos != 0 && P.p->first[r] > current_lastest_pos)
+                if (current_lastest_pos >= ranges[i].first && current_lastest_pos < ranges[i].second) breaks.push_back(current_lastest_pos);
+            if (P.p->last[r] > current_lastest_pos) current_lastest_pos = P.p->last[r];
+        }
+        if (!breaks.empty()) all_breaks.push_back({i, breaks});
+    }
+    std::vector<std::vector<uint32_t>> new_parts;
+    std::vector<std::pair<uint32_t, uint32_t>> new_ranges;
+    for (auto& bi : all_breaks) {
+        size_t spot_index = 0;
+        auto& break_spots = bi.second;
+        uint32_t break_start = ranges[bi.first].first;
+        uint32_t end_spot = break_spots[spot_index];
+        std::vector<uint32_t> new_part;
+        for (uint32_t r : parts[bi.first]) {
+            if (P.p->last[r] <= end_spot) new_part.push_back(r);
+            else {                                                   // :69-84 — the read that trips the split is dropped
+                new_parts.push_back(new_part);
+                new_ranges.push_back({break_start, end_spot});
+                break_start = end_spot + 1;
+                spot_index += 1;
+                if (spot_index != break_spots.size()) end_spot = break_spots[spot_index];
+                else end_spot = UINT32_MAX;
+                new_part.clear();
+            }
+        }
+        new_parts.push_back(new_part);
+        new_ranges.push_back({break_start, ranges[bi.first].second});
+    }
+    for (auto& bi : all_breaks) parts[bi.first].clear();
+    for (size_t i = 0; i < new_parts.size(); ++i) { parts.push_back(new_parts[i]); ranges.push_back(new_ranges[i]); }
+}
+
+void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32_t>>& parts,
+                                   std::vector<std::pair<uint32_t, uint32_t>>& ranges, double epsilon) {
+    HapBlock block = hap_block_from_partition(P, parts, true);                              // :184
+    std::vector<std::vector<uint32_t>> read_to_parts(P.n());                                 // :185-193
+    for (size_t i = 0; i < parts.size(); ++i)
+        for (uint32_t r : parts[i]) {
+            auto& v = read_to_parts[r];
+            if (std::find(v.begin(), v.end(), (uint32_t)i) == v.end()) v.push_back((uint32_t)i);
+        }
+    for (uint32_t r = 0; r < P.n(); ++r)                                                     // :195-200
+        for (uint32_t id : read_to_parts[r]) remove_read_from_block(P, block.blocks[id], r);
+    for (auto& p : parts) p.clear();
+    for (uint32_t r = 0; r < P.n(); ++r) {                                                   // :203-222, canonical order (2)
+        if (read_to_parts[r].empty()) continue;
+        bool have = false; double bd = 0, bs = 0; uint32_t bid = 0;
+        for (uint32_t id : read_to_parts[r]) {
+            SD d = distance_read_haplo_epsilon_empty(P, r, block.blocks[id]);
+            double key_d = qm_to_f64(d.diff, d.m, epsilon) + 1.;                             // (diff + 1., id, same)
+            double key_s = qm_to_f64(d.same, 0, epsilon);
+            bool less = !have || key_d < bd || (key_d == bd && (id < bid || (id == bid && key_s < bs)));
+            if (less) { have = true; bd = key_d; bs = key_s; bid = id; }
+        }
+        parts[bid].push_back(r);
+        add_read_to_block(P, block.blocks[bid], r);
+    }
+    separate_broken_haplogroups(P, parts, ranges);                                            // :231-233
+    // sort_parts :276-288 — stable sort by range
+    std::vector<size_t> idx(parts.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ranges[a] < ranges[b]; });
+    std::vector<std::vector<uint32_t>> np; std::vector<std::pair<uint32_t, uint32_t>> nr;
+    for (size_t i : idx) { np.push_back(parts[i]); nr.push_back(ranges[i]); }
+    parts.swap(np); ranges.swap(nr);
+}
+
+int validate(const floria_pileup* p) {
+    if (!p || (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last))) { g_err = "null pileup field"; return FLORIA_E_INVALID; }
+    for (uint32_t r = 0; r < p->n_reads; ++r) {
+        uint32_t b = p->read_off[r], e = p->read_off[r + 1];
+        if (e <= b) { g_err = "read with no cells"; return FLORIA_E_INVALID; }
+        if (p->snp[b] != p->first[r] || p->snp[e - 1] != p->last[r]) { g_err = "first/last do not match cells"; return FLORIA_E_INVALID; }
+        for (uint32_t c = b; c < e; ++c) {
+            if (c > b && p->snp[c] <= p->snp[c - 1]) { g_err = "cells not strictly ascending"; return FLORIA_E_INVALID; }
+            if (p->allele[c] >= FLORIA_MAX_ALLELES) { g_err = "allele index > 3"; return FLORIA_E_UNSUPPORTED; }
+        }
+        if (r > 0) {   // Frag::cmp order (types_structs.rs:87-93)
+            bool ok = p->first[r - 1] < p->first[r] || (p->first[r - 1] == p->first[r] && p->last[r - 1] >= p->last[r]);
+            if (!ok) { g_err = "reads not sorted by Frag::cmp"; return FLORIA_E_INVALID; }
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ==================================================================================================
+extern "C" {
+
+const char* floria_oracle_last_error(void) { return g_err.c_str(); }
+
+int floria_oracle_weight_q24(uint32_t* out256) { memcpy(out256, g_w.q24, sizeof(g_w.q24)); return 0; }
+
+int floria_oracle_block_ranges(const uint64_t* snp_to_genome_pos, uint32_t n_snps, uint64_t block_length,
+                               uint64_t overlap_len, double minimal_density, floria_ranges** out) {
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    int rc = range_with_lengths(snp_to_genome_pos, n_snps, block_length, overlap_len, minimal_density, v);
+    if (rc) return rc;
+    floria_ranges* r = (floria_ranges*)calloc(1, sizeof(floria_ranges));
+    r->n = (uint32_t)v.size();
+    r->start = (uint32_t*)malloc(sizeof(uint32_t) * (v.size() + 1));
+    r->end   = (uint32_t*)malloc(sizeof(uint32_t) * (v.size() + 1));
+    for (size_t i = 0; i < v.size(); ++i) { r->start[i] = v[i].first; r->end[i] = v[i].second; }
+    *out = r;
+    return 0;
+}
+void floria_oracle_ranges_free(floria_ranges* r) { if (r) { free(r->start); free(r->end); free(r); } }
+
+// S1 for a batch of blocks, `threads` worker threads pulling blocks from a shared counter
+// (graph_processing.rs:345-362: one rayon task per block).
+int floria_oracle_phase_blocks(const floria_pileup* pileup, const uint32_t* blk_start, const uint32_t* blk_end,
+                               uint32_t n_blocks, const floria_params* params, uint32_t threads,
+                               floria_block_result** out) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    if (!params || params->max_ploidy < 1 || params->max_ploidy > FLORIA_MAX_PLOIDY || params->beam < 1) { g_err = "bad params"; return FLORIA_E_INVALID; }
+    Pile P{pileup};
+    std::vector<BlockOut> outs(n_blocks);
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t b = next.fetch_add(1);
+            if (b >= n_blocks) break;
+            get_local_hap_blocks(P, blk_start[b], blk_end[b], *params, outs[b]);
+        }
+    };
+    if (threads <= 1) worker();
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < threads; ++t) th.emplace_back(worker); for (auto& t : th) t.join(); }
+
+    floria_block_result* R = (floria_block_result*)calloc(1, sizeof(floria_block_result));
+    R->n_blocks = n_blocks; R->max_ploidy = params->max_ploidy;
+    R->best_ploidy = (uint32_t*)calloc(n_blocks + 1, sizeof(uint32_t));
+    R->ploidies_tried = (uint32_t*)calloc(n_blocks + 1, sizeof(uint32_t));
+    R->read_off = (uint64_t*)calloc(n_blocks + 1, sizeof(uint64_t));
+    R->mec = (double*)calloc((size_t)n_blocks * params->max_ploidy + 1, sizeof(double));
+    uint64_t tot = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) { R->read_off[b] = tot; tot += outs[b].reads.size(); }
+    R->read_off[n_blocks] = tot;
+    R->read_id = (uint32_t*)malloc(sizeof(uint32_t) * (tot + 1));
+    R->part = (uint8_t*)malloc(tot + 1);
+    R->min_prune_margin = std::numeric_limits<double>::infinity();
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        R->best_ploidy[b] = outs[b].best_ploidy;
+        R->ploidies_tried[b] = outs[b].tried;
+        for (size_t i = 0; i < outs[b].reads.size(); ++i) {
+            R->read_id[R->read_off[b] + i] = outs[b].reads[i];
+            R->part[R->read_off[b] + i] = outs[b].part.empty() ? 0 : outs[b].part[i];
+        }
+        for (uint32_t p = 0; p < params->max_ploidy; ++p) R->mec[(size_t)b * params->max_ploidy + p] = outs[b].mec.empty() ? 0.0 : outs[b].mec[p];
+        if (outs[b].best_ploidy && outs[b].min_margin < R->min_prune_margin) R->min_prune_margin = outs[b].min_margin;
+    }
+    *out = R;
+    return 0;
+}
+void floria_oracle_block_result_free(floria_block_result* r) {
+    if (!r) return;
+    free(r->best_ploidy); free(r->ploidies_tried); free(r->read_off); free(r->read_id); free(r->part); free(r->mec); free(r);
+}
+
+// Beam search + optimise for ONE ploidy of one block (unit-test hook): partition after beam search
+// (part_beam) and after optimize_clustering (part_opt), plus the two MEC figures.
+int floria_oracle_one_ploidy(const floria_pileup* pileup, uint32_t start, uint32_t end, uint32_t ploidy, double epsilon,
+                             uint32_t beam, uint32_t* n_out, uint32_t* read_id, uint8_t* part_beam, uint8_t* part_opt,
+                             double* mec_bad, double* num_alleles, int* iters) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    Pile P{pileup};
+    std::vector<uint32_t> reads = find_reads_in_interval(P, start, end);
+    *n_out = (uint32_t)reads.size();
+    if (reads.empty()) return 0;
+    std::vector<std::vector<uint32_t>> part;
+    beam_search_phasing(P, reads, (int)ploidy, epsilon, DIV_FACTOR, std::log(PROB_CUTOFF), beam, part, nullptr);
+    auto fill = [&](const std::vector<std::vector<uint32_t>>& pp, uint8_t* dst) {
+        for (int k = 0; k < (int)pp.size(); ++k)
+            for (uint32_t r : pp[k]) dst[std::lower_bound(reads.begin(), reads.end(), r) - reads.begin()] = (uint8_t)k;
+    };
+    for (size_t i = 0; i < reads.size(); ++i) read_id[i] = reads[i];
+    fill(part, part_beam);
+    auto opt = optimize_clustering(P, part, epsilon, NUM_ITER_OPTIMIZE, iters);
+    fill(opt, part_opt);
+    double mec = 0, na = 0;
+    HapBlock np = hap_block_from_partition(P, opt, false);
+    for (const QM& s : mec_stats_of_block(np, 1)) { double good = (double)s.bases, bad = (double)s.errors + (double)s.m * epsilon; mec += bad; na += good; na += bad; }
+    *mec_bad = mec; *num_alleles = na;
+    return 0;
+}
+
+// S2
+int floria_oracle_reassign(const floria_pileup* pileup, const uint64_t* grp_off, const uint32_t* grp_read,
+                           const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    Pile P{pileup};
+    std::vector<std::vector<uint32_t>> parts(n_groups);
+    std::vector<std::pair<uint32_t, uint32_t>> ranges(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
+            if (grp_read[i] >= P.n()) { g_err = "group read id out of range"; return FLORIA_E_INVALID; }
+            parts[g].push_back(grp_read[i]);
+        }
+        std::sort(parts[g].begin(), parts[g].end());
+        parts[g].erase(std::unique(parts[g].begin(), parts[g].end()), parts[g].end());   // FxHashSet semantics
+        ranges[g] = {grp_range[2 * g], grp_range[2 * g + 1]};
+    }
+    process_reads_for_final_parts(P, parts, ranges, epsilon);
+    floria_groups* G = (floria_groups*)calloc(1, sizeof(floria_groups));
+    G->n_groups = (uint32_t)parts.size();
+    G->grp_off = (uint64_t*)calloc(parts.size() + 1, sizeof(uint64_t));
+    G->range = (uint32_t*)calloc(2 * parts.size() + 2, sizeof(uint32_t));
+    uint64_t tot = 0;
+    for (size_t g = 0; g < parts.size(); ++g) { G->grp_off[g] = tot; tot += parts[g].size(); G->range[2 * g] = ranges[g].first; G->range[2 * g + 1] = ranges[g].second; }
+    G->grp_off[parts.size()] = tot;
+    G->grp_read = (uint32_t*)malloc(sizeof(uint32_t) * (tot + 1));
+    for (size_t g = 0; g < parts.size(); ++g) std::copy(parts[g].begin(), parts[g].end(), G->grp_read + G->grp_off[g]);
+    *out = G;
+    return 0;
+}
+void floria_oracle_groups_free(floria_groups* g) { if (g) { free(g->grp_off); free(g->grp_read); free(g->range); free(g); } }
+
+// Isolated BinaryHeap emulation for unit tests: ops[i] >= 0 pushes score[ops[i]] ... encoded as:
+// scores[n] pushed in order with capacity `limit` (pop when len > limit, global_clustering.rs:130-134);
+// returns the heap array (payload ids) and the into_sorted_vec order.
+int floria_oracle_heap_trace(const double* scores, uint32_t n, uint32_t limit, int32_t* heap_ids, uint32_t* heap_len,
+                             int32_t* sorted_ids) {
+    BinaryHeap h;
+    for (uint32_t i = 0; i < n; ++i) {
+        HeapItem it; it.score = scores[i]; it.node = (int)i;
+        h.push(std::move(it));
+        if (h.len() > limit) h.pop();
+    }
+    *heap_len = (uint32_t)h.len();
+    for (size_t i = 0; i < h.len(); ++i) heap_ids[i] = h.data[i].node;
+    h.into_sorted_vec();
+    for (size_t i = 0; i < h.len(); ++i) sorted_ids[i] = h.data[i].node;
+    return 0;
+}
+
+double floria_oracle_binom(uint64_t n, uint64_t k, double p, double div) { return stable_binom_cdf_p_rev(n, k, p, div); }
+
+}  // extern "C"

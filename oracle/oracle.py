@@ -1,0 +1,128 @@
+"""ctypes wrapper of oracle/libfloria_oracle.so — the CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY (see floria_oracle.cpp header): imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg; never by anything under floria_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from floria_amd import _capi as capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libfloria_oracle.so")
+    src = os.path.join(_HERE, "floria_oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "floria_hip.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfloria_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.floria_oracle_last_error.restype = C.c_char_p
+        L.floria_oracle_binom.restype = C.c_double
+        L.floria_oracle_binom.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double]
+        _LIB = L
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError(f"oracle rc={rc}: {lib().floria_oracle_last_error().decode()}")
+
+
+def weight_q24():
+    out = np.zeros(256, np.uint32)
+    _check(lib().floria_oracle_weight_q24(capi.ptr(out, C.c_uint32)))
+    return out
+
+
+def block_ranges(snp_pos, block_length, overlap_len=None, minimal_density=0.0005):
+    snp_pos = np.ascontiguousarray(snp_pos, np.uint64)
+    if overlap_len is None:
+        overlap_len = block_length // 3            # graph_processing.rs:337
+    out = C.POINTER(capi.CRanges)()
+    _check(lib().floria_oracle_block_ranges(capi.ptr(snp_pos, C.c_uint64), C.c_uint32(len(snp_pos)), C.c_uint64(block_length),
+                                            C.c_uint64(overlap_len), C.c_double(minimal_density), C.byref(out)))
+    r = out.contents
+    res = (capi.np_from(r.start, r.n, np.uint32), capi.np_from(r.end, r.n, np.uint32))
+    lib().floria_oracle_ranges_free(out)
+    return res
+
+
+def make_params(epsilon, max_ploidy=5, beam=10, ploidy_sensitivity=2, stopping_heuristic=1):
+    return capi.CParams(float(epsilon), int(max_ploidy), int(beam), int(ploidy_sensitivity), int(stopping_heuristic))
+
+
+def phase_blocks(pileup, blk_start, blk_end, params, threads=1):
+    cp = pileup.as_c()
+    bs = np.ascontiguousarray(blk_start, np.uint32)
+    be = np.ascontiguousarray(blk_end, np.uint32)
+    out = C.POINTER(capi.CBlockResult)()
+    _check(lib().floria_oracle_phase_blocks(C.byref(cp), capi.ptr(bs, C.c_uint32), capi.ptr(be, C.c_uint32), C.c_uint32(len(bs)),
+                                            C.byref(params), C.c_uint32(threads), C.byref(out)))
+    res = capi.BlockResult(out.contents)
+    lib().floria_oracle_block_result_free(out)
+    return res
+
+
+def one_ploidy(pileup, start, end, ploidy, epsilon, beam=10):
+    """(read_id, part_after_beam, part_after_optimize, mec_bad, num_alleles, iters) for one (block, ploidy) job."""
+    cp = pileup.as_c()
+    n = C.c_uint32(0)
+    cap = pileup.n_reads + 1
+    rid = np.zeros(cap, np.uint32)
+    pb = np.zeros(cap, np.uint8)
+    po = np.zeros(cap, np.uint8)
+    mec = C.c_double(0)
+    na = C.c_double(0)
+    it = C.c_int(0)
+    _check(lib().floria_oracle_one_ploidy(C.byref(cp), C.c_uint32(start), C.c_uint32(end), C.c_uint32(ploidy), C.c_double(epsilon),
+                                          C.c_uint32(beam), C.byref(n), capi.ptr(rid, C.c_uint32), capi.ptr(pb, C.c_uint8),
+                                          capi.ptr(po, C.c_uint8), C.byref(mec), C.byref(na), C.byref(it)))
+    k = n.value
+    return rid[:k].copy(), pb[:k].copy(), po[:k].copy(), mec.value, na.value, it.value
+
+
+def reassign(pileup, groups, ranges, epsilon):
+    """groups: list of read-id arrays; ranges: [(start,end)] -> (list of arrays, [(start,end)])"""
+    cp = pileup.as_c()
+    off = np.zeros(len(groups) + 1, np.uint64)
+    off[1:] = np.cumsum([len(g) for g in groups])
+    reads = (np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32)).astype(np.uint32)
+    reads = np.ascontiguousarray(reads)
+    rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+    out = C.POINTER(capi.CGroups)()
+    _check(lib().floria_oracle_reassign(C.byref(cp), capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
+                                        C.c_uint32(len(groups)), C.c_double(epsilon), C.byref(out)))
+    g = capi.Groups(out.contents)
+    lib().floria_oracle_groups_free(out)
+    return g
+
+
+def heap_trace(scores, limit):
+    scores = np.ascontiguousarray(scores, np.float64)
+    n = len(scores)
+    ids = np.zeros(n + 1, np.int32)
+    srt = np.zeros(n + 1, np.int32)
+    ln = C.c_uint32(0)
+    _check(lib().floria_oracle_heap_trace(capi.ptr(scores, C.c_double), C.c_uint32(n), C.c_uint32(limit), capi.ptr(ids, C.c_int32),
+                                          C.byref(ln), capi.ptr(srt, C.c_int32)))
+    return ids[:ln.value].copy(), srt[:ln.value].copy()
+
+
+def binom(n, k, p, div=0.25):
+    return lib().floria_oracle_binom(n, k, p, div)
