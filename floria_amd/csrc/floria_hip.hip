@@ -1,0 +1,747 @@
+// floria_hip.hip — host side of libfloria_hip.so (C ABI in include/floria_hip.h) + kernel launches.
+//
+// Host responsibilities (the reference does these on its rayon workers / main thread):
+//   get_range_with_lengths            utils_frags.rs:405-463      -> floria_hip_block_ranges
+//   find_reads_in_interval            local_clustering.rs:12-59   -> build_block_lists (binary search + filter)
+//   per-ploidy loop of get_local_hap_blocks graph_processing.rs:132-252 -> one launch triple per ploidy:
+//       beam_kernel -> optimize_kernel -> select_kernel (the stop rule sets blk_done so later
+//       ploidies skip finished blocks: no speculative work, results identical)
+//   separate_broken_haplogroups / sort_parts  part_block_manip.rs:27-98,276-288 -> host bookkeeping after
+//       reassign_kernel
+// There is NO CPU compute fallback: every entry point needs a working HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/floria_hip.h"
+#include "beam_kernel.h"
+#include "optimize_kernel.h"
+#include "reassign_kernel.h"
+
+static_assert(FLORIA_MAX_PLOIDY == fl::MAX_PLOIDY, "ploidy limits out of sync");
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(_e == hipErrorOutOfMemory ? FLORIA_E_NOMEM : FLORIA_E_DEVICE,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+    } while (0)
+
+constexpr double DIV_FACTOR  = 0.25;   // constants.rs:5
+constexpr double PROB_CUTOFF = 0.01;   // constants.rs:6
+constexpr uint32_t BINOM_NMAX_CAP = 1024;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(FLORIA_E_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace
+
+struct floria_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t user_slots = 0;
+    int n_cu = 256;
+    // cached tables
+    double binom_eps = -1.0;
+    uint32_t binom_nmax = 0;
+    DevBuf d_binom;
+    DevBuf d_hash;            // Rq1 | Rp1 | Rq2 | Rp2, each hash_len u64
+    uint32_t hash_len = 0;
+    uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
+    // scratch pools
+    DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc;
+    floria_timing timing{};
+};
+
+struct floria_hip_contig {
+    floria_hip_ctx* ctx = nullptr;
+    uint32_t n_reads = 0;
+    uint64_t n_cells = 0;
+    uint32_t max_len = 0;       // max cells per read
+    uint32_t n_alleles = 2;     // 2 or 4 (kernel template)
+    std::vector<uint32_t> h_first, h_last, h_read_off;
+    DevBuf d_read_off, d_first, d_last, d_snp, d_aq;
+    fl::ContigDev dev{};
+};
+
+namespace {
+
+int validate_pileup(const floria_pileup* p, uint32_t* max_len, uint32_t* max_allele) {
+    if (!p) return fail(FLORIA_E_INVALID, "null pileup");
+    if (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last))
+        return fail(FLORIA_E_INVALID, "null pileup field");
+    uint32_t ml = 0, ma = 0;
+    for (uint32_t r = 0; r < p->n_reads; ++r) {
+        const uint32_t b = p->read_off[r], e = p->read_off[r + 1];
+        if (e <= b) return fail(FLORIA_E_INVALID, "read " + std::to_string(r) + " has no cells");
+        if (p->snp[b] != p->first[r] || p->snp[e - 1] != p->last[r]) return fail(FLORIA_E_INVALID, "first/last of read " + std::to_string(r) + " do not match its cells");
+        if (p->snp[b] == 0) return fail(FLORIA_E_INVALID, "SNP positions are 1-based");
+        for (uint32_t c = b; c < e; ++c) {
+            if (c > b && p->snp[c] <= p->snp[c - 1]) return fail(FLORIA_E_INVALID, "cells of read " + std::to_string(r) + " not strictly ascending");
+            if (p->allele[c] >= FLORIA_MAX_ALLELES) return fail(FLORIA_E_UNSUPPORTED, "allele index > 3 (read " + std::to_string(r) + ")");
+            ma = std::max<uint32_t>(ma, p->allele[c]);
+        }
+        ml = std::max(ml, e - b);
+        if (r > 0) {   // Frag::cmp (types_structs.rs:87-93)
+            const bool ok = p->first[r - 1] < p->first[r] || (p->first[r - 1] == p->first[r] && p->last[r - 1] >= p->last[r]);
+            if (!ok) return fail(FLORIA_E_INVALID, "reads not sorted by Frag::cmp at read " + std::to_string(r));
+        }
+    }
+    *max_len = ml; *max_allele = ma;
+    return 0;
+}
+
+// find_reads_in_interval (local_clustering.rs:12-59): reads with last >= start, first <= end and
+// last - first <= 10000; reads are sorted by first so the candidates are one binary-searched range.
+void reads_in_interval(const floria_hip_contig* c, uint32_t start, uint32_t end, std::vector<uint32_t>& out,
+                       uint32_t* pos0, uint32_t* pos1) {
+    const auto& F = c->h_first; const auto& L = c->h_last;
+    const uint32_t lo_first = start > 10000 ? start - 10000 : 0;
+    size_t lo = std::lower_bound(F.begin(), F.end(), lo_first) - F.begin();
+    size_t hi = std::upper_bound(F.begin(), F.end(), end) - F.begin();
+    uint32_t mn = UINT32_MAX, mx = 0;
+    for (size_t r = lo; r < hi; ++r) {
+        if (L[r] < start) continue;
+        if (L[r] - F[r] > 10000) continue;
+        out.push_back((uint32_t)r);
+        mn = std::min(mn, F[r]); mx = std::max(mx, L[r]);
+    }
+    *pos0 = mn; *pos1 = mx;
+}
+
+int ensure_binom(floria_hip_ctx* ctx, double eps, uint32_t nmax) {
+    nmax = std::min(nmax, BINOM_NMAX_CAP);
+    if (ctx->binom_eps == eps && ctx->binom_nmax >= nmax && ctx->d_binom.p) return 0;
+    nmax = std::max(nmax, ctx->binom_eps == eps ? ctx->binom_nmax : 0u);
+    std::vector<double> tab((size_t)(nmax + 1) * (nmax + 2) / 2);
+    for (uint64_t n = 0; n <= nmax; ++n)
+        for (uint64_t k = 0; k <= n; ++k) {
+            // stable_binom_cdf_p_rev (utils_frags.rs:211-248), host libm
+            double v = 0.0;
+            if (n != 0) {
+                double n64 = (double)n, k64 = (double)k;
+                double a = k64 / n64;
+                if (a == 1.0) a = 0.9999999;
+                if (a == 0.0) a = 0.0000001;
+                double rel_ent = a * std::log(a / eps) + (1.0 - a) * std::log((1.0 - a) / (1.0 - eps));
+                if (a < eps) rel_ent = -rel_ent;
+                v = -1.0 * n64 / DIV_FACTOR * rel_ent;
+            }
+            tab[n * (n + 1) / 2 + k] = v;
+        }
+    int rc = ctx->d_binom.ensure(tab.size() * sizeof(double));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_binom.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->binom_eps = eps; ctx->binom_nmax = nmax;
+    return 0;
+}
+
+int ensure_hash(floria_hip_ctx* ctx, uint32_t len) {
+    if (ctx->hash_len >= len && ctx->d_hash.p) return 0;
+    len = std::max<uint32_t>(len + len / 4, 4096);
+    std::vector<uint64_t> t((size_t)len * 4);
+    uint64_t s = 0x1577f10a1aull;
+    for (uint32_t i = 0; i < len; ++i) {
+        t[i] = splitmix64(s) | 1ull;                 // Rq1 (odd)
+        t[(size_t)len + i] = splitmix64(s);          // Rp1
+        t[(size_t)2 * len + i] = splitmix64(s) | 1ull;
+        t[(size_t)3 * len + i] = splitmix64(s);
+    }
+    int rc = ctx->d_hash.ensure(t.size() * 8);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_hash.p, t.data(), t.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->hash_len = len;
+    return 0;
+}
+
+struct EventTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<int> kind;
+    hipStream_t s;
+    explicit EventTimer(hipStream_t st) : s(st) {}
+    ~EventTimer() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+    int begin(int k) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        ev.push_back({a, b}); kind.push_back(k);
+        (void)hipEventRecord(a, s);
+        return (int)ev.size() - 1;
+    }
+    void end(int i) { if (i >= 0) (void)hipEventRecord(ev[i].second, s); }
+    double sum(int k) {
+        double t = 0;
+        for (size_t i = 0; i < ev.size(); ++i) if (kind[i] == k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[i].first, ev[i].second) == hipSuccess) t += ms; }
+        return t;
+    }
+    double span() {
+        if (ev.empty()) return 0;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev.front().first, ev.back().second);
+        return ms;
+    }
+};
+enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5 };
+
+template <int A>
+int run_phase(floria_hip_ctx* ctx, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const uint32_t* d_jobs,
+              uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
+              uint8_t* d_beam_part, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
+              uint32_t* d_tried, uint32_t* d_queue, unsigned long long* d_margin, uint32_t* d_diag,
+              unsigned long long* d_steps, EventTimer& T) {
+    const uint32_t P = prm->max_ploidy, B = prm->beam;
+    const uint32_t n_jobs = (uint32_t)jobs.size();
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const double cutoff = std::log(PROB_CUTOFF);      // graph_processing.rs:146
+    for (uint32_t p = 1; p <= P; ++p) {
+        if (n_jobs == 0) break;
+        const uint32_t LM = p * B;
+        if (LM > 65000) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam too large");
+        // ---- beam search ---------------------------------------------------------------------------------------
+        {
+            const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
+            const uint64_t hist_stride = (uint64_t)fl::beam_hist_off(n_max, LM, B) + LM;
+            uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * 8;
+            slots = std::min(slots, n_jobs);
+            const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
+            while (slots > 1 && (state_bytes + hist_stride * 4) * slots > budget) slots /= 2;
+            int rc = ctx->state_pool.ensure(state_bytes * slots); if (rc) return rc;
+            rc = ctx->hist_pool.ensure(hist_stride * 4 * slots); if (rc) return rc;
+            fl::BeamArgs a{};
+            a.bs = bs; a.job_block = d_jobs; a.n_jobs = n_jobs; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
+            a.queue_head = d_queue; a.blk_done = d_done;
+            a.state_pool = ctx->state_pool.as<uint64_t>(); a.hist_pool = ctx->hist_pool.as<uint32_t>(); a.hist_stride = hist_stride;
+            a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
+            a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
+            const uint64_t* H = ctx->d_hash.as<uint64_t>();
+            a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
+            memcpy(a.Rk1, ctx->Rk1, sizeof(a.Rk1)); memcpy(a.Rk2, ctx->Rk2, sizeof(a.Rk2));
+            a.part_out = d_beam_part; a.min_margin_bits = d_margin; a.diag = d_diag; a.steps_done = d_steps;
+            const fl::BeamLds LY = fl::beam_lds_layout(LM);
+            if (LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
+            if (LY.total > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute((const void*)fl::beam_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY.total));
+            HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
+            int t = T.begin(K_BEAM);
+            hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), LY.total, ctx->stream, a);
+            T.end(t);
+            HIPCHK(hipGetLastError());
+            ctx->timing.beam_launches++;
+        }
+        // ---- optimise + MEC stats ----------------------------------------------------------------------------------
+        {
+            uint32_t slots = std::min<uint32_t>((uint32_t)ctx->n_cu * 4, n_jobs);
+            uint64_t cand_cap = 1;
+            while (cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) cand_cap <<= 1;
+            int rc = ctx->opt_hist.ensure((uint64_t)slots * span_max * p * A * 8); if (rc) return rc;
+            rc = ctx->opt_dist.ensure((uint64_t)slots * n_max * p * 8); if (rc) return rc;
+            rc = ctx->opt_gain.ensure((uint64_t)slots * cand_cap * 8); if (rc) return rc;
+            rc = ctx->opt_key.ensure((uint64_t)slots * cand_cap * 4); if (rc) return rc;
+            rc = ctx->opt_moves.ensure((uint64_t)slots * n_max * 4); if (rc) return rc;
+            fl::OptArgs a{};
+            a.bs = bs; a.job_block = d_jobs; a.n_jobs = n_jobs; a.ploidy = p; a.max_ploidy = P; a.span_max = span_max; a.n_max = n_max;
+            a.queue_head = d_queue; a.blk_done = d_done; a.eps = prm->epsilon;
+            a.part_in = d_beam_part; a.part_out = d_planes + (uint64_t)(p - 1) * tot_reads;
+            a.hist_pool = ctx->opt_hist.as<uint64_t>(); a.dist_pool = ctx->opt_dist.as<double>();
+            a.cand_gain_pool = ctx->opt_gain.as<uint64_t>(); a.cand_key_pool = ctx->opt_key.as<uint32_t>();
+            a.moves_pool = ctx->opt_moves.as<uint32_t>(); a.cand_cap = cand_cap;
+            a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
+            const size_t lds = ((size_t)(n_max + 31) / 32) * 4 + 16;
+            HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
+            int t = T.begin(K_OPT);
+            hipLaunchKernelGGL(fl::optimize_kernel<A>, dim3(slots), dim3(fl::OPT_THREADS), lds, ctx->stream, a);
+            T.end(t);
+            HIPCHK(hipGetLastError());
+            ctx->timing.optimize_launches++;
+        }
+        // ---- stop rule --------------------------------------------------------------------------------------------------
+        {
+            fl::SelectArgs s{};
+            s.n_blocks = bs.n_blocks; s.ploidy = p; s.max_ploidy = P; s.stopping_heuristic = prm->stopping_heuristic; s.eps = prm->epsilon;
+            const double eps = prm->epsilon, pl = (double)p;    // graph_processing.rs:204-220
+            if (prm->ploidy_sensitivity == 1)      s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 0.50) + 1.00));
+            else if (prm->ploidy_sensitivity == 2) s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1. / 3.));
+            else                                   s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1.00));
+            s.blk_read_off = bs.blk_read_off; s.mec = d_mec; s.num_alleles = d_na; s.blk_done = d_done; s.best_ploidy = d_best; s.tried = d_tried;
+            int t = T.begin(K_SEL);
+            hipLaunchKernelGGL(fl::select_kernel, dim3((bs.n_blocks + 255) / 256), dim3(256), 0, ctx->stream, s);
+            T.end(t);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* floria_hip_last_error(void) { return g_err.c_str(); }
+const char* floria_hip_version(void) { return "floria_hip 0.1.0 (gfx950)"; }
+
+int floria_hip_create(int device, floria_hip_ctx** out) {
+    if (!out) return fail(FLORIA_E_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(FLORIA_E_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(FLORIA_E_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    floria_hip_ctx* c = new floria_hip_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(FLORIA_E_DEVICE, "hipStreamCreate failed"); }
+    // phred_scale (utils_frags.rs:702-711): w = 1f32 - 10f32.powf(q as f32 / -10.), exact multiple of 2^-24
+    uint32_t w24[256];
+    for (int q = 0; q < 256; ++q) {
+        float x = (float)q / -10.0f;
+        float prob = 1.0f - powf(10.0f, x);
+        double s = (double)prob * 16777216.0;
+        w24[q] = (uint32_t)s;
+        if ((double)w24[q] != s) { delete c; return fail(FLORIA_E_DEVICE, "quality weight is not a multiple of 2^-24"); }
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_w24), w24, sizeof(w24));
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(FLORIA_E_DEVICE, std::string("weight LUT upload: ") + hipGetErrorString(e)); }
+    uint64_t s = 0xf10a1a2024ull;
+    for (int k = 0; k < FLORIA_MAX_PLOIDY; ++k) { c->Rk1[k] = splitmix64(s) | 1ull; c->Rk2[k] = splitmix64(s) | 1ull; }
+    *out = c;
+    return 0;
+}
+
+void floria_hip_destroy(floria_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc}) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots) {
+    if (!ctx) return fail(FLORIA_E_INVALID, "null ctx");
+    ctx->user_slots = beam_slots;
+    return 0;
+}
+
+int floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out) {
+    if (!ctx || !out) return fail(FLORIA_E_INVALID, "null argument");
+    *out = ctx->timing;
+    return 0;
+}
+
+// ---- get_range_with_lengths (utils_frags.rs:405-463) ------------------------------------------------------
+int floria_hip_block_ranges(const uint64_t* g, uint32_t n, uint64_t block_length, uint64_t overlap_len,
+                            double minimal_density, floria_ranges** out) {
+    if (!g || !out) return fail(FLORIA_E_INVALID, "null argument");
+    if (n == 0) return fail(FLORIA_E_INVALID, "empty snp_to_genome_pos");
+    std::vector<uint32_t> S, E;
+    uint64_t cum_pos = 0, last_pos = g[0];
+    uint32_t left_endpoint = 0, new_left_end = 0;
+    bool hit_new_left = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t pos = g[i];
+        if (i == n - 1) { S.push_back(left_endpoint); E.push_back(i); break; }                         // :418-421
+        if (pos < last_pos) return fail(FLORIA_E_INVALID, "VCF malformed. Positions are not increasing");   // :422-425
+        cum_pos += pos - last_pos;
+        last_pos = pos;
+        if (cum_pos > block_length - overlap_len && !hit_new_left) { new_left_end = i; hit_new_left = true; }
+        if (cum_pos > block_length) {
+            cum_pos = 0;
+            const double snp_density = (double)(i - left_endpoint) / (double)block_length;
+            if (snp_density > minimal_density) { S.push_back(left_endpoint); E.push_back(i - 1); }
+            left_endpoint = (g[new_left_end] + block_length < g[new_left_end + 1]) ? new_left_end : new_left_end + 1;   // :447-453
+            last_pos = g[left_endpoint];
+            hit_new_left = false;
+        }
+    }
+    floria_ranges* r = (floria_ranges*)calloc(1, sizeof(floria_ranges));
+    if (!r) return fail(FLORIA_E_NOMEM, "calloc");
+    r->n = (uint32_t)S.size();
+    r->start = (uint32_t*)malloc(sizeof(uint32_t) * (S.size() + 1));
+    r->end = (uint32_t*)malloc(sizeof(uint32_t) * (S.size() + 1));
+    for (size_t i = 0; i < S.size(); ++i) { r->start[i] = S[i] + 1; r->end[i] = E[i] + 1; }   // 1-indexed :461
+    *out = r;
+    return 0;
+}
+void floria_hip_ranges_free(floria_ranges* r) { if (r) { free(r->start); free(r->end); free(r); } }
+
+// ---- contig upload ------------------------------------------------------------------------------------------
+int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria_hip_contig** out) {
+    if (!ctx || !out) return fail(FLORIA_E_INVALID, "null argument");
+    *out = nullptr;
+    uint32_t ml = 0, ma = 0;
+    int rc = validate_pileup(p, &ml, &ma);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    floria_hip_contig* c = new floria_hip_contig();
+    c->ctx = ctx; c->n_reads = p->n_reads; c->max_len = ml; c->n_alleles = ma >= 2 ? 4 : 2;
+    const uint64_t nc = p->n_reads ? p->read_off[p->n_reads] : 0;
+    c->n_cells = nc;
+    c->h_first.assign(p->first, p->first + p->n_reads);
+    c->h_last.assign(p->last, p->last + p->n_reads);
+    c->h_read_off.assign(p->read_off, p->read_off + p->n_reads + (p->n_reads ? 1 : 0));
+    std::vector<uint16_t> aq(nc);
+    for (uint64_t i = 0; i < nc; ++i) aq[i] = (uint16_t)((p->allele[i] << 8) | p->qual[i]);
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        int r2 = b.ensure(std::max<size_t>(bytes, 16));
+        if (r2) return r2;
+        if (bytes) { hipError_t e = hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return fail(FLORIA_E_DEVICE, hipGetErrorString(e)); }
+        return 0;
+    };
+    rc = up(c->d_read_off, p->read_off, (size_t)(p->n_reads + 1) * 4 * (p->n_reads ? 1 : 0));
+    if (!rc) rc = up(c->d_first, p->first, (size_t)p->n_reads * 4);
+    if (!rc) rc = up(c->d_last, p->last, (size_t)p->n_reads * 4);
+    if (!rc) rc = up(c->d_snp, p->snp, nc * 4);
+    if (!rc) rc = up(c->d_aq, aq.data(), nc * 2);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(FLORIA_E_DEVICE, "upload sync failed");
+    if (rc) { floria_hip_contig_free(c); return rc; }
+    c->dev.read_off = c->d_read_off.as<uint32_t>(); c->dev.first = c->d_first.as<uint32_t>(); c->dev.last = c->d_last.as<uint32_t>();
+    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aq = c->d_aq.as<uint16_t>(); c->dev.n_reads = p->n_reads;
+    *out = c;
+    return 0;
+}
+void floria_hip_contig_free(floria_hip_contig* c) {
+    if (!c) return;
+    for (DevBuf* b : {&c->d_read_off, &c->d_first, &c->d_last, &c->d_snp, &c->d_aq}) b->release();
+    delete c;
+}
+
+// ---- S1 --------------------------------------------------------------------------------------------------------
+int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
+                                  const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
+                                  uint32_t n_blocks, const floria_params* prm, floria_block_result** out) {
+    if (!ctx || !out || !prm || (n_blocks && (!blk_start || !blk_end || !contigs))) return fail(FLORIA_E_INVALID, "null argument");
+    *out = nullptr;
+    if (prm->max_ploidy < 1 || prm->max_ploidy > FLORIA_MAX_PLOIDY) return fail(FLORIA_E_INVALID, "max_ploidy must be in 1..16");
+    if (prm->beam < 1) return fail(FLORIA_E_INVALID, "beam (max_number_solns) must be >= 1");
+    if (!(prm->epsilon > 0.0 && prm->epsilon < 1.0)) return fail(FLORIA_E_INVALID, "epsilon must be in (0,1)");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->timing = floria_timing{};
+    const uint32_t P = prm->max_ploidy;
+
+    // ---- block read lists (find_reads_in_interval) ------------------------------------------------------
+    std::vector<uint64_t> roff(n_blocks + 1, 0);
+    std::vector<uint32_t> rids, pos0(n_blocks, 0), span(n_blocks, 0), bc(n_blocks, 0);
+    uint32_t n_max = 1, span_max = 1, len_max = 1, nall = 2;
+    uint64_t algo_bytes = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t ci = blk_contig ? blk_contig[b] : 0;
+        if (ci >= n_contigs || !contigs[ci]) return fail(FLORIA_E_INVALID, "blk_contig out of range");
+        if (contigs[ci]->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
+        bc[b] = ci;
+        uint32_t p0, p1;
+        const size_t before = rids.size();
+        reads_in_interval(contigs[ci], blk_start[b], blk_end[b], rids, &p0, &p1);
+        const uint32_t n = (uint32_t)(rids.size() - before);
+        roff[b + 1] = rids.size();
+        if (n) {
+            pos0[b] = p0; span[b] = p1 - p0 + 1;
+            n_max = std::max(n_max, n); span_max = std::max(span_max, span[b]);
+            uint64_t ab = 16 + (uint64_t)n + 8ull * P + 4;            // SURVEY.md §8(d) bytes(block)
+            const auto& ro = contigs[ci]->h_read_off;
+            for (size_t i = before; i < rids.size(); ++i) { const uint64_t L = ro[rids[i] + 1] - ro[rids[i]]; ab += 8 + (L + 3) / 4 + (L + 7) / 8 + L; }
+            algo_bytes += ab;
+        }
+        len_max = std::max(len_max, contigs[ci]->max_len);
+        nall = std::max(nall, contigs[ci]->n_alleles);
+    }
+    if (n_max >= (1u << 20)) return fail(FLORIA_E_UNSUPPORTED, "more than 2^20 reads in one block");
+    const uint64_t tot = rids.size();
+    std::vector<uint32_t> jobs;
+    for (uint32_t b = 0; b < n_blocks; ++b) if (roff[b + 1] > roff[b]) jobs.push_back(b);
+    std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return (roff[a + 1] - roff[a]) > (roff[b2 + 1] - roff[b2]); });
+
+    int rc = ensure_binom(ctx, prm->epsilon, len_max); if (rc) return rc;
+    rc = ensure_hash(ctx, span_max * nall); if (rc) return rc;
+
+    // ---- device staging (one misc allocation) --------------------------------------------------------------
+    std::vector<fl::ContigDev> cdev(n_contigs);
+    for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) cdev[i] = contigs[i]->dev;
+    struct Seg { size_t off, bytes; };
+    size_t cursor = 0;
+    auto seg = [&](size_t bytes) { Seg s{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return s; };
+    Seg s_cdev = seg(sizeof(fl::ContigDev) * std::max(1u, n_contigs)), s_bc = seg(4ull * n_blocks + 4), s_bs = seg(4ull * n_blocks + 4),
+        s_be = seg(4ull * n_blocks + 4), s_p0 = seg(4ull * n_blocks + 4), s_sp = seg(4ull * n_blocks + 4), s_roff = seg(8ull * (n_blocks + 1)),
+        s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg(tot + 16),
+        s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
+        s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(16), s_margin = seg(16),
+        s_diag = seg(16), s_steps = seg(16);
+    rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
+    char* M = ctx->misc.as<char>();
+    EventTimer T(ctx->stream);
+    int th = T.begin(K_H2D);
+    auto h2d = [&](Seg s, const void* src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(M + s.off, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; };
+    HIPCHK(h2d(s_cdev, cdev.data(), sizeof(fl::ContigDev) * n_contigs));
+    HIPCHK(h2d(s_bc, bc.data(), 4ull * n_blocks));
+    HIPCHK(h2d(s_bs, blk_start, 4ull * n_blocks));
+    HIPCHK(h2d(s_be, blk_end, 4ull * n_blocks));
+    HIPCHK(h2d(s_p0, pos0.data(), 4ull * n_blocks));
+    HIPCHK(h2d(s_sp, span.data(), 4ull * n_blocks));
+    HIPCHK(h2d(s_roff, roff.data(), 8ull * (n_blocks + 1)));
+    HIPCHK(h2d(s_rids, rids.data(), 4ull * tot));
+    HIPCHK(h2d(s_jobs, jobs.data(), 4ull * jobs.size()));
+    HIPCHK(hipMemsetAsync(M + s_mec.off, 0, s_mec.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_na.off, 0, s_na.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_it.off, 0, s_it.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_done.off, 0, s_done.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_best.off, 0, s_best.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_tried.off, 0, s_tried.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_out.off, 0, s_out.bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_diag.off, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_steps.off, 0, 16, ctx->stream));
+    const double inf = std::numeric_limits<double>::infinity();
+    HIPCHK(hipMemcpyAsync(M + s_margin.off, &inf, 8, hipMemcpyHostToDevice, ctx->stream));
+    T.end(th);
+
+    fl::BlockSet bs{};
+    bs.contigs = (const fl::ContigDev*)(M + s_cdev.off);
+    bs.blk_contig = (const uint32_t*)(M + s_bc.off); bs.blk_start = (const uint32_t*)(M + s_bs.off); bs.blk_end = (const uint32_t*)(M + s_be.off);
+    bs.blk_pos0 = (const uint32_t*)(M + s_p0.off); bs.blk_span = (const uint32_t*)(M + s_sp.off);
+    bs.blk_read_off = (const uint64_t*)(M + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
+
+    auto run = nall == 2 ? run_phase<2> : run_phase<4>;
+    rc = run(ctx, bs, jobs, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
+             (uint8_t*)(M + s_bpart.off), (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
+             (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
+             (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    {
+        int t = T.begin(K_SEL);
+        if (n_blocks) hipLaunchKernelGGL(fl::gather_kernel, dim3(n_blocks), dim3(64), 0, ctx->stream, n_blocks, bs.blk_read_off,
+                                         (const uint32_t*)(M + s_best.off), (const uint8_t*)(M + s_planes.off), tot, (uint8_t*)(M + s_out.off));
+        T.end(t);
+        HIPCHK(hipGetLastError());
+    }
+
+    // ---- results ------------------------------------------------------------------------------------------------
+    floria_block_result* R = (floria_block_result*)calloc(1, sizeof(floria_block_result));
+    if (!R) return fail(FLORIA_E_NOMEM, "calloc");
+    R->n_blocks = n_blocks; R->max_ploidy = P;
+    R->best_ploidy = (uint32_t*)calloc(n_blocks + 1, 4);
+    R->ploidies_tried = (uint32_t*)calloc(n_blocks + 1, 4);
+    R->read_off = (uint64_t*)calloc(n_blocks + 1, 8);
+    R->read_id = (uint32_t*)malloc(4 * (tot + 1));
+    R->part = (uint8_t*)malloc(tot + 1);
+    R->mec = (double*)calloc((size_t)n_blocks * P + 1, 8);
+    if (!R->best_ploidy || !R->ploidies_tried || !R->read_off || !R->read_id || !R->part || !R->mec) { floria_hip_block_result_free(R); return fail(FLORIA_E_NOMEM, "malloc"); }
+    int td = T.begin(K_D2H);
+    hipError_t e = hipSuccess;
+    uint32_t diag[4] = {0, 0, 0, 0};
+    unsigned long long steps = 0;
+    double margin = inf;
+    if (n_blocks) {
+        e = hipMemcpyAsync(R->best_ploidy, M + s_best.off, 4ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(R->ploidies_tried, M + s_tried.off, 4ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(R->mec, M + s_mec.off, 8ull * n_blocks * P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && tot) e = hipMemcpyAsync(R->part, M + s_out.off, tot, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(diag, M + s_diag.off, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&steps, M + s_steps.off, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&margin, M + s_margin.off, 8, hipMemcpyDeviceToHost, ctx->stream);
+    T.end(td);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, std::string("phase_blocks: ") + hipGetErrorString(e)); }
+    if (diag[1]) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
+    memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
+    if (tot) memcpy(R->read_id, rids.data(), 4ull * tot);
+    R->min_prune_margin = margin;
+    ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
+    ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
+    ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
+    *out = R;
+    return 0;
+}
+
+int floria_hip_phase_blocks_resident(floria_hip_ctx* ctx, const floria_hip_contig* contig, const uint32_t* blk_start,
+                                     const uint32_t* blk_end, uint32_t n_blocks, const floria_params* params,
+                                     floria_block_result** out) {
+    if (!contig) return fail(FLORIA_E_INVALID, "null contig");
+    const floria_hip_contig* arr[1] = {contig};
+    return floria_hip_phase_blocks_batch(ctx, arr, 1, nullptr, blk_start, blk_end, n_blocks, params, out);
+}
+
+int floria_hip_phase_blocks(floria_hip_ctx* ctx, const floria_pileup* pileup, const uint32_t* blk_start, const uint32_t* blk_end,
+                            uint32_t n_blocks, const floria_params* params, floria_block_result** out) {
+    floria_hip_contig* c = nullptr;
+    int rc = floria_hip_contig_upload(ctx, pileup, &c);
+    if (rc) return rc;
+    rc = floria_hip_phase_blocks_resident(ctx, c, blk_start, blk_end, n_blocks, params, out);
+    floria_hip_contig_free(c);
+    return rc;
+}
+
+void floria_hip_block_result_free(floria_block_result* r) {
+    if (!r) return;
+    free(r->best_ploidy); free(r->ploidies_tried); free(r->read_off); free(r->read_id); free(r->part); free(r->mec); free(r);
+}
+
+// ---- S2 --------------------------------------------------------------------------------------------------------
+int floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* c, const uint64_t* grp_off, const uint32_t* grp_read,
+                        const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
+    if (!ctx || !c || !out || (n_groups && (!grp_off || !grp_range))) return fail(FLORIA_E_INVALID, "null argument");
+    if (c->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->timing = floria_timing{};
+    const uint32_t N = c->n_reads;
+    const uint32_t A = c->n_alleles;
+    // read -> groups (part_block_manip.rs:185-193); groups are sets
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    std::vector<uint32_t> g_p0(n_groups, UINT32_MAX), g_p1(n_groups, 0);
+    for (uint32_t g = 0; g < n_groups; ++g)
+        for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
+            const uint32_t r = grp_read[i];
+            if (r >= N) return fail(FLORIA_E_INVALID, "group read id out of range");
+            pairs.push_back({r, g});
+            g_p0[g] = std::min(g_p0[g], c->h_first[r]); g_p1[g] = std::max(g_p1[g], c->h_last[r]);
+        }
+    std::sort(pairs.begin(), pairs.end());
+    pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+    std::vector<uint64_t> r2g_off(N + 1, 0), hist_off(n_groups + 1, 0);
+    std::vector<uint32_t> r2g(pairs.size());
+    for (auto& pr : pairs) r2g_off[pr.first + 1]++;
+    for (uint32_t r = 0; r < N; ++r) r2g_off[r + 1] += r2g_off[r];
+    for (size_t i = 0; i < pairs.size(); ++i) r2g[i] = pairs[i].second;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint64_t w = g_p0[g] == UINT32_MAX ? 0 : (uint64_t)(g_p1[g] - g_p0[g] + 1) * A;
+        hist_off[g + 1] = hist_off[g] + w;
+        if (g_p0[g] == UINT32_MAX) g_p0[g] = 0;
+    }
+    std::vector<int32_t> assign(N, -1);
+    if (N && n_groups) {
+        struct Seg { size_t off, bytes; };
+        size_t cursor = 0;
+        auto seg = [&](size_t bytes) { Seg s{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return s; };
+        Seg s_cd = seg(sizeof(fl::ContigDev)), s_ro = seg(8ull * (N + 1)), s_r2g = seg(4ull * r2g.size() + 4), s_ho = seg(8ull * (n_groups + 1)),
+            s_p0 = seg(4ull * n_groups + 4), s_hist = seg(8ull * hist_off[n_groups] + 8), s_as = seg(4ull * N + 4), s_zero = seg(64), s_q = seg(16);
+        int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
+        char* M = ctx->misc.as<char>();
+        EventTimer T(ctx->stream);
+        int th = T.begin(K_H2D);
+        HIPCHK(hipMemcpyAsync(M + s_cd.off, &c->dev, sizeof(fl::ContigDev), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(M + s_ro.off, r2g_off.data(), 8ull * (N + 1), hipMemcpyHostToDevice, ctx->stream));
+        if (!r2g.empty()) HIPCHK(hipMemcpyAsync(M + s_r2g.off, r2g.data(), 4ull * r2g.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(M + s_ho.off, hist_off.data(), 8ull * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(M + s_p0.off, g_p0.data(), 4ull * n_groups, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(M + s_hist.off, 0, s_hist.bytes, ctx->stream));
+        HIPCHK(hipMemsetAsync(M + s_zero.off, 0, 64, ctx->stream));
+        HIPCHK(hipMemsetAsync(M + s_q.off, 0, 16, ctx->stream));
+        T.end(th);
+        fl::ReassignArgs a{};
+        a.contigs = (const fl::ContigDev*)(M + s_cd.off); a.n_contigs = 1;
+        a.r2g_off_base = (const uint64_t*)(M + s_zero.off); a.r2g_off = (const uint64_t*)(M + s_ro.off);
+        a.r2g_base = (const uint64_t*)(M + s_zero.off); a.r2g = (const uint32_t*)(M + s_r2g.off);
+        a.grp_base = (const uint64_t*)(M + s_zero.off); a.grp_hist_off = (const uint64_t*)(M + s_ho.off); a.grp_pos0 = (const uint32_t*)(M + s_p0.off);
+        a.hist = (uint64_t*)(M + s_hist.off); a.assign = (int32_t*)(M + s_as.off); a.assign_base = (const uint64_t*)(M + s_zero.off);
+        a.eps = epsilon; a.queue_head = (uint32_t*)(M + s_q.off);
+        int tk = T.begin(K_REASSIGN);
+        if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(1), dim3(64), 0, ctx->stream, a);
+        T.end(tk);
+        HIPCHK(hipGetLastError());
+        int td = T.begin(K_D2H);
+        HIPCHK(hipMemcpyAsync(assign.data(), M + s_as.off, 4ull * N, hipMemcpyDeviceToHost, ctx->stream));
+        T.end(td);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->timing.reassign_ms = T.sum(K_REASSIGN); ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
+    }
+    // ---- host bookkeeping: rebuild groups, separate_broken_haplogroups (:27-98), sort_parts (:276-288) ----------
+    std::vector<std::vector<uint32_t>> parts(n_groups);
+    std::vector<std::pair<uint32_t, uint32_t>> ranges(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) ranges[g] = {grp_range[2 * g], grp_range[2 * g + 1]};
+    for (uint32_t r = 0; r < N; ++r) if (assign[r] >= 0) parts[assign[r]].push_back(r);       // ascending id
+    {
+        const auto& F = c->h_first; const auto& L = c->h_last;
+        std::vector<std::pair<size_t, std::vector<uint32_t>>> all_breaks;
+        const size_t n0 = ranges.size();
+        for (size_t i = 0; i < n0; ++i) {
+            uint32_t latest = 0;
+            std::vector<uint32_t> breaks;
+            for (uint32_t r : parts[i]) {                                // sorted by first_position (ids ascend)
+                if (latest != 0 && F[r] > latest && latest >= ranges[i].first && latest < ranges[i].second) breaks.push_back(latest);
+                if (L[r] > latest) latest = L[r];
+            }
+            if (!breaks.empty()) all_breaks.push_back({i, std::move(breaks)});
+        }
+        std::vector<std::vector<uint32_t>> new_parts;
+        std::vector<std::pair<uint32_t, uint32_t>> new_ranges;
+        for (auto& bi : all_breaks) {
+            size_t spot = 0;
+            uint32_t break_start = ranges[bi.first].first, end_spot = bi.second[0];
+            std::vector<uint32_t> np;
+            for (uint32_t r : parts[bi.first]) {
+                if (L[r] <= end_spot) np.push_back(r);
+                else {                                                   // :69-84: this read is not re-inserted
+                    new_parts.push_back(std::move(np)); np.clear();
+                    new_ranges.push_back({break_start, end_spot});
+                    break_start = end_spot + 1;
+                    ++spot;
+                    end_spot = spot != bi.second.size() ? bi.second[spot] : UINT32_MAX;
+                }
+            }
+            new_parts.push_back(std::move(np));
+            new_ranges.push_back({break_start, ranges[bi.first].second});
+        }
+        for (auto& bi : all_breaks) parts[bi.first].clear();
+        for (size_t i = 0; i < new_parts.size(); ++i) { parts.push_back(std::move(new_parts[i])); ranges.push_back(new_ranges[i]); }
+    }
+    std::vector<size_t> idx(parts.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ranges[a] < ranges[b]; });
+    floria_groups* G = (floria_groups*)calloc(1, sizeof(floria_groups));
+    if (!G) return fail(FLORIA_E_NOMEM, "calloc");
+    G->n_groups = (uint32_t)parts.size();
+    G->grp_off = (uint64_t*)calloc(parts.size() + 1, 8);
+    G->range = (uint32_t*)calloc(2 * parts.size() + 2, 4);
+    uint64_t tot = 0;
+    for (size_t k = 0; k < idx.size(); ++k) { G->grp_off[k] = tot; tot += parts[idx[k]].size(); G->range[2 * k] = ranges[idx[k]].first; G->range[2 * k + 1] = ranges[idx[k]].second; }
+    G->grp_off[idx.size()] = tot;
+    G->grp_read = (uint32_t*)malloc(4 * (tot + 1));
+    for (size_t k = 0; k < idx.size(); ++k) std::copy(parts[idx[k]].begin(), parts[idx[k]].end(), G->grp_read + G->grp_off[k]);
+    *out = G;
+    return 0;
+}
+void floria_hip_groups_free(floria_groups* g) { if (g) { free(g->grp_off); free(g->grp_read); free(g->range); free(g); } }
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// optimize_kernel.h — iterative MEC optimisation + MEC statistics of one (SNP block, ploidy) job per
+// 256-thread workgroup, then the ploidy stop rule and the final gather.
+//
+// Follows local_clustering.rs:71-130 (optimize_clustering), :292-358 (opt_iterate), :218-260
+// (get_mec_stats_epsilon), :187-215 (get_mec_stats_epsilon_no_phred), utils_frags.rs:160-184
+// (hap_block_from_partition) and graph_processing.rs:156-162,196-251 (mec_vector, stop rule).
+//
+// Layout: one histogram slab per resident job, [pos][partition][allele] u64 cells holding
+// (read count << 44 | Q24 weighted sum): the phred histogram (hap_block_from_partition(.., true)) and the
+// unit-count histogram (.., false) of the reference are the two fields of the same cell, so
+// get_mec_stats_epsilon_no_phred needs no second pass over the reads.  opt_iterate's candidate moves are
+// sorted with a bitonic network on the key (gain desc, partition asc, read asc, target asc), which is the
+// reference's stable sort_by over its enumeration order with set iteration canonicalised to ascending
+// counter_id (DESIGN.md "Iteration order").
+#pragma once
+#include "common.h"
+
+namespace fl {
+
+constexpr int OPT_THREADS = 256;
+constexpr int OPT_SORT_LDS = 2048;        // candidates sorted in LDS up to this many
+constexpr int NUM_ITER_OPTIMIZE = 20;     // constants.rs:3
+
+struct OptArgs {
+    BlockSet bs;
+    const uint32_t* job_block;
+    uint32_t  n_jobs;
+    uint32_t  ploidy, max_ploidy;
+    uint32_t  span_max, n_max;
+    uint32_t* queue_head;
+    const uint8_t* blk_done;
+    double    eps;
+    const uint8_t* part_in;      // beam output  [total reads]
+    uint8_t*  part_out;          // optimised    [total reads]  (this ploidy's plane)
+    uint64_t* hist_pool;         // [slots][span_max*ploidy*A]
+    double*   dist_pool;         // [slots][n_max*ploidy]
+    uint64_t* cand_gain_pool;    // [slots][cand_cap]   (f64 bits of the gain)
+    uint32_t* cand_key_pool;     // [slots][cand_cap]
+    uint32_t* moves_pool;        // [slots][n_max]      applied moves (read_local << 8 | from << 4 | to)
+    uint64_t  cand_cap;          // pow2 >= n_max*(ploidy-1)
+    double*   mec;               // [n_blocks*max_ploidy]   mec_vector[p-1]
+    double*   num_alleles;       // [n_blocks*max_ploidy]
+    uint32_t* iters;             // [n_blocks*max_ploidy]   optimisation rounds run (diagnostic)
+};
+
+__device__ __forceinline__ bool cand_before(uint64_t ga, uint32_t ka, uint64_t gb, uint32_t kb) {
+    return ga > gb || (ga == gb && ka < kb);
+}
+
+// bitonic sort of n (pow2) candidates, ascending in cand_before order
+template <class G, class K>
+__device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthreads) {
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n; i += nthreads) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t ga = gain[i], gb = gain[ixj];
+                    uint32_t ka = key[i], kb = key[ixj];
+                    bool up = (i & k) == 0;
+                    bool sw = up ? cand_before(gb, kb, ga, ka) : cand_before(ga, ka, gb, kb);
+                    if (sw) { gain[i] = gb; gain[ixj] = ga; key[i] = kb; key[ixj] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int A>
+__global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
+    extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded]
+    __shared__ uint64_t s_gain[OPT_SORT_LDS];
+    __shared__ uint32_t s_key[OPT_SORT_LDS];
+    __shared__ uint64_t s_redq[OPT_THREADS / 64], s_redq2[OPT_THREADS / 64];
+    __shared__ uint32_t s_redm[OPT_THREADS / 64];
+    __shared__ uint64_t s_errq[MAX_PLOIDY], s_goodq[MAX_PLOIDY];
+    __shared__ uint32_t s_errm[MAX_PLOIDY];
+    __shared__ uint32_t s_size[MAX_PLOIDY];
+    __shared__ uint32_t s_ncand, s_nmoves, s_job;
+    __shared__ double s_score;
+    uint32_t* s_moved = (uint32_t*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t p = g.ploidy, PA = p * A;
+    uint64_t* hist = g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
+    double* dist = g.dist_pool + (uint64_t)blockIdx.x * g.n_max * p;
+    uint64_t* cgain = g.cand_gain_pool + (uint64_t)blockIdx.x * g.cand_cap;
+    uint32_t* ckey = g.cand_key_pool + (uint64_t)blockIdx.x * g.cand_cap;
+    uint32_t* moves = g.moves_pool + (uint64_t)blockIdx.x * g.n_max;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_job = atomicAdd(g.queue_head, 1u);
+        __syncthreads();
+        const uint32_t job = s_job;
+        if (job >= g.n_jobs) break;
+        const uint32_t b = g.job_block[job];
+        if (g.blk_done[b]) continue;
+        const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
+        const uint64_t roff = g.bs.blk_read_off[b];
+        const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
+        const uint32_t* reads = g.bs.blk_read + roff;
+        const uint32_t pos0 = g.bs.blk_pos0[b], span = g.bs.blk_span[b];
+        const uint8_t* pin = g.part_in + roff;
+        uint8_t* part = g.part_out + roff;
+        const uint32_t ncell = span * PA;
+
+        // ---- hap_block_from_partition (utils_frags.rs:177-184): phred sums and unit counts in one cell -----
+        for (uint32_t x = tid; x < ncell; x += OPT_THREADS) hist[x] = 0;
+        if (tid < MAX_PLOIDY) s_size[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += OPT_THREADS) {
+            const uint32_t r = reads[i], k = pin[i];
+            part[i] = (uint8_t)k;
+            atomicAdd(&s_size[k], 1u);
+            const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+            for (uint32_t c = cb; c < ce; ++c) {
+                const uint32_t aq = cd.cell_aq[c];
+                atomicAdd((unsigned long long*)&hist[(uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A + (aq >> 8)],
+                          (unsigned long long)((1ull << CNT_SHIFT) | c_w24[aq & 0xff]));
+            }
+        }
+        __syncthreads();
+
+        // get_mec_stats_epsilon (local_clustering.rs:218-260) -> per-partition (errors Q24, #eps) and
+        // _no_phred (:187-215) -> (good count, bad count, #eps); returns score = -(sum_k errors_k) via s_score
+        auto mec_stats = [&](bool phred) {
+            for (uint32_t k = 0; k < p; ++k) {
+                uint64_t eq = 0, gq = 0;
+                uint32_t em = 0;
+                for (uint32_t pr = tid; pr < span; pr += OPT_THREADS) {
+                    const uint64_t* cp = hist + (uint64_t)pr * PA + k * A;
+                    uint64_t mx = 0, tot = 0, cn = 0;
+#pragma unroll
+                    for (int al = 0; al < A; ++al) {
+                        const uint64_t v = cp[al];
+                        const uint64_t q = phred ? (v & QMASK44) : (v >> CNT_SHIFT);
+                        mx = q > mx ? q : mx; tot += q; cn += v >> CNT_SHIFT;
+                    }
+                    if (cn) {                                   // position key exists in the partition's map
+                        gq += mx; eq += tot - mx;
+                        if (mx <= (phred ? ONE_Q24 : 1ull)) em += 1;           // cons_bases <= 1. -> errors += epsilon
+                    }
+                }
+                eq = wave_sum_u64(eq); gq = wave_sum_u64(gq); em = wave_sum_u32(em);
+                if (lane == 0) { s_redq[wid] = eq; s_redq2[wid] = gq; s_redm[wid] = em; }
+                __syncthreads();
+                if (tid == 0) {
+                    uint64_t a = 0, c = 0; uint32_t m2 = 0;
+                    for (int w = 0; w < OPT_THREADS / 64; ++w) { a += s_redq[w]; c += s_redq2[w]; m2 += s_redm[w]; }
+                    s_errq[k] = a; s_goodq[k] = c; s_errm[k] = m2;
+                }
+                __syncthreads();
+            }
+            if (tid == 0 && phred) {
+                double s = 0.0;                                 // binom_vec.iter().map(|x| x.1).sum() * -1.
+                for (uint32_t k = 0; k < p; ++k) s += qm_to_f64(s_errq[k], s_errm[k], g.eps);
+                s_score = s * -1.0;
+            }
+            __syncthreads();
+        };
+
+        bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
+        uint32_t iters_done = 0;
+        if (not_empty) {
+            mec_stats(true);
+            double prev_score = s_score;
+            for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
+                iters_done = it + 1;
+                // ---- opt_iterate (:292-358): distance of every read to every partition ------------------------
+                for (uint32_t pair = tid; pair < n * p; pair += OPT_THREADS) {
+                    const uint32_t i = pair / p, k = pair - i * p;
+                    const uint32_t r = reads[i];
+                    const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+                    uint64_t qd = 0; uint32_t m = 0;
+                    for (uint32_t c = cb; c < ce; ++c) {
+                        const uint32_t aq = cd.cell_aq[c], al = aq >> 8;
+                        const uint64_t* cp = hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A;
+                        uint64_t mx = 0, va = 0;
+#pragma unroll
+                        for (int x = 0; x < A; ++x) { const uint64_t q = cp[x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
+                        if (mx == 0) m += 1;
+                        else if (va != mx) qd += c_w24[aq & 0xff];
+                    }
+                    dist[pair] = qm_to_f64(qd, m, g.eps);
+                }
+                if (tid == 0) { s_ncand = 0; s_nmoves = 0; }
+                for (uint32_t x = tid; x < (n + 31) / 32; x += OPT_THREADS) s_moved[x] = 0;
+                __syncthreads();
+                for (uint32_t pair = tid; pair < n * p; pair += OPT_THREADS) {
+                    const uint32_t i = pair / p, j = pair - i * p;
+                    const uint32_t pi = part[i];
+                    if (j == pi || s_size[pi] <= 1) continue;                   // :300-302, :309-311
+                    const double diff_score = dist[i * p + pi] - dist[pair];    // :320
+                    if (diff_score > 0.0) {
+                        const uint32_t idx = atomicAdd(&s_ncand, 1u);
+                        cgain[idx] = (uint64_t)__double_as_longlong(diff_score);
+                        ckey[idx] = (pi << 28) | (i << 4) | j;
+                    }
+                }
+                __syncthreads();
+                const uint32_t M = s_ncand;
+                if (M == 0) break;          // new_part == best_part -> new_score == prev_score -> not accepted (:114-126)
+                uint32_t M2 = 1;
+                while (M2 < M) M2 <<= 1;
+                const bool in_lds = M2 <= OPT_SORT_LDS;
+                if (in_lds) {
+                    for (uint32_t x = tid; x < M2; x += OPT_THREADS) { s_gain[x] = x < M ? cgain[x] : 0; s_key[x] = x < M ? ckey[x] : 0xffffffffu; }
+                    __syncthreads();
+                    bitonic_sort(s_gain, s_key, M2, tid, OPT_THREADS);          // best_moves.sort_by(desc) :330
+                } else {
+                    for (uint32_t x = M + tid; x < M2; x += OPT_THREADS) { cgain[x] = 0; ckey[x] = 0xffffffffu; }
+                    __syncthreads();
+                    bitonic_sort(cgain, ckey, M2, tid, OPT_THREADS);
+                }
+                // ---- serial application (:336-356) --------------------------------------------------------------
+                if (tid == 0) {
+                    uint32_t number_of_moves = M / 10;
+                    if (number_of_moves == 0 && M > 0) number_of_moves = M / 3 + 1;
+                    uint32_t nm = 0;
+                    for (uint32_t mv = 0; mv < M; ++mv) {
+                        const uint32_t key = in_lds ? s_key[mv] : ckey[mv];
+                        const uint32_t i = key >> 28, rl = (key >> 4) & 0xffffffu, j = key & 15;
+                        if (s_moved[rl >> 5] & (1u << (rl & 31))) continue;
+                        if (s_size[i] == 1) continue;
+                        s_size[j] += 1; s_size[i] -= 1;
+                        s_moved[rl >> 5] |= 1u << (rl & 31);
+                        moves[nm++] = (rl << 8) | (i << 4) | j;
+                        if (mv > number_of_moves) break;
+                    }
+                    s_nmoves = nm;
+                }
+                __syncthreads();
+                const uint32_t nm = s_nmoves;
+                // apply to histogram + partition (direction +1), or undo (direction -1)
+                auto apply_moves = [&](bool undo) {
+                    for (uint32_t x = wid; x < nm; x += OPT_THREADS / 64) {
+                        const uint32_t mvv = moves[x], rl = mvv >> 8;
+                        uint32_t from = (mvv >> 4) & 15, to = mvv & 15;
+                        if (undo) { uint32_t t = from; from = to; to = t; }
+                        const uint32_t r = reads[rl];
+                        const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+                        for (uint32_t c = cb + lane; c < ce; c += 64) {
+                            const uint32_t aq = cd.cell_aq[c];
+                            const unsigned long long d = (1ull << CNT_SHIFT) | c_w24[aq & 0xff];
+                            uint64_t* cp = hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + (aq >> 8);
+                            atomicAdd((unsigned long long*)(cp + from * A), 0ull - d);
+                            atomicAdd((unsigned long long*)(cp + to * A), d);
+                        }
+                        if (lane == 0) part[rl] = (uint8_t)to;
+                    }
+                    __syncthreads();
+                };
+                apply_moves(false);
+                mec_stats(true);
+                const double new_score = s_score;
+                if (new_score > prev_score) prev_score = new_score;
+                else {                                   // rejected: keep best_part / prev_hap_block
+                    apply_moves(true);
+                    if (tid == 0) for (uint32_t x = 0; x < nm; ++x) { const uint32_t mvv = moves[x]; s_size[(mvv >> 4) & 15] += 1; s_size[mvv & 15] -= 1; }
+                    __syncthreads();
+                    break;
+                }
+            }
+        }
+        // ---- get_mec_stats_epsilon_no_phred of the optimised partition (graph_processing.rs:156-162) -----------
+        mec_stats(false);
+        if (tid == 0) {
+            double mecv = 0.0, na = 0.0;
+            for (uint32_t k = 0; k < p; ++k) {
+                const double good = (double)s_goodq[k];
+                const double bad = (double)s_errq[k] + (double)s_errm[k] * g.eps;
+                mecv += bad; na += good; na += bad;
+            }
+            g.mec[(uint64_t)b * g.max_ploidy + p - 1] = mecv;
+            g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] = na;
+            g.iters[(uint64_t)b * g.max_ploidy + p - 1] = iters_done;
+        }
+    }
+}
+
+// ---- ploidy stop rule (graph_processing.rs:196-251), one thread per block, after ploidy p finished ----------
+struct SelectArgs {
+    uint32_t n_blocks, ploidy, max_ploidy;
+    int32_t  stopping_heuristic;
+    double   eps, mec_threshold;     // threshold for THIS ploidy, computed on the host with libm pow (:204-220)
+    const uint64_t* blk_read_off;
+    const double* mec;
+    const double* num_alleles;
+    uint8_t*  blk_done;
+    uint32_t* best_ploidy;
+    uint32_t* tried;
+};
+__global__ void select_kernel(SelectArgs g) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.n_blocks || g.blk_done[b]) return;
+    if (g.blk_read_off[b + 1] == g.blk_read_off[b]) { g.blk_done[b] = 1; g.best_ploidy[b] = 0; g.tried[b] = 0; return; }
+    const uint32_t p = g.ploidy;
+    const double mec_p = g.mec[(uint64_t)b * g.max_ploidy + p - 1];
+    const double expected = g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] * g.eps;         // :196
+    uint32_t best = p;
+    bool stop = false;
+    if (p > 1) {
+        const double mec_prev = g.mec[(uint64_t)b * g.max_ploidy + p - 2];
+        if ((mec_p / mec_prev) < g.mec_threshold) { /* do nothing */ }
+        else if (g.stopping_heuristic) { best = p - 1; stop = true; }                         // :233-238
+        if (!stop && mec_p < expected) stop = true;                                           // :240-243
+    } else if (mec_p < expected) stop = true;                                                 // :247-250
+    g.tried[b] = p;
+    if (stop || p == g.max_ploidy) { g.blk_done[b] = 1; g.best_ploidy[b] = best; }
+}
+
+// final partition of every read of every block at the chosen ploidy
+__global__ void gather_kernel(uint32_t n_blocks, const uint64_t* blk_read_off, const uint32_t* best_ploidy,
+                              const uint8_t* part_planes, uint64_t plane_stride, uint8_t* out) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t bp = best_ploidy[b];
+    if (bp == 0) return;
+    const uint8_t* src = part_planes + (uint64_t)(bp - 1) * plane_stride;
+    for (uint64_t i = blk_read_off[b] + threadIdx.x; i < blk_read_off[b + 1]; i += blockDim.x) out[i] = src[i];
+}
+
+}  // namespace fl

@@ -1,0 +1,90 @@
+// reassign_kernel.h — final read -> haplogroup reassignment, one contig per wavefront.
+//
+// Follows part_block_manip.rs:184-222 (process_reads_for_final_parts): every read that sits in >= 1
+// stitched haplogroup is removed from all of them (:195-200 — after which every histogram is empty) and
+// greedily re-inserted into the candidate with minimal (diff + 1, id, same) (:203-222), the histograms
+// being updated after every insertion (add_read_to_block, utils_frags.rs:465-474).  The chain is
+// sequentially dependent; reads are visited in ascending counter_id (DESIGN.md "Iteration order").
+// separate_broken_haplogroups / sort_parts (:27-98, :276-288) are integer bookkeeping done by the host.
+#pragma once
+#include "common.h"
+
+namespace fl {
+
+struct ReassignArgs {
+    const ContigDev* contigs;
+    uint32_t n_contigs;
+    // per contig (CSR over contigs)
+    const uint64_t* r2g_off_base;   // [n_contigs]   offset of the contig's read->groups offsets array
+    const uint64_t* r2g_off;        // per contig: [n_reads+1] offsets into r2g (relative to the contig's r2g base)
+    const uint64_t* r2g_base;       // [n_contigs]
+    const uint32_t* r2g;            // candidate group ids (contig-local, ascending) of every read
+    const uint64_t* grp_base;       // [n_contigs]   first group slot of the contig
+    const uint64_t* grp_hist_off;   // [total groups] offset (u64 cells) of the group's histogram window
+    const uint32_t* grp_pos0;       // [total groups] first SNP position of the window
+    uint64_t* hist;                 // zero-initialised, [sum window*A]
+    int32_t*  assign;               // per contig reads: chosen contig-local group id or -1
+    const uint64_t* assign_base;    // [n_contigs]
+    double eps;
+    uint32_t* queue_head;
+};
+
+template <int A>
+__global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
+    const int lane = threadIdx.x;
+    for (;;) {
+        uint32_t ci = 0;
+        if (lane == 0) ci = atomicAdd(g.queue_head, 1u);
+        ci = __shfl(ci, 0);
+        if (ci >= g.n_contigs) break;
+        const ContigDev cd = g.contigs[ci];
+        const uint64_t* roff = g.r2g_off + g.r2g_off_base[ci];
+        const uint32_t* r2g = g.r2g + g.r2g_base[ci];
+        const uint64_t gb = g.grp_base[ci];
+        int32_t* assign = g.assign + g.assign_base[ci];
+        for (uint32_t r = 0; r < cd.n_reads; ++r) {
+            const uint64_t c0 = roff[r], c1 = roff[r + 1];
+            if (c0 == c1) { if (lane == 0) assign[r] = -1; continue; }
+            const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+            uint32_t best = r2g[c0];
+            if (c1 - c0 > 1) {
+                double bd = 0.0, bsame = 0.0;
+                bool have = false;
+                for (uint64_t x = c0; x < c1; ++x) {
+                    const uint32_t gid = r2g[x];
+                    const uint64_t* h = g.hist + g.grp_hist_off[gb + gid];
+                    const uint32_t p0 = g.grp_pos0[gb + gid];
+                    uint64_t qs = 0, qd = 0; uint32_t m = 0;
+                    for (uint32_t c = cb + lane; c < ce; c += 64) {          // utils_frags.rs:32-75
+                        const uint32_t aq = cd.cell_aq[c], al = aq >> 8;
+                        const uint64_t* cp = h + (uint64_t)(cd.cell_snp[c] - p0) * A;
+                        uint64_t mx = 0, va = 0;
+#pragma unroll
+                        for (int a = 0; a < A; ++a) { const uint64_t q = cp[a]; mx = q > mx ? q : mx; va = (a == (int)al) ? q : va; }
+                        if (mx == 0) m += 1;
+                        else if (va == mx) qs += c_w24[aq & 0xff];
+                        else qd += c_w24[aq & 0xff];
+                    }
+                    qs = wave_sum_u64(qs); qd = wave_sum_u64(qd); m = wave_sum_u32(m);
+                    const double kd = qm_to_f64(qd, m, g.eps) + 1.;              // (diff + 1., id, same) :211
+                    const double ks = qm_to_f64(qs, 0, g.eps);
+                    const bool less = !have || kd < bd || (kd == bd && (gid < best || (gid == best && ks < bsame)));
+                    if (less) { have = true; bd = kd; bsame = ks; best = gid; }
+                }
+            }
+            // add_read_to_block (utils_frags.rs:465-474)
+            {
+                uint64_t* h = g.hist + g.grp_hist_off[gb + best];
+                const uint32_t p0 = g.grp_pos0[gb + best];
+                for (uint32_t c = cb + lane; c < ce; c += 64) {
+                    const uint32_t aq = cd.cell_aq[c];
+                    h[(uint64_t)(cd.cell_snp[c] - p0) * A + (aq >> 8)] += c_w24[aq & 0xff];
+                }
+            }
+            if (lane == 0) assign[r] = (int32_t)best;
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace fl

@@ -1,0 +1,188 @@
+"""ctypes binding of libfloria_hip.so (include/floria_hip.h) — the Python mirror of the two reference
+seams: `generate_hap_graph`'s per-block loop (graph_processing.rs:325-372) and
+`process_reads_for_final_parts` (part_block_manip.rs:174-274).
+
+No fallback: if the shared library is missing or no HIP device is usable, everything here raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _capi as capi
+from .pileup import Pileup
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libfloria_hip.so")
+_LIB = None
+
+# every symbol include/floria_hip.h declares
+SYMBOLS = [
+    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version",
+    "floria_hip_block_ranges", "floria_hip_ranges_free", "floria_hip_contig_upload", "floria_hip_contig_free",
+    "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
+    "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
+    "floria_hip_set_slots",
+]
+
+
+class FloriaHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfloria_hip rc={code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile libfloria_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "floria_hip.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", _CSRC, "-B", "libfloria_hip.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise FloriaHipError(-2, f"{_SO} is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_SO)
+        L.floria_hip_last_error.restype = C.c_char_p
+        L.floria_hip_version.restype = C.c_char_p
+        for s in ("floria_hip_destroy", "floria_hip_ranges_free", "floria_hip_contig_free", "floria_hip_block_result_free", "floria_hip_groups_free"):
+            getattr(L, s).restype = None
+        L.floria_hip_destroy.argtypes = [C.c_void_p]
+        L.floria_hip_contig_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise FloriaHipError(rc, load().floria_hip_last_error().decode())
+
+
+def make_params(epsilon, max_ploidy=5, beam=10, ploidy_sensitivity=2, stopping_heuristic=1):
+    """The hot-path fields of `Options` (types_structs.rs:20-51) with the CLI defaults
+    (parse_cmd_line.rs: -p 5, -n 10, -s 2, stopping heuristic on)."""
+    return capi.CParams(float(epsilon), int(max_ploidy), int(beam), int(ploidy_sensitivity), int(stopping_heuristic))
+
+
+def get_range_with_lengths(snp_to_genome_pos, block_length, overlap_len=None, minimal_density=0.0005):
+    """utils_frags::get_range_with_lengths (utils_frags.rs:405-463); overlap defaults to block_length/3
+    as in generate_hap_graph (graph_processing.rs:334-339).  Returns (start, end) uint32 arrays, 1-based inclusive."""
+    g = np.ascontiguousarray(snp_to_genome_pos, np.uint64)
+    if overlap_len is None:
+        overlap_len = block_length // 3
+    out = C.POINTER(capi.CRanges)()
+    _check(load().floria_hip_block_ranges(capi.ptr(g, C.c_uint64), C.c_uint32(len(g)), C.c_uint64(block_length), C.c_uint64(overlap_len),
+                                          C.c_double(minimal_density), C.byref(out)))
+    r = out.contents
+    res = (capi.np_from(r.start, r.n, np.uint32), capi.np_from(r.end, r.n, np.uint32))
+    load().floria_hip_ranges_free(out)
+    return res
+
+
+class ResidentContig:
+    def __init__(self, ctx, pileup: Pileup):
+        self.ctx = ctx
+        self.n_reads = pileup.n_reads
+        cp = pileup.as_c()
+        h = C.c_void_p()
+        _check(load().floria_hip_contig_upload(ctx._h, C.byref(cp), C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if self._h:
+            load().floria_hip_contig_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FloriaHip:
+    """One context per device (floria_hip_create)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(load().floria_hip_create(C.c_int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            load().floria_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_slots(self, n):
+        _check(load().floria_hip_set_slots(self._h, C.c_uint32(n)))
+
+    def upload(self, pileup: Pileup):
+        return ResidentContig(self, pileup)
+
+    def timing(self):
+        t = capi.CTiming()
+        _check(load().floria_hip_last_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in capi.CTiming._fields_}
+
+    # S1 --------------------------------------------------------------------------------------------
+    def phase_blocks(self, contig, blk_start, blk_end, params):
+        """get_local_hap_blocks for every (start,end) SNP range of one contig (graph_processing.rs:345-362)."""
+        if isinstance(contig, Pileup):
+            rc = self.upload(contig)
+            try:
+                return self.phase_blocks(rc, blk_start, blk_end, params)
+            finally:
+                rc.free()
+        bs = np.ascontiguousarray(blk_start, np.uint32)
+        be = np.ascontiguousarray(blk_end, np.uint32)
+        out = C.POINTER(capi.CBlockResult)()
+        _check(load().floria_hip_phase_blocks_resident(self._h, contig._h, capi.ptr(bs, C.c_uint32), capi.ptr(be, C.c_uint32),
+                                                       C.c_uint32(len(bs)), C.byref(params), C.byref(out)))
+        res = capi.BlockResult(out.contents)
+        load().floria_hip_block_result_free(out)
+        return res
+
+    def phase_blocks_batch(self, contigs, blk_contig, blk_start, blk_end, params, copy_out=True):
+        arr = (C.c_void_p * len(contigs))(*[c._h for c in contigs])
+        bc = np.ascontiguousarray(blk_contig, np.uint32)
+        bs = np.ascontiguousarray(blk_start, np.uint32)
+        be = np.ascontiguousarray(blk_end, np.uint32)
+        out = C.POINTER(capi.CBlockResult)()
+        _check(load().floria_hip_phase_blocks_batch(self._h, arr, C.c_uint32(len(contigs)), capi.ptr(bc, C.c_uint32), capi.ptr(bs, C.c_uint32),
+                                                    capi.ptr(be, C.c_uint32), C.c_uint32(len(bs)), C.byref(params), C.byref(out)))
+        res = capi.BlockResult(out.contents) if copy_out else None
+        load().floria_hip_block_result_free(out)
+        return res
+
+    # S2 --------------------------------------------------------------------------------------------
+    def reassign(self, contig, groups, ranges, epsilon):
+        """process_reads_for_final_parts (part_block_manip.rs:174-274): groups = list of read-id arrays,
+        ranges = [(start,end)] -> _capi.Groups"""
+        if isinstance(contig, Pileup):
+            rc = self.upload(contig)
+            try:
+                return self.reassign(rc, groups, ranges, epsilon)
+            finally:
+                rc.free()
+        off = np.zeros(len(groups) + 1, np.uint64)
+        off[1:] = np.cumsum([len(g) for g in groups])
+        reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
+        rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+        out = C.POINTER(capi.CGroups)()
+        _check(load().floria_hip_reassign(self._h, contig._h, capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
+                                          C.c_uint32(len(groups)), C.c_double(epsilon), C.byref(out)))
+        g = capi.Groups(out.contents)
+        load().floria_hip_groups_free(out)
+        return g
