@@ -1,0 +1,126 @@
+"""Known-answer tests that pin the CPU oracle (oracle/floria_oracle.cpp).
+
+The reference ships no tests or golden vectors for this path and cannot be built here,
+so these KATs are derived BY HAND from the reference source (citations inline).  `-m "not gpu"`.
+"""
+import numpy as np
+import pytest
+
+from floria_amd.pileup import Pileup
+
+EPS = 0.03125   # dyadic: every f64 sum on the path is exact
+
+
+def test_weights_are_q24_and_match_f32_formula(oracle_mod):
+    # utils_frags.rs:702-711: prob = 1f32 - 10f32.powf(q as f32 / -10.)
+    w = oracle_mod.weight_q24()
+    # numpy's own float32 pow is 1 ulp off for some q (e.g. q=2), so the expectation is the correctly rounded
+    # powf: evaluate 10^x in float64 on the float32 argument and round once to float32 (what glibc powf returns)
+    x = np.arange(256, dtype=np.float32) / np.float32(-10.0)
+    pw = np.power(10.0, x.astype(np.float64)).astype(np.float32)
+    expect = (np.float32(1.0) - pw).astype(np.float64) * 2.0 ** 24
+    assert np.array_equal(expect, np.floor(expect)), "w(q) must be a multiple of 2^-24"
+    assert np.array_equal(w.astype(np.float64), expect)
+    assert w[0] == 0 and w[255] == 2 ** 24 and w[20] == int(round(0.99 * 2 ** 24))
+
+
+def test_binary_heap_matches_hand_traces(oracle_mod):
+    # std BinaryHeap, traced by hand:
+    # two tied pushes keep insertion order in the array; into_sorted_vec swaps them
+    h, s = oracle_mod.heap_trace([1.0, 1.0], 10)
+    assert list(h) == [0, 1] and list(s) == [1, 0]
+    # five ties with capacity 3: push0..2 -> [0,1,2]; push3 -> [0,1,2,3]; pop: last(3)->root, old root 0 evicted,
+    # sift_down_to_bottom picks the RIGHT child on ties (`<=`) -> [2,1,3]; push4, pop evicts 2 -> [3,1,4]
+    h, s = oracle_mod.heap_trace([2.0] * 5, 3)
+    assert list(h) == [3, 1, 4] and list(s) == [1, 4, 3]
+    # distinct scores: the 4 smallest survive, worst popped each time; sorted ascending
+    h, s = oracle_mod.heap_trace([3., 1., 2., 1., 3., 2., 0.5], 4)
+    assert sorted(h) == [1, 3, 5, 6] or sorted(h) == [1, 2, 3, 6]
+    assert [float([3., 1., 2., 1., 3., 2., 0.5][i]) for i in s] == sorted([[3., 1., 2., 1., 3., 2., 0.5][i] for i in h])
+
+
+def test_stable_binom_cdf_p_rev_values(oracle_mod):
+    # utils_frags.rs:211-248 evaluated by hand with numpy (same libm)
+    def ref(n, k, p, div=0.25):
+        if n == 0:
+            return 0.0
+        a = k / n
+        if a == 1.0:
+            a = 0.9999999
+        if a == 0.0:
+            a = 0.0000001
+        rel = a * np.log(a / p) + (1.0 - a) * np.log((1.0 - a) / (1.0 - p))
+        if a < p:
+            rel = -rel
+        return -1.0 * n / div * rel
+    for n, k in [(0, 0), (3, 3), (10, 1), (10, 0), (100, 3), (100, 4), (7, 7), (500, 250)]:
+        assert oracle_mod.binom(n, k, EPS) == pytest.approx(ref(n, k, EPS), rel=1e-13, abs=1e-13)
+    assert oracle_mod.binom(3, 3, EPS) == pytest.approx(-41.5888, abs=1e-3)      # SURVEY.md Appendix E value
+
+
+def kat1_pileup():
+    # 6 reads x 4 SNPs, read i carries allele i%2 everywhere, q=20
+    return Pileup.from_reads([([1, 2, 3, 4], [i % 2] * 4, [20] * 4) for i in range(6)])
+
+
+def test_kat1_two_clean_strains(oracle_mod):
+    r = oracle_mod.phase_blocks(kat1_pileup(), [1], [4], oracle_mod.make_params(EPS, 5, 10, 2, 1))
+    # ploidy 1: 4 sites x 3 minority reads = 12 (unit weights); expected = 24*eps = 0.75 -> continue
+    # ploidy 2: two mirrored lineages tie at MEC 0.25; into_sorted_vec on the tied 2-heap picks the SECOND
+    # lineage -> partition[0] = {1,3,5}, partition[1] = {0,2,4}; mec 0 < 0.75 -> best_ploidy = 2
+    assert list(r.best_ploidy) == [2] and list(r.ploidies_tried) == [2]
+    assert list(r.mec[0]) == [12.0, 0.0, 0.0, 0.0, 0.0]
+    parts = r.partitions(0)
+    assert list(parts[0]) == [1, 3, 5] and list(parts[1]) == [0, 2, 4]
+
+
+def test_kat2_single_read_and_empty_block(oracle_mod):
+    p = Pileup.from_reads([([3, 4, 5], [0, 1, 0], [30, 30, 30])])
+    r = oracle_mod.phase_blocks(p, [1, 3], [2, 5], oracle_mod.make_params(EPS, 3, 10))
+    # block (1,2): no read has last >= 1 and first <= 2 -> None (graph_processing.rs:129-131)
+    assert r.best_ploidy[0] == 0 and r.read_off[1] == 0
+    # block (3,5): one read; ploidy 1: every site has max count 1 <= 1 -> errors = 3*eps, bases 3,
+    # expected = (3 + 3 eps) * eps; 3 eps = 0.09375 >= 0.0966..? 0.09375 < 0.09668 -> stop at ploidy 1
+    assert r.best_ploidy[1] == 1 and r.mec[1, 0] == 3 * EPS
+    assert list(r.block(1)[0]) == [0] and list(r.block(1)[1]) == [0]
+
+
+def test_kat3_q0_observation_counts_as_present_but_weightless(oracle_mod):
+    # a q=0 cell has w=0 (utils_frags.rs:706): it creates the allele key (set_to_seq_dict :166-168) so the
+    # no_phred histogram counts it, but it never contributes to same/diff
+    p = Pileup.from_reads([([1, 2], [0, 0], [0, 30]), ([1, 2], [1, 0], [30, 30]), ([1, 2], [1, 0], [30, 30])])
+    rid, pb, po, mec, na, it = oracle_mod.one_ploidy(p, 1, 2, 1, EPS)
+    # ploidy 1 unit counts: site 1 -> {0:1, 1:2}: bases 2, errors 1; site 2 -> {0:3}: bases 3; mec = 1
+    assert mec == 1.0 and na == 6.0
+
+
+def test_get_range_with_lengths_hand_example(oracle_mod):
+    # utils_frags.rs:405-463 traced by hand: positions 100,200,...,1000; block 300, overlap 100
+    pos = np.arange(1, 11) * 100
+    s, e = oracle_mod.block_ranges(pos, 300, 100, 0.0005)
+    # i=1..3: cum=100,200,300 (hit_new_left at cum>200 -> i=3); i=4: cum=400>300 -> push (0,3); left: g[3]+300<g[4]? no -> 4
+    # i=5: cum=100 (from g[4]) ... i=7: cum=300 -> new_left=7; i=8: cum=400 -> push (4,7); left=8; i=9 last -> push (8,9)
+    assert list(zip(s, e)) == [(1, 4), (5, 8), (9, 10)]
+
+
+def test_get_range_with_lengths_on_reference_vcf_positions(oracle_mod):
+    # block counts on tests/test.vcf's 954 SNP positions were computed independently in SURVEY.md §8d:
+    # 17 at -l 10000, 33 at 5000, 176 at 500 (fixture: the POS column only)
+    pos = np.load(__file__.rsplit("/", 1)[0] + "/golden/test_vcf_positions.npy")
+    assert len(pos) == 954
+    for L, n in ((10000, 17), (5000, 33), (500, 176)):
+        s, e = oracle_mod.block_ranges(pos, L)
+        assert len(s) == n
+        assert s[0] == 1 and e[-1] == 954 and np.all(s <= e)
+
+
+def test_dyadic_epsilon_mec_is_integer_plus_m_eps(oracle_mod):
+    rng = np.random.default_rng(3)
+    from tests.helpers import random_pileup
+    p = random_pileup(rng, 60, 30, 3)
+    r = oracle_mod.phase_blocks(p, [1, 11], [15, 30], oracle_mod.make_params(EPS, 4, 10))
+    m = r.mec / EPS
+    assert np.array_equal(m, np.round(m)), "mec_no_phred must be integer + m*eps"
+    for b in range(2):
+        ids, part = r.block(b)
+        assert np.all(part < r.best_ploidy[b]) and np.array_equal(ids, np.sort(ids))
