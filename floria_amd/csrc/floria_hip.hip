@@ -465,6 +465,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     std::vector<uint32_t> rids, pos0(n_blocks, 0), span(n_blocks, 0), bc(n_blocks, 0);
     uint32_t n_max = 1, span_max = 1, len_max = 1, nall = 2;
     uint64_t algo_bytes = 0;
+    std::vector<uint64_t> blk_bytes(n_blocks, 0);
     for (uint32_t b = 0; b < n_blocks; ++b) {
         const uint32_t ci = blk_contig ? blk_contig[b] : 0;
         if (ci >= n_contigs || !contigs[ci]) return fail(FLORIA_E_INVALID, "blk_contig out of range");
@@ -482,6 +483,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
             const auto& ro = contigs[ci]->h_read_off;
             for (size_t i = before; i < rids.size(); ++i) { const uint64_t L = ro[rids[i] + 1] - ro[rids[i]]; ab += 8 + (L + 3) / 4 + (L + 7) / 8 + L; }
             algo_bytes += ab;
+            blk_bytes[b] = ab;
         }
         len_max = std::max(len_max, contigs[ci]->max_len);
         nall = std::max(nall, contigs[ci]->n_alleles);
@@ -589,6 +591,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
     ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
     ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
+    for (uint32_t b = 0; b < n_blocks; ++b) { ctx->timing.beam_launch_bytes += blk_bytes[b] * R->ploidies_tried[b]; ctx->timing.jobs += R->ploidies_tried[b]; }
     *out = R;
     return 0;
 }

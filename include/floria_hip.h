@@ -116,6 +116,8 @@ typedef struct {
     uint32_t beam_launches, optimize_launches;
     uint64_t algorithmic_bytes;/* SURVEY.md §8(d) bytes(block) summed over the call's blocks */
     uint64_t beam_steps;       /* reads consumed by beam search, summed over (block, ploidy) jobs */
+    uint64_t beam_launch_bytes;/* sum over beam launches of bytes(block) of the blocks that launch phased */
+    uint64_t jobs;             /* (block, ploidy) jobs actually run */
 } floria_timing;
 
 typedef struct floria_hip_ctx floria_hip_ctx;
