@@ -25,6 +25,7 @@
 
 #include "../../include/floria_hip.h"
 #include "beam_kernel.h"
+#include "beam_fast_kernel.h"
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
 
@@ -95,6 +96,7 @@ struct floria_hip_contig {
     uint64_t n_cells = 0;
     uint32_t max_len = 0;       // max cells per read
     uint32_t n_alleles = 2;     // 2 or 4 (kernel template)
+    bool has_q0 = false;        // some cell has qual 0 (weight 0): presence != (weight sum > 0)
     std::vector<uint32_t> h_first, h_last, h_read_off;
     DevBuf d_read_off, d_first, d_last, d_snp, d_aq;
     fl::ContigDev dev{};
@@ -221,7 +223,7 @@ struct EventTimer {
 enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5 };
 
 template <int A>
-int run_phase(floria_hip_ctx* ctx, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const uint32_t* d_jobs,
+int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const uint32_t* d_jobs,
               uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
               uint8_t* d_beam_part, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
               uint32_t* d_tried, uint32_t* d_queue, unsigned long long* d_margin, uint32_t* d_diag,
@@ -260,8 +262,14 @@ int run_phase(floria_hip_ctx* ctx, const fl::BlockSet& bs, const std::vector<uin
             if (LY.total > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void*)fl::beam_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY.total));
             HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
+            const bool fast = LM <= 63 && (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull && !getenv("FLORIA_HIP_GENERIC_BEAM");
             int t = T.begin(K_BEAM);
-            hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), LY.total, ctx->stream, a);
+            if (fast) {
+                const fl::FastLds FL = fl::fast_lds_layout(LM, any_q0);
+                if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, ctx->stream, a);
+                else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, ctx->stream, a);
+            } else
+                hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), LY.total, ctx->stream, a);
             T.end(t);
             HIPCHK(hipGetLastError());
             ctx->timing.beam_launches++;
@@ -422,7 +430,7 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     c->h_last.assign(p->last, p->last + p->n_reads);
     c->h_read_off.assign(p->read_off, p->read_off + p->n_reads + (p->n_reads ? 1 : 0));
     std::vector<uint16_t> aq(nc);
-    for (uint64_t i = 0; i < nc; ++i) aq[i] = (uint16_t)((p->allele[i] << 8) | p->qual[i]);
+    for (uint64_t i = 0; i < nc; ++i) { aq[i] = (uint16_t)((p->allele[i] << 8) | p->qual[i]); if (p->qual[i] == 0) c->has_q0 = true; }
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         int r2 = b.ensure(std::max<size_t>(bytes, 16));
         if (r2) return r2;
@@ -464,6 +472,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     std::vector<uint64_t> roff(n_blocks + 1, 0);
     std::vector<uint32_t> rids, pos0(n_blocks, 0), span(n_blocks, 0), bc(n_blocks, 0);
     uint32_t n_max = 1, span_max = 1, len_max = 1, nall = 2;
+    bool any_q0 = false;
     uint64_t algo_bytes = 0;
     std::vector<uint64_t> blk_bytes(n_blocks, 0);
     for (uint32_t b = 0; b < n_blocks; ++b) {
@@ -487,6 +496,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
         }
         len_max = std::max(len_max, contigs[ci]->max_len);
         nall = std::max(nall, contigs[ci]->n_alleles);
+        any_q0 = any_q0 || contigs[ci]->has_q0;
     }
     if (n_max >= (1u << 20)) return fail(FLORIA_E_UNSUPPORTED, "more than 2^20 reads in one block");
     const uint64_t tot = rids.size();
@@ -543,7 +553,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     bs.blk_read_off = (const uint64_t*)(M + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
 
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
-    rc = run(ctx, bs, jobs, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
+    rc = run(ctx, any_q0, bs, jobs, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
              (uint8_t*)(M + s_bpart.off), (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
              (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T);
