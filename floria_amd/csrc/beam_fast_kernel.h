@@ -20,7 +20,13 @@
 namespace fl {
 
 constexpr int FAST_TILE = 256;
-constexpr int FAST_UNROLL = 8;
+#ifndef FLORIA_FAST_UNROLL
+#define FLORIA_FAST_UNROLL 8
+#endif
+#ifndef FLORIA_FAST_WAVES
+#define FLORIA_FAST_WAVES 2
+#endif
+constexpr int FAST_UNROLL = FLORIA_FAST_UNROLL;
 
 struct __align__(16) FastState { uint64_t q, h1, h2; uint32_t m; uint32_t bufk; };   // bufk = slab | partition << 16
 
@@ -115,7 +121,7 @@ struct RegHeap {
 };
 
 template <int A, bool Q0>
-__global__ __launch_bounds__(64) void beam_fast_kernel(BeamArgs g) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_WAVES, FLORIA_FAST_WAVES))) void beam_fast_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
     const uint32_t p = g.ploidy, B = g.beam, LM = p * B;
@@ -253,22 +259,34 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(BeamArgs g) {
                     }
                     t1 *= rk1; t2 *= rk2;
                 }
-                // ---- distance_read_haplo_epsilon_empty (utils_frags.rs:32-75) ---------------------------------------
-                auto cell = [&](const ulonglong2* vv, uint32_t c) {
-                    const uint32_t aw = c_aw[c];
+                // ---- distance_read_haplo_epsilon_empty (utils_frags.rs:32-75), branch-free ------------------------------
+                // per cell: empty position (no non-zero count) -> m += 1; read allele (tied for) the consensus -> same += w;
+                // else diff += w.  32-bit partial sums per batch of cells (w <= 2^24), folded into u64 after each batch.
+                uint32_t ps = 0, pd = 0;
+                auto cell = [&](const ulonglong2* vv, uint32_t aw, uint32_t c) {
                     const uint32_t al = aw >> 28;
-                    const uint64_t w = aw & 0x0fffffffu;
-                    uint64_t v[A];
+                    const uint32_t w = aw & 0x0fffffffu;
+                    bool nonempty, same;
+                    uint64_t va;
+                    if (A == 2) {
+                        const uint64_t v0 = Q0 ? (vv[0].x & QMASK63) : vv[0].x, v1 = Q0 ? (vv[0].y & QMASK63) : vv[0].y;
+                        nonempty = (v0 | v1) != 0;
+                        same = al ? (v1 >= v0) : (v0 >= v1);
+                        va = al ? vv[0].y : vv[0].x;
+                    } else {
+                        uint64_t v[A];
 #pragma unroll
-                    for (int x = 0; x < A; x += 2) { v[x] = vv[x / 2].x; v[x + 1] = vv[x / 2].y; }
-                    uint64_t mx = 0, va = 0;
+                        for (int x = 0; x < A; x += 2) { v[x] = vv[x / 2].x; v[x + 1] = vv[x / 2].y; }
+                        uint64_t mx = 0; va = 0;
 #pragma unroll
-                    for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
-                    const uint64_t qa = Q0 ? (va & QMASK63) : va;
-                    if (mx == 0) m += 1;
-                    else if (qa == mx) qs += w;
-                    else qd += w;
-                    if (Q0) { if (!(va >> 63)) { np1 += c_rp1[c]; np2 += c_rp2[c]; } }
+                        for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
+                        nonempty = mx != 0;
+                        same = (Q0 ? (va & QMASK63) : va) == mx;
+                    }
+                    ps += (nonempty && same) ? w : 0u;
+                    pd += (nonempty && !same) ? w : 0u;
+                    m += nonempty ? 0u : 1u;
+                    if (Q0) { const bool np = !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
                 };
                 for (uint32_t t = 0; t < ntiles; ++t) {
                     if (ntiles > 1) stage_tile(t, false);
@@ -276,23 +294,35 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(BeamArgs g) {
                     if (act) {
                         uint32_t c = 0;
                         for (; c + FAST_UNROLL <= nin; c += FAST_UNROLL) {
+                            uint32_t offs[FAST_UNROLL], aws[FAST_UNROLL];
+#pragma unroll
+                            for (int u = 0; u < FAST_UNROLL; u += 4) {
+                                const uint4 o4 = *(const uint4*)(c_off + c + u), a4 = *(const uint4*)(c_aw + c + u);
+                                offs[u] = o4.x; offs[u + 1] = o4.y; offs[u + 2] = o4.z; offs[u + 3] = o4.w;
+                                aws[u] = a4.x; aws[u + 1] = a4.y; aws[u + 2] = a4.z; aws[u + 3] = a4.w;
+                            }
                             ulonglong2 vv[FAST_UNROLL][A / 2];
 #pragma unroll
                             for (int u = 0; u < FAST_UNROLL; ++u) {
-                                const char* cp = slab + (lane_off + c_off[c + u]);
+                                const char* cp = slab + (lane_off + offs[u]);
 #pragma unroll
                                 for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
                             }
+                            ps = 0; pd = 0;
 #pragma unroll
-                            for (int u = 0; u < FAST_UNROLL; ++u) cell(vv[u], c + u);
+                            for (int u = 0; u < FAST_UNROLL; ++u) cell(vv[u], aws[u], c + u);
+                            qs += ps; qd += pd;
                         }
+                        ps = 0; pd = 0;
                         for (; c < nin; ++c) {
                             ulonglong2 vv[A / 2];
                             const char* cp = slab + (lane_off + c_off[c]);
 #pragma unroll
                             for (int x = 0; x < A / 2; ++x) vv[x] = *(const ulonglong2*)(cp + 16 * x);
-                            cell(vv, c);
+                            cell(vv, c_aw[c], c);
+                            if ((c & 7) == 7) { qs += ps; qd += pd; ps = 0; pd = 0; }
                         }
+                        qs += ps; qd += pd;
                         m += tl - nin;                                  // cells beyond hi_rel: empty positions (:45-48)
                         if (Q0) { np1 += rpb1; np2 += rpb2; }
                     }
@@ -413,12 +443,25 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(BeamArgs g) {
                 if (ntiles > 1) stage_tile(t, false);
                 const uint32_t tl = min((uint32_t)FAST_TILE, L - t * FAST_TILE);
                 const uint32_t items = nnext * tl;
-                for (uint32_t x = lane; x < items; x += 64) {
+                auto addr_of = [&](uint32_t x, uint32_t& w) -> uint64_t* {
                     const uint32_t e = x / tl, c = x - e * tl;
                     const uint32_t aw = c_aw[c], bk = nx[e].bufk;
-                    uint64_t* cp = (uint64_t*)(slab + ((bk & 0xffff) * state_bytes + c_off[c] + ((bk >> 16) * A + (aw >> 28)) * 8));
-                    const uint64_t nv = *cp + (uint64_t)(aw & 0x0fffffffu);
-                    *cp = Q0 ? (nv | PRESENT_BIT) : nv;
+                    w = aw & 0x0fffffffu;
+                    return (uint64_t*)(slab + ((bk & 0xffff) * state_bytes + c_off[c] + ((bk >> 16) * A + (aw >> 28)) * 8));
+                };
+                uint32_t x = lane;
+                for (; x + 192 < items; x += 256) {           // 4 independent read-modify-writes in flight
+                    uint32_t w0, w1, w2, w3;
+                    uint64_t *p0 = addr_of(x, w0), *p1 = addr_of(x + 64, w1), *p2 = addr_of(x + 128, w2), *p3 = addr_of(x + 192, w3);
+                    const uint64_t v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
+                    *p0 = Q0 ? ((v0 + w0) | PRESENT_BIT) : v0 + w0; *p1 = Q0 ? ((v1 + w1) | PRESENT_BIT) : v1 + w1;
+                    *p2 = Q0 ? ((v2 + w2) | PRESENT_BIT) : v2 + w2; *p3 = Q0 ? ((v3 + w3) | PRESENT_BIT) : v3 + w3;
+                }
+                for (; x < items; x += 64) {
+                    uint32_t w0;
+                    uint64_t* p0 = addr_of(x, w0);
+                    const uint64_t v0 = *p0;
+                    *p0 = Q0 ? ((v0 + w0) | PRESENT_BIT) : v0 + w0;
                 }
             }
             __syncthreads();

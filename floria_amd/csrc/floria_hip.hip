@@ -241,7 +241,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         {
             const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
             const uint64_t hist_stride = (uint64_t)fl::beam_hist_off(n_max, LM, B) + LM;
-            uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * 8;
+            uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * 4 * FLORIA_FAST_WAVES;
             slots = std::min(slots, n_jobs);
             const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
             while (slots > 1 && (state_bytes + hist_stride * 4) * slots > budget) slots /= 2;

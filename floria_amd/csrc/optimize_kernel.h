@@ -174,15 +174,30 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     const uint32_t r = reads[i];
                     const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
                     uint64_t qd = 0; uint32_t m = 0;
-                    for (uint32_t c = cb; c < ce; ++c) {
-                        const uint32_t aq = cd.cell_aq[c], al = aq >> 8;
-                        const uint64_t* cp = hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A;
+                    auto one = [&](const uint64_t* cp, uint32_t aq) {
+                        const uint32_t al = aq >> 8;
                         uint64_t mx = 0, va = 0;
 #pragma unroll
                         for (int x = 0; x < A; ++x) { const uint64_t q = cp[x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
-                        if (mx == 0) m += 1;
-                        else if (va != mx) qd += c_w24[aq & 0xff];
+                        m += mx == 0 ? 1u : 0u;
+                        qd += (mx != 0 && va != mx) ? (uint64_t)c_w24[aq & 0xff] : 0ull;
+                    };
+                    uint32_t c = cb;
+                    for (; c + 4 <= ce; c += 4) {                    // 4 independent (cell -> histogram) load chains in flight
+                        uint32_t sn[4], aqs[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { sn[u] = cd.cell_snp[c + u]; aqs[u] = cd.cell_aq[c + u]; }
+                        uint64_t hv[4][A];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint64_t* cp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
+#pragma unroll
+                            for (int x = 0; x < A; ++x) hv[u][x] = cp[x];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) one(hv[u], aqs[u]);
                     }
+                    for (; c < ce; ++c) one(hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A, cd.cell_aq[c]);
                     dist[pair] = qm_to_f64(qd, m, g.eps);
                 }
                 if (tid == 0) { s_ncand = 0; s_nmoves = 0; }
