@@ -1,0 +1,490 @@
+// beam_slab_kernel.h — beam search over SHARED partition slabs (production path for ploidy*beam <= 63).
+//
+// Measured on the reference algorithm (profiles/r01_unique_partitions.txt): the beam is full of label-permuted
+// mirrors of the same clustering — at ploidy 4 a step has ~41 (state, partition) pairs but only ~4 distinct
+// partition histograms (ploidy 3: 23 vs 4; ploidy 2: 13 vs 6.5).  The reference recomputes the read<->haplotype
+// distance for every pair (global_clustering.rs:74-91); here a partition histogram is a reference-shared SLAB:
+//
+//   * a state is p slab ids; a child inherits p-1 ids and gets ONE new slab version "old slab + read";
+//     children that extend the same old slab share the new version (mirrors stay shared by construction, starting
+//     from the single empty slab all p partitions of the root point to);
+//   * distance_read_haplo_epsilon_empty (utils_frags.rs:32-75) runs once per LIVE slab, with 64/nlive lanes per
+//     slab striding over the read's cells and a segmented butterfly to combine them;
+//   * a new version is written in place when no survivor still inherits the old one, else to a free slab after
+//     a copy of the live SNP window; adds happen once per distinct new version.
+//
+// Everything observable is unchanged: per-pair (same, diff), p-values, pruning, child scores, the 128-bit
+// linear state hash for the duplicate test, the std::BinaryHeap order — bit-identical to beam_kernel.h.
+// Slab layout: [pos][allele] u64 (16 B per SNP for biallelic data): consecutive cells of a read are consecutive
+// 16-B pieces, so four cells share a 64-B line.
+#pragma once
+#include "beam_fast_kernel.h"
+
+namespace fl {
+
+constexpr int SLAB_TILE = 256;
+constexpr int SLAB_NS_MAX = 512;      // ploidy * (ploidy*beam) slabs per resident job
+
+struct SlabLds {
+    uint32_t off_coff, off_caw, off_crp1, off_crp2;
+    uint32_t off_q[2], off_h1[2], off_h2[2], off_m[2], off_sl[2];     // state arrays (SoA) x2
+    uint32_t off_live, off_s2l, off_ref, off_leader, off_newid, off_free, off_pk;
+    uint32_t off_rqs, off_rqd, off_rm, off_rt1, off_rt2, off_rnp1, off_rnp2;
+    uint32_t total;
+};
+__host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool q0) {
+    SlabLds L;
+    const uint32_t NS = LM * p;
+    uint32_t o = 0;
+    auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15) & ~15u; return r; };
+    L.off_coff = take(SLAB_TILE * 4); L.off_caw = take(SLAB_TILE * 4);
+    L.off_crp1 = take(q0 ? SLAB_TILE * 8 : 0); L.off_crp2 = take(q0 ? SLAB_TILE * 8 : 0);
+    for (int i = 0; i < 2; ++i) {
+        L.off_q[i] = take(LM * 8); L.off_h1[i] = take(LM * 8); L.off_h2[i] = take(LM * 8); L.off_m[i] = take(LM * 4);
+        L.off_sl[i] = take(NS * 2);
+    }
+    L.off_live = take(NS * 2); L.off_s2l = take(NS * 2); L.off_ref = take(NS); L.off_leader = take(NS * 4);
+    L.off_newid = take(NS * 2); L.off_free = take(64 * 2); L.off_pk = take(64 * 4);
+    L.off_rqs = take(NS * 8); L.off_rqd = take(NS * 8); L.off_rm = take(NS * 4); L.off_rt1 = take(NS * 8); L.off_rt2 = take(NS * 8);
+    L.off_rnp1 = take(q0 ? NS * 8 : 0); L.off_rnp2 = take(q0 ? NS * 8 : 0);
+    L.total = o;
+    return L;
+}
+
+template <int A, bool Q0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_WAVES, FLORIA_FAST_WAVES)))
+void beam_slab_kernel(BeamArgs g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t p = g.ploidy, B = g.beam, LM = p * B, NS = LM * p;
+    const SlabLds LY = slab_lds_layout(LM, p, Q0);
+    uint32_t* c_off = (uint32_t*)(smem + LY.off_coff);
+    uint32_t* c_aw  = (uint32_t*)(smem + LY.off_caw);
+    uint64_t* c_rp1 = (uint64_t*)(smem + LY.off_crp1);
+    uint64_t* c_rp2 = (uint64_t*)(smem + LY.off_crp2);
+    uint16_t* live_id = (uint16_t*)(smem + LY.off_live);
+    uint16_t* s2l = (uint16_t*)(smem + LY.off_s2l);
+    uint8_t*  ref = (uint8_t*)(smem + LY.off_ref);
+    uint32_t* leader = (uint32_t*)(smem + LY.off_leader);
+    uint16_t* newid = (uint16_t*)(smem + LY.off_newid);
+    uint16_t* freelist = (uint16_t*)(smem + LY.off_free);
+    uint32_t* s_pk = (uint32_t*)(smem + LY.off_pk);
+    uint64_t* r_qs = (uint64_t*)(smem + LY.off_rqs);
+    uint64_t* r_qd = (uint64_t*)(smem + LY.off_rqd);
+    uint32_t* r_m = (uint32_t*)(smem + LY.off_rm);
+    uint64_t* r_t1 = (uint64_t*)(smem + LY.off_rt1);
+    uint64_t* r_t2 = (uint64_t*)(smem + LY.off_rt2);
+    uint64_t* r_np1 = (uint64_t*)(smem + LY.off_rnp1);
+    uint64_t* r_np2 = (uint64_t*)(smem + LY.off_rnp2);
+
+    const uint32_t pos_bytes = A * 8;
+    const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
+    char* pool = (char*)(g.state_pool + (uint64_t)blockIdx.x * ((uint64_t)LM * g.span_max * p * A));
+    uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
+    const uint64_t lane_lt = (1ull << lane) - 1;
+
+    const uint32_t S = 64 / p;
+    const uint32_t my_sl = lane / p, my_k = lane % p;
+    const bool lane_pair = my_sl < S;
+    const uint64_t rk1 = g.Rk1[my_k], rk2 = g.Rk2[my_k];
+    const int seg0 = (int)(my_sl * p);
+    double min_margin = 1e300;
+    uint32_t n_fallback = 0;
+
+    for (;;) {
+        uint32_t job = 0;
+        if (lane == 0) job = atomicAdd(g.queue_head, 1u);
+        job = uni(__shfl(job, 0));
+        if (job >= g.n_jobs) break;
+        const uint32_t b = uni(g.job_block[job]);
+        if (g.blk_done[b]) continue;
+        const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
+        const uint64_t roff = g.bs.blk_read_off[b];
+        const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
+        const uint32_t* reads = g.bs.blk_read + roff;
+        const uint32_t pos0 = g.bs.blk_pos0[b];
+
+        int cur = 0;
+        auto ST_q = [&](int w) { return (uint64_t*)(smem + LY.off_q[w]); };
+        auto ST_h1 = [&](int w) { return (uint64_t*)(smem + LY.off_h1[w]); };
+        auto ST_h2 = [&](int w) { return (uint64_t*)(smem + LY.off_h2[w]); };
+        auto ST_m = [&](int w) { return (uint32_t*)(smem + LY.off_m[w]); };
+        auto ST_sl = [&](int w) { return (uint16_t*)(smem + LY.off_sl[w]); };
+        uint32_t nstates = 1, nlive = 1;
+        // root: every partition points at slab 0, which is logically empty (nothing written: hi_rel = -1)
+        if (lane == 0) { ST_q(0)[0] = 0; ST_h1(0)[0] = 0; ST_h2(0)[0] = 0; ST_m(0)[0] = 0; live_id[0] = 0; s2l[0] = 0; }
+        if (lane < p) ST_sl(0)[lane] = 0;
+        int32_t hi_rel = -1;
+        uint32_t start_rel = 0;
+        uint64_t ev_s = 0, ev_h1 = 0, ev_h2 = 0, ev_q = 0;
+        uint32_t ev_m = 0, ev_pk = 0;
+        RegHeap H; H.hp_s = 0; H.hp_id = 0; H.len = 0;
+        uint32_t r_next = n > 0 ? reads[0] : 0;
+        __syncthreads();
+
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t r = uni(r_next);
+            if (i + 1 < n) r_next = reads[i + 1];
+            const uint32_t cbeg = uni(cd.read_off[r]), L = uni(cd.read_off[r + 1]) - cbeg;
+            const uint32_t first_rel = uni(cd.first[r]) - pos0;
+            const int32_t  last_rel = (int32_t)(uni(cd.last[r]) - pos0);
+            const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
+            const uint32_t ntiles = (L + SLAB_TILE - 1) / SLAB_TILE;
+            uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);
+            uint32_t* st_m = ST_m(cur); uint16_t* st_sl = ST_sl(cur);
+
+            uint64_t tw1 = 0, tw2 = 0, rpb1 = 0, rpb2 = 0;
+            uint32_t nin = 0;
+            auto stage_tile = [&](uint32_t t, bool with_tw) {
+                __syncthreads();
+                uint32_t cnt_in = 0;
+                uint64_t b1 = 0, b2 = 0;
+                for (uint32_t c = lane; c < SLAB_TILE; c += 64) {
+                    const uint32_t cc = t * SLAB_TILE + c;
+                    bool in = false;
+                    if (cc < L) {
+                        const uint32_t pr = cd.cell_snp[cbeg + cc] - pos0;
+                        const uint32_t aq = cd.cell_aq[cbeg + cc];
+                        const uint32_t al = aq >> 8;
+                        const uint32_t w = c_w24[aq & 0xff];
+                        const uint32_t idx = pr * A + al;
+                        c_off[c] = pr * pos_bytes;
+                        c_aw[c] = (al << 28) | w;
+                        in = (int32_t)pr <= hi_rel;
+                        if (with_tw) { tw1 += g.Rq1[idx] * (uint64_t)w; tw2 += g.Rq2[idx] * (uint64_t)w; }
+                        if (Q0) {
+                            const uint64_t r1 = g.Rp1[idx], r2 = g.Rp2[idx];
+                            c_rp1[c] = r1; c_rp2[c] = r2;
+                            if (!in) { b1 += r1; b2 += r2; }
+                        }
+                    }
+                    cnt_in += (uint32_t)__popcll(__ballot(in));
+                }
+                nin = uni(cnt_in);
+                if (Q0) { rpb1 = wave_sum_u64(b1); rpb2 = wave_sum_u64(b2); }
+                __syncthreads();
+            };
+            if (ntiles > 1) {
+                for (uint32_t c = lane; c < L; c += 64) {
+                    const uint32_t pr = cd.cell_snp[cbeg + c] - pos0;
+                    const uint32_t aq = cd.cell_aq[cbeg + c];
+                    const uint32_t idx = pr * A + (aq >> 8);
+                    const uint64_t w = c_w24[aq & 0xff];
+                    tw1 += g.Rq1[idx] * w; tw2 += g.Rq2[idx] * w;
+                }
+            } else stage_tile(0, true);
+            tw1 = wave_sum_u64(tw1); tw2 = wave_sum_u64(tw2);
+
+            // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
+            uint32_t Gs = 1;
+            while (Gs < 16 && nlive * (Gs * 2) <= 64) Gs *= 2;
+            const uint32_t per = 64 / Gs;                       // slabs per pass
+            for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
+                const uint32_t li = l0 + lane / Gs, sub = lane % Gs;
+                const bool act = li < nlive;
+                const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
+                uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
+                uint32_t m = 0;
+                {   // positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel]
+                    const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
+                    for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
+                        if (act) {
+#pragma unroll
+                            for (int al = 0; al < A; ++al) {
+                                const uint64_t v = *(const uint64_t*)(pool + (slab_off + (uint32_t)pr * pos_bytes + al * 8));
+                                if (v) {
+                                    const uint64_t qv = Q0 ? (v & QMASK63) : v;
+                                    t1 += g.Rq1[pr * A + al] * qv; t2 += g.Rq2[pr * A + al] * qv;
+                                    if (Q0) { t1 += g.Rp1[pr * A + al]; t2 += g.Rp2[pr * A + al]; }
+                                }
+                            }
+                        }
+                    }
+                }
+                uint32_t ps = 0, pd = 0;
+                auto cell = [&](const ulonglong2* vv, uint32_t aw, uint32_t c) {
+                    const uint32_t al = aw >> 28;
+                    const uint32_t w = aw & 0x0fffffffu;
+                    bool nonempty, same;
+                    uint64_t va;
+                    if (A == 2) {
+                        const uint64_t v0 = Q0 ? (vv[0].x & QMASK63) : vv[0].x, v1 = Q0 ? (vv[0].y & QMASK63) : vv[0].y;
+                        nonempty = (v0 | v1) != 0;
+                        same = al ? (v1 >= v0) : (v0 >= v1);
+                        va = al ? vv[0].y : vv[0].x;
+                    } else {
+                        uint64_t v[A];
+#pragma unroll
+                        for (int x = 0; x < A; x += 2) { v[x] = vv[x / 2].x; v[x + 1] = vv[x / 2].y; }
+                        uint64_t mx = 0; va = 0;
+#pragma unroll
+                        for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
+                        nonempty = mx != 0;
+                        same = (Q0 ? (va & QMASK63) : va) == mx;
+                    }
+                    ps += (nonempty && same) ? w : 0u;
+                    pd += (nonempty && !same) ? w : 0u;
+                    m += nonempty ? 0u : 1u;
+                    if (Q0) { const bool np = !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
+                };
+                for (uint32_t t = 0; t < ntiles; ++t) {
+                    if (ntiles > 1) stage_tile(t, false);
+                    const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                    if (act) {
+                        uint32_t c = sub;
+                        for (; c + 3 * Gs < nin; c += 4 * Gs) {              // 4 independent loads in flight per lane
+                            uint32_t offs[4], aws[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { offs[u] = c_off[c + u * Gs]; aws[u] = c_aw[c + u * Gs]; }
+                            ulonglong2 vv[4][A / 2];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const char* cp = pool + (slab_off + offs[u]);
+#pragma unroll
+                                for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
+                            }
+                            ps = 0; pd = 0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) cell(vv[u], aws[u], c + u * Gs);
+                            qs += ps; qd += pd;
+                        }
+                        for (; c < nin; c += Gs) {
+                            ulonglong2 vv[A / 2];
+                            const char* cp = pool + (slab_off + c_off[c]);
+#pragma unroll
+                            for (int x = 0; x < A / 2; ++x) vv[x] = *(const ulonglong2*)(cp + 16 * x);
+                            ps = 0; pd = 0;
+                            cell(vv, c_aw[c], c);
+                            qs += ps; qd += pd;
+                        }
+                        if (sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }   // cells beyond hi_rel (:45-48)
+                    }
+                }
+                // segmented butterfly over the Gs lanes of a slab
+                for (uint32_t o = Gs >> 1; o > 0; o >>= 1) {
+                    qs += shfl_u64(qs, (int)(lane ^ o)); qd += shfl_u64(qd, (int)(lane ^ o)); m += __shfl(m, (int)(lane ^ o));
+                    t1 += shfl_u64(t1, (int)(lane ^ o)); t2 += shfl_u64(t2, (int)(lane ^ o));
+                    if (Q0) { np1 += shfl_u64(np1, (int)(lane ^ o)); np2 += shfl_u64(np2, (int)(lane ^ o)); }
+                }
+                if (act && sub == 0) {
+                    r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m; r_t1[li] = t1; r_t2[li] = t2;
+                    if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
+                }
+            }
+            __syncthreads();
+
+            // ---- B: per (state, partition) pair: p-value, log-sum-exp, pruning, child (:74-134) -----------------------
+            uint64_t evalid = 0;
+            H.len = 0;
+            for (uint32_t a0 = 0; a0 < nstates; a0 += S) {
+                const uint32_t a = a0 + my_sl;
+                const bool act = lane_pair && a < nstates;
+                uint64_t qd = 0, t1 = 0, t2 = 0, np1 = 0, np2 = 0;
+                uint32_t m = 0;
+                double pv = 0.0;
+                if (act) {
+                    const uint32_t li = s2l[st_sl[a * p + my_k]];
+                    const uint64_t qs = r_qs[li];
+                    qd = r_qd[li]; m = r_m[li];
+                    t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2;
+                    if (Q0) { np1 = r_np1[li]; np2 = r_np2[li]; }
+                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
+                    const uint64_t nn = (uint64_t)(same_f + diff_f), kk = (uint64_t)diff_f;
+                    if (nn <= g.binom_nmax) pv = g.binom_tab[nn * (nn + 1) / 2 + kk];
+                    else { pv = binom_device(nn, kk, g.eps, g.div_factor); n_fallback++; }
+                }
+                double mx = 0.0, sum = 0.0;
+                uint64_t ts1 = 0, ts2 = 0;
+                for (uint32_t j = 0; j < p; ++j) {
+                    const double o = shfl_f64(pv, seg0 + (int)j);
+                    mx = (j == 0) ? o : (o > mx ? o : mx);
+                    ts1 += shfl_u64(t1, seg0 + (int)j);
+                    ts2 += shfl_u64(t2, seg0 + (int)j);
+                }
+                for (uint32_t j = 0; j < p; ++j) sum += exp(shfl_f64(pv, seg0 + (int)j) - mx);
+                const double lse = mx + log(sum);
+                bool pass = false;
+                uint64_t ch1 = 0, ch2 = 0, cq = 0, cs = 0;
+                uint32_t cm = 0;
+                if (act) {
+                    const double am = fabs((pv - lse) - g.cutoff);
+                    min_margin = am < min_margin ? am : min_margin;
+                    pass = (pv - lse) > g.cutoff;
+                    cq = st_q[a] + qd;
+                    cm = st_m[a] + m;
+                    cs = (uint64_t)__double_as_longlong(qm_to_f64(cq, cm, g.eps));
+                    ch1 = (st_h1[a] - ts1) + rk1 * (tw1 + (Q0 ? np1 : 0));
+                    ch2 = (st_h2[a] - ts2) + rk2 * (tw2 + (Q0 ? np2 : 0));
+                }
+                uint64_t passmask = __ballot(pass);
+                while (passmask) {
+                    const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
+                    passmask &= passmask - 1;
+                    const uint64_t s_s = rl64(cs, src), s_h1 = rl64(ch1, src), s_h2 = rl64(ch2, src);
+                    const bool dup = ((evalid >> lane) & 1) && ev_h1 == s_h1 && ev_h2 == s_h2 && ev_s >= s_s;
+                    if (__ballot(dup)) continue;
+                    const uint32_t id = (uint32_t)__ffsll((unsigned long long)~evalid) - 1;
+                    evalid |= 1ull << id;
+                    wl64(ev_s, s_s, id); wl64(ev_h1, s_h1, id); wl64(ev_h2, s_h2, id);
+                    wl64(ev_q, rl64(cq, src), id); wl32(ev_m, rl32(cm, src), id);
+                    wl32(ev_pk, (a0 + src / p) | ((src % p) << 16), id);
+                    H.push(s_s, id);
+                    if (H.len > limit) evalid &= ~(1ull << H.pop());
+                }
+            }
+
+            // ---- M: survivors (lane j = heap slot j = next state j) and their slabs -----------------------------------
+            const uint32_t nnext = H.len;
+            const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
+            const bool surv = lane < nnext;
+            const uint32_t eid = surv ? H.hp_id : 0;
+            const uint64_t n_q = shfl_u64(ev_q, (int)eid), n_h1 = shfl_u64(ev_h1, (int)eid), n_h2 = shfl_u64(ev_h2, (int)eid);
+            const uint32_t n_m = __shfl(ev_m, (int)eid), n_pk = __shfl(ev_pk, (int)eid);
+            const uint32_t pj = n_pk & 0xffff, kj = n_pk >> 16;
+            uint64_t* nx_q = ST_q(cur ^ 1); uint64_t* nx_h1 = ST_h1(cur ^ 1); uint64_t* nx_h2 = ST_h2(cur ^ 1);
+            uint32_t* nx_m = ST_m(cur ^ 1); uint16_t* nx_sl = ST_sl(cur ^ 1);
+            for (uint32_t x = lane; x < NS; x += 64) { ref[x] = 0; leader[x] = 0xffffffffu; }
+            s_pk[lane] = n_pk;
+            __syncthreads();
+            // inherited pointers (every partition but the modified one) and the modified slab's leader
+            for (uint32_t x = lane; x < nnext * p; x += 64) {
+                const uint32_t j = x / p, k = x - j * p;
+                const uint32_t pk = s_pk[j];
+                const uint32_t sid = st_sl[(pk & 0xffff) * p + k];
+                nx_sl[x] = (uint16_t)sid;
+                if (k != (pk >> 16)) ref[sid] = 1;
+            }
+            const uint32_t u_old = surv ? st_sl[pj * p + kj] : 0;
+            if (surv) atomicMin(&leader[u_old], lane);
+            __syncthreads();
+            const bool lead = surv && leader[u_old] == lane;
+            const bool inplace = lead && ref[u_old] == 0;
+            const bool needcopy = lead && !inplace;
+            __syncthreads();                                           // all reads of ref[] done before in-place marks
+            if (inplace) { ref[u_old] = 2; newid[u_old] = (uint16_t)u_old; }
+            __syncthreads();
+            // free slabs = not referenced; the first ncopy of them (ascending id) go to the copy leaders
+            const uint64_t cmask = __ballot(needcopy);
+            const uint32_t ncopy = (uint32_t)__popcll(cmask);
+            if (ncopy) {
+                uint32_t found = 0;
+                for (uint32_t x0 = 0; x0 < NS && found < ncopy; x0 += 64) {
+                    const uint32_t x = x0 + lane;
+                    const bool fr = x < NS && ref[x] == 0;
+                    const uint64_t fm = __ballot(fr);
+                    const uint32_t pos = found + (uint32_t)__popcll(fm & lane_lt);
+                    if (fr && pos < 64) freelist[pos] = (uint16_t)x;
+                    found += (uint32_t)__popcll(fm);
+                }
+                if (found < ncopy && lane == 0) atomicAdd(&g.diag[1], 1u);
+                __syncthreads();
+                if (needcopy) { const uint32_t f = freelist[__popcll(cmask & lane_lt)]; newid[u_old] = (uint16_t)f; ref[f] = 2; }
+                __syncthreads();
+            }
+            // survivor records
+            if (surv) {
+                nx_q[lane] = n_q; nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; nx_m[lane] = n_m;
+                nx_sl[lane * p + kj] = newid[u_old];
+                slot_hist[beam_hist_off(i, LM, B) + lane] = pj | (kj << 16);
+            }
+            // copies of the written window [first_rel, hi_rel] for the new versions that could not go in place
+            if (ncopy && hi_rel >= (int32_t)first_rel) {
+                const uint32_t cnt2 = ((uint32_t)(hi_rel - (int32_t)first_rel + 1) * A) >> 1;
+                uint64_t cm2 = cmask;
+                while (cm2) {
+                    const uint32_t jj = (uint32_t)__ffsll((unsigned long long)cm2) - 1;
+                    cm2 &= cm2 - 1;
+                    const uint32_t su = rl32(u_old, jj);
+                    const uint32_t du = newid[su];
+                    const ulonglong2* s = (const ulonglong2*)(pool + (su * slab_bytes + first_rel * pos_bytes));
+                    ulonglong2* d = (ulonglong2*)(pool + (du * slab_bytes + first_rel * pos_bytes));
+                    uint32_t x = lane;
+                    for (; x + 192 < cnt2; x += 256) {
+                        const ulonglong2 v0 = s[x], v1 = s[x + 64], v2 = s[x + 128], v3 = s[x + 192];
+                        d[x] = v0; d[x + 64] = v1; d[x + 128] = v2; d[x + 192] = v3;
+                    }
+                    for (; x < cnt2; x += 64) d[x] = s[x];
+                }
+            }
+            __syncthreads();
+            // next live list = every referenced slab (ascending id); zero their newly reached positions (hi_rel, new_hi]
+            uint32_t nl = 0;
+            for (uint32_t x0 = 0; x0 < NS; x0 += 64) {
+                const uint32_t x = x0 + lane;
+                const bool rf = x < NS && ref[x] != 0;
+                const uint64_t fm = __ballot(rf);
+                if (rf) { const uint32_t idx = nl + (uint32_t)__popcll(fm & lane_lt); live_id[idx] = (uint16_t)x; s2l[x] = (uint16_t)idx; }
+                nl += (uint32_t)__popcll(fm);
+            }
+            __syncthreads();
+            if (new_hi > hi_rel) {
+                const uint32_t cntz = (uint32_t)(new_hi - hi_rel) * A;
+                const uint32_t items = nl * cntz;
+                for (uint32_t x = lane; x < items; x += 64) {
+                    const uint32_t e = x / cntz, o = x - e * cntz;
+                    *(uint64_t*)(pool + ((uint32_t)live_id[e] * slab_bytes + (uint32_t)(hi_rel + 1) * pos_bytes + o * 8)) = 0;
+                }
+            }
+            __syncthreads();
+            // add the read ONCE per distinct new version (types_structs.rs:368-373)
+            {
+                const uint64_t lmask = __ballot(lead);
+                const uint32_t nlead = (uint32_t)__popcll(lmask);
+                // leaders' target slabs, compacted into freelist[] (reused as scratch)
+                if (lead) freelist[__popcll(lmask & lane_lt)] = newid[u_old];
+                for (uint32_t t = 0; t < ntiles; ++t) {
+                    if (ntiles > 1) stage_tile(t, false); else __syncthreads();
+                    const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                    const uint32_t items = nlead * tl;
+                    auto addr_of = [&](uint32_t x, uint32_t& w) -> uint64_t* {
+                        const uint32_t e = x / tl, c = x - e * tl;
+                        const uint32_t aw = c_aw[c];
+                        w = aw & 0x0fffffffu;
+                        return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + c_off[c] + (aw >> 28) * 8));
+                    };
+                    uint32_t x = lane;
+                    for (; x + 192 < items; x += 256) {
+                        uint32_t w0, w1, w2, w3;
+                        uint64_t *p0 = addr_of(x, w0), *p1 = addr_of(x + 64, w1), *p2 = addr_of(x + 128, w2), *p3 = addr_of(x + 192, w3);
+                        const uint64_t v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
+                        *p0 = Q0 ? ((v0 + w0) | PRESENT_BIT) : v0 + w0; *p1 = Q0 ? ((v1 + w1) | PRESENT_BIT) : v1 + w1;
+                        *p2 = Q0 ? ((v2 + w2) | PRESENT_BIT) : v2 + w2; *p3 = Q0 ? ((v3 + w3) | PRESENT_BIT) : v3 + w3;
+                    }
+                    for (; x < items; x += 64) {
+                        uint32_t w0;
+                        uint64_t* p0 = addr_of(x, w0);
+                        const uint64_t v0 = *p0;
+                        *p0 = Q0 ? ((v0 + w0) | PRESENT_BIT) : v0 + w0;
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+            nstates = nnext;
+            nlive = nl;
+            hi_rel = new_hi;
+            start_rel = first_rel;
+        }
+
+        if (n > 0) {
+            H.hp_id = lane;
+            uint32_t ecur = H.sorted_first();
+            uint8_t* out = g.part_out + roff;
+            for (int32_t i = (int32_t)n - 1; i >= 0; --i) {
+                const uint32_t rec = slot_hist[beam_hist_off((uint32_t)i, LM, B) + ecur];
+                if (lane == 0) out[i] = (uint8_t)(rec >> 16);
+                ecur = uni(rec & 0xffff);
+            }
+            if (lane == 0) atomicAdd(g.steps_done, (unsigned long long)n);
+        }
+        __syncthreads();
+    }
+    min_margin = wave_min_f64(min_margin);
+    n_fallback = wave_sum_u32(n_fallback);
+    if (lane == 0) {
+        atomicMin(g.min_margin_bits, (unsigned long long)__double_as_longlong(min_margin));
+        if (n_fallback) atomicAdd(&g.diag[0], n_fallback);
+    }
+}
+
+}  // namespace fl

@@ -26,6 +26,7 @@
 #include "../../include/floria_hip.h"
 #include "beam_kernel.h"
 #include "beam_fast_kernel.h"
+#include "beam_slab_kernel.h"
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
 
@@ -262,9 +263,18 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             if (LY.total > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void*)fl::beam_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY.total));
             HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
-            const bool fast = LM <= 63 && (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull && !getenv("FLORIA_HIP_GENERIC_BEAM");
+            const char* force = getenv("FLORIA_HIP_BEAM");       // dev/test knob: generic | fast | slab
+            const bool small = LM <= 63 && (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull;
+            const fl::SlabLds SL = fl::slab_lds_layout(LM, p, any_q0);
+            bool slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && SL.total <= 60 * 1024;
+            bool fast = small;
+            if (force && !strcmp(force, "generic")) { slab = false; fast = false; }
+            if (force && !strcmp(force, "fast")) slab = false;
             int t = T.begin(K_BEAM);
-            if (fast) {
+            if (slab) {
+                if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), SL.total, ctx->stream, a);
+                else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), SL.total, ctx->stream, a);
+            } else if (fast) {
                 const fl::FastLds FL = fl::fast_lds_layout(LM, any_q0);
                 if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, ctx->stream, a);
                 else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, ctx->stream, a);
