@@ -302,10 +302,19 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             a.cand_gain_pool = ctx->opt_gain.as<uint64_t>(); a.cand_key_pool = ctx->opt_key.as<uint32_t>();
             a.moves_pool = ctx->opt_moves.as<uint32_t>(); a.cand_cap = cand_cap;
             a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
-            const size_t lds = ((size_t)(n_max + 31) / 32) * 4 + 16;
+            const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
+            const size_t hist_bytes = (size_t)span_max * p * A * 8;
+            const bool hl = hist_bytes + moved_bytes <= 56 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
+            const size_t lds = moved_bytes + (hl ? hist_bytes : 0) + 16;
+            if (hl) slots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((150 * 1024) / (lds + 14 * 1024))));
+            if (lds > 48 * 1024) {
+                if (hl) HIPCHK(hipFuncSetAttribute((const void*)fl::optimize_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                else HIPCHK(hipFuncSetAttribute((const void*)fl::optimize_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
             HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
             int t = T.begin(K_OPT);
-            hipLaunchKernelGGL(fl::optimize_kernel<A>, dim3(slots), dim3(fl::OPT_THREADS), lds, ctx->stream, a);
+            if (hl) hipLaunchKernelGGL((fl::optimize_kernel<A, true>), dim3(slots), dim3(fl::OPT_THREADS), lds, ctx->stream, a);
+            else hipLaunchKernelGGL((fl::optimize_kernel<A, false>), dim3(slots), dim3(fl::OPT_THREADS), lds, ctx->stream, a);
             T.end(t);
             HIPCHK(hipGetLastError());
             ctx->timing.optimize_launches++;

@@ -18,8 +18,9 @@
 namespace fl {
 
 constexpr int OPT_THREADS = 256;
-constexpr int OPT_SORT_LDS = 2048;        // candidates sorted in LDS up to this many
+constexpr int OPT_SORT_LDS = 1024;        // candidates sorted in LDS up to this many
 constexpr int NUM_ITER_OPTIMIZE = 20;     // constants.rs:3
+constexpr int OPT_U = 8;                  // cells per software-pipelined batch of the distance loop
 
 struct OptArgs {
     BlockSet bs;
@@ -67,13 +68,13 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
     }
 }
 
-template <int A>
+// HL = the job's histogram slab lives in LDS (span_max*ploidy*A*8 bytes fit): distance loads, the build/move atomics and the
+// MEC reductions then never leave the CU; only the reads' cells stream from HBM/L2.
+template <int A, bool HL>
 __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
-    extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded]
+    extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
     __shared__ uint64_t s_gain[OPT_SORT_LDS];
     __shared__ uint32_t s_key[OPT_SORT_LDS];
-    __shared__ uint64_t s_redq[OPT_THREADS / 64], s_redq2[OPT_THREADS / 64];
-    __shared__ uint32_t s_redm[OPT_THREADS / 64];
     __shared__ uint64_t s_errq[MAX_PLOIDY], s_goodq[MAX_PLOIDY];
     __shared__ uint32_t s_errm[MAX_PLOIDY];
     __shared__ uint32_t s_size[MAX_PLOIDY];
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t p = g.ploidy, PA = p * A;
-    uint64_t* hist = g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
+    const uint32_t moved_bytes = (((g.n_max + 31) / 32) * 4 + 15) & ~15u;
+    uint64_t* hist = HL ? (uint64_t*)(smem + moved_bytes) : g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
     double* dist = g.dist_pool + (uint64_t)blockIdx.x * g.n_max * p;
     uint64_t* cgain = g.cand_gain_pool + (uint64_t)blockIdx.x * g.cand_cap;
     uint32_t* ckey = g.cand_key_pool + (uint64_t)blockIdx.x * g.cand_cap;
@@ -126,6 +128,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         // get_mec_stats_epsilon (local_clustering.rs:218-260) -> per-partition (errors Q24, #eps) and
         // _no_phred (:187-215) -> (good count, bad count, #eps); returns score = -(sum_k errors_k) via s_score
         auto mec_stats = [&](bool phred) {
+            if (tid < MAX_PLOIDY) { s_errq[tid] = 0; s_goodq[tid] = 0; s_errm[tid] = 0; }
+            __syncthreads();
             for (uint32_t k = 0; k < p; ++k) {
                 uint64_t eq = 0, gq = 0;
                 uint32_t em = 0;
@@ -144,15 +148,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     }
                 }
                 eq = wave_sum_u64(eq); gq = wave_sum_u64(gq); em = wave_sum_u32(em);
-                if (lane == 0) { s_redq[wid] = eq; s_redq2[wid] = gq; s_redm[wid] = em; }
-                __syncthreads();
-                if (tid == 0) {
-                    uint64_t a = 0, c = 0; uint32_t m2 = 0;
-                    for (int w = 0; w < OPT_THREADS / 64; ++w) { a += s_redq[w]; c += s_redq2[w]; m2 += s_redm[w]; }
-                    s_errq[k] = a; s_goodq[k] = c; s_errm[k] = m2;
-                }
-                __syncthreads();
+                if (lane == 0) { atomicAdd((unsigned long long*)&s_errq[k], (unsigned long long)eq); atomicAdd((unsigned long long*)&s_goodq[k], (unsigned long long)gq); atomicAdd(&s_errm[k], em); }
             }
+            __syncthreads();
             if (tid == 0 && phred) {
                 double s = 0.0;                                 // binom_vec.iter().map(|x| x.1).sum() * -1.
                 for (uint32_t k = 0; k < p; ++k) s += qm_to_f64(s_errq[k], s_errm[k], g.eps);
@@ -168,6 +166,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             double prev_score = s_score;
             for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
                 iters_done = it + 1;
+                if (p == 1) break;      // one partition: opt_iterate has no target (j != i), new_part == best_part, not accepted
                 // ---- opt_iterate (:292-358): distance of every read to every partition ------------------------
                 for (uint32_t pair = tid; pair < n * p; pair += OPT_THREADS) {
                     const uint32_t i = pair / p, k = pair - i * p;
@@ -183,19 +182,19 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         qd += (mx != 0 && va != mx) ? (uint64_t)c_w24[aq & 0xff] : 0ull;
                     };
                     uint32_t c = cb;
-                    for (; c + 4 <= ce; c += 4) {                    // 4 independent (cell -> histogram) load chains in flight
-                        uint32_t sn[4], aqs[4];
+                    for (; c + OPT_U <= ce; c += OPT_U) {            // OPT_U independent (cell -> histogram) load chains in flight
+                        uint32_t sn[OPT_U], aqs[OPT_U];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { sn[u] = cd.cell_snp[c + u]; aqs[u] = cd.cell_aq[c + u]; }
-                        uint64_t hv[4][A];
+                        for (int u = 0; u < OPT_U; ++u) { sn[u] = cd.cell_snp[c + u]; aqs[u] = cd.cell_aq[c + u]; }
+                        uint64_t hv[OPT_U][A];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < OPT_U; ++u) {
                             const uint64_t* cp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
 #pragma unroll
                             for (int x = 0; x < A; ++x) hv[u][x] = cp[x];
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) one(hv[u], aqs[u]);
+                        for (int u = 0; u < OPT_U; ++u) one(hv[u], aqs[u]);
                     }
                     for (; c < ce; ++c) one(hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A, cd.cell_aq[c]);
                     dist[pair] = qm_to_f64(qd, m, g.eps);
