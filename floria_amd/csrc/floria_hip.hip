@@ -29,6 +29,7 @@
 #include "beam_slab_kernel.h"
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
+#include "blocks_kernel.h"
 
 static_assert(FLORIA_MAX_PLOIDY == fl::MAX_PLOIDY, "ploidy limits out of sync");
 
@@ -87,7 +88,7 @@ struct floria_hip_ctx {
     uint32_t hash_len = 0;
     uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
     // scratch pools
-    DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc;
+    DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
     floria_timing timing{};
 };
 
@@ -380,7 +381,7 @@ void floria_hip_destroy(floria_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc}) b->release();
+    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0}) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -487,71 +488,83 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     ctx->timing = floria_timing{};
     const uint32_t P = prm->max_ploidy;
 
-    // ---- block read lists (find_reads_in_interval) ------------------------------------------------------
-    std::vector<uint64_t> roff(n_blocks + 1, 0);
-    std::vector<uint32_t> rids, pos0(n_blocks, 0), span(n_blocks, 0), bc(n_blocks, 0);
+    // ---- block read lists: find_reads_in_interval on the device (blocks_kernel.h) -------------------------------
+    std::vector<uint32_t> bc(n_blocks, 0);
     uint32_t n_max = 1, span_max = 1, len_max = 1, nall = 2;
     bool any_q0 = false;
-    uint64_t algo_bytes = 0;
-    std::vector<uint64_t> blk_bytes(n_blocks, 0);
     for (uint32_t b = 0; b < n_blocks; ++b) {
         const uint32_t ci = blk_contig ? blk_contig[b] : 0;
         if (ci >= n_contigs || !contigs[ci]) return fail(FLORIA_E_INVALID, "blk_contig out of range");
         if (contigs[ci]->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
         bc[b] = ci;
-        uint32_t p0, p1;
-        const size_t before = rids.size();
-        reads_in_interval(contigs[ci], blk_start[b], blk_end[b], rids, &p0, &p1);
-        const uint32_t n = (uint32_t)(rids.size() - before);
-        roff[b + 1] = rids.size();
-        if (n) {
-            pos0[b] = p0; span[b] = p1 - p0 + 1;
-            n_max = std::max(n_max, n); span_max = std::max(span_max, span[b]);
-            uint64_t ab = 16 + (uint64_t)n + 8ull * P + 4;            // SURVEY.md §8(d) bytes(block)
-            const auto& ro = contigs[ci]->h_read_off;
-            for (size_t i = before; i < rids.size(); ++i) { const uint64_t L = ro[rids[i] + 1] - ro[rids[i]]; ab += 8 + (L + 3) / 4 + (L + 7) / 8 + L; }
-            algo_bytes += ab;
-            blk_bytes[b] = ab;
-        }
-        len_max = std::max(len_max, contigs[ci]->max_len);
-        nall = std::max(nall, contigs[ci]->n_alleles);
-        any_q0 = any_q0 || contigs[ci]->has_q0;
     }
-    if (n_max >= (1u << 20)) return fail(FLORIA_E_UNSUPPORTED, "more than 2^20 reads in one block");
-    const uint64_t tot = rids.size();
-    std::vector<uint32_t> jobs;
-    for (uint32_t b = 0; b < n_blocks; ++b) if (roff[b + 1] > roff[b]) jobs.push_back(b);
-    std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return (roff[a + 1] - roff[a]) > (roff[b2 + 1] - roff[b2]); });
-
-    int rc = ensure_binom(ctx, prm->epsilon, len_max); if (rc) return rc;
-    rc = ensure_hash(ctx, span_max * nall); if (rc) return rc;
-
-    // ---- device staging (one misc allocation) --------------------------------------------------------------
+    for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) {
+        len_max = std::max(len_max, contigs[i]->max_len);
+        nall = std::max(nall, contigs[i]->n_alleles);
+        any_q0 = any_q0 || contigs[i]->has_q0;
+    }
     std::vector<fl::ContigDev> cdev(n_contigs);
     for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) cdev[i] = contigs[i]->dev;
     struct Seg { size_t off, bytes; };
     size_t cursor = 0;
     auto seg = [&](size_t bytes) { Seg s{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return s; };
-    Seg s_cdev = seg(sizeof(fl::ContigDev) * std::max(1u, n_contigs)), s_bc = seg(4ull * n_blocks + 4), s_bs = seg(4ull * n_blocks + 4),
-        s_be = seg(4ull * n_blocks + 4), s_p0 = seg(4ull * n_blocks + 4), s_sp = seg(4ull * n_blocks + 4), s_roff = seg(8ull * (n_blocks + 1)),
-        s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg(tot + 16),
-        s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
-        s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(16), s_margin = seg(16),
-        s_diag = seg(16), s_steps = seg(16);
-    rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
-    char* M = ctx->misc.as<char>();
+    const Seg s_cdev = seg(sizeof(fl::ContigDev) * std::max(1u, n_contigs)), s_bc = seg(4ull * n_blocks + 4), s_bs = seg(4ull * n_blocks + 4),
+              s_be = seg(4ull * n_blocks + 4), s_p0 = seg(4ull * n_blocks + 4), s_sp = seg(4ull * n_blocks + 4), s_cnt = seg(4ull * n_blocks + 4),
+              s_bytes = seg(8ull * n_blocks + 8), s_roff = seg(8ull * (n_blocks + 1));
+    int rc = ctx->misc0.ensure(cursor + 256); if (rc) return rc;
+    char* M0 = ctx->misc0.as<char>();
     EventTimer T(ctx->stream);
     int th = T.begin(K_H2D);
-    auto h2d = [&](Seg s, const void* src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(M + s.off, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; };
-    HIPCHK(h2d(s_cdev, cdev.data(), sizeof(fl::ContigDev) * n_contigs));
-    HIPCHK(h2d(s_bc, bc.data(), 4ull * n_blocks));
-    HIPCHK(h2d(s_bs, blk_start, 4ull * n_blocks));
-    HIPCHK(h2d(s_be, blk_end, 4ull * n_blocks));
-    HIPCHK(h2d(s_p0, pos0.data(), 4ull * n_blocks));
-    HIPCHK(h2d(s_sp, span.data(), 4ull * n_blocks));
-    HIPCHK(h2d(s_roff, roff.data(), 8ull * (n_blocks + 1)));
-    HIPCHK(h2d(s_rids, rids.data(), 4ull * tot));
-    HIPCHK(h2d(s_jobs, jobs.data(), 4ull * jobs.size()));
+    HIPCHK(hipMemcpyAsync(M0 + s_cdev.off, cdev.data(), sizeof(fl::ContigDev) * n_contigs, hipMemcpyHostToDevice, ctx->stream));
+    if (n_blocks) {
+        HIPCHK(hipMemcpyAsync(M0 + s_bc.off, bc.data(), 4ull * n_blocks, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(M0 + s_bs.off, blk_start, 4ull * n_blocks, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(M0 + s_be.off, blk_end, 4ull * n_blocks, hipMemcpyHostToDevice, ctx->stream));
+    }
+    T.end(th);
+    fl::ScanArgs sa{};
+    sa.contigs = (const fl::ContigDev*)(M0 + s_cdev.off);
+    sa.blk_contig = (const uint32_t*)(M0 + s_bc.off); sa.blk_start = (const uint32_t*)(M0 + s_bs.off); sa.blk_end = (const uint32_t*)(M0 + s_be.off);
+    sa.n_blocks = n_blocks; sa.max_ploidy = P;
+    sa.cnt = (uint32_t*)(M0 + s_cnt.off); sa.pos0 = (uint32_t*)(M0 + s_p0.off); sa.span = (uint32_t*)(M0 + s_sp.off); sa.bytes = (uint64_t*)(M0 + s_bytes.off);
+    std::vector<uint32_t> cnt(n_blocks, 0), span(n_blocks, 0);
+    std::vector<uint64_t> blk_bytes(n_blocks, 0), roff(n_blocks + 1, 0);
+    if (n_blocks) {
+        int tk = T.begin(K_SEL);
+        hipLaunchKernelGGL(fl::block_reads_kernel<false>, dim3(n_blocks), dim3(64), 0, ctx->stream, sa);
+        T.end(tk);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(cnt.data(), sa.cnt, 4ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(span.data(), sa.span, 4ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(blk_bytes.data(), sa.bytes, 8ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    uint64_t algo_bytes = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        roff[b + 1] = roff[b] + cnt[b];
+        n_max = std::max(n_max, cnt[b]); span_max = std::max(span_max, span[b]);
+        algo_bytes += blk_bytes[b];
+    }
+    if (n_max >= (1u << 20)) return fail(FLORIA_E_UNSUPPORTED, "more than 2^20 reads in one block");
+    const uint64_t tot = roff[n_blocks];
+    std::vector<uint32_t> jobs;
+    for (uint32_t b = 0; b < n_blocks; ++b) if (cnt[b]) jobs.push_back(b);
+    std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return cnt[a] > cnt[b2]; });
+
+    rc = ensure_binom(ctx, prm->epsilon, len_max); if (rc) return rc;
+    rc = ensure_hash(ctx, span_max * nall); if (rc) return rc;
+
+    // ---- device staging of the per-call arrays ----------------------------------------------------------------------
+    cursor = 0;
+    const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg(tot + 16),
+              s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
+              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(16), s_margin = seg(16),
+              s_diag = seg(16), s_steps = seg(16);
+    rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
+    char* M = ctx->misc.as<char>();
+    th = T.begin(K_H2D);
+    HIPCHK(hipMemcpyAsync(M0 + s_roff.off, roff.data(), 8ull * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (!jobs.empty()) HIPCHK(hipMemcpyAsync(M + s_jobs.off, jobs.data(), 4ull * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_mec.off, 0, s_mec.bytes, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_na.off, 0, s_na.bytes, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_it.off, 0, s_it.bytes, ctx->stream));
@@ -564,12 +577,19 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     const double inf = std::numeric_limits<double>::infinity();
     HIPCHK(hipMemcpyAsync(M + s_margin.off, &inf, 8, hipMemcpyHostToDevice, ctx->stream));
     T.end(th);
+    if (n_blocks) {
+        sa.roff = (const uint64_t*)(M0 + s_roff.off); sa.rids = (uint32_t*)(M + s_rids.off);
+        int tk = T.begin(K_SEL);
+        hipLaunchKernelGGL(fl::block_reads_kernel<true>, dim3(n_blocks), dim3(64), 0, ctx->stream, sa);
+        T.end(tk);
+        HIPCHK(hipGetLastError());
+    }
 
     fl::BlockSet bs{};
-    bs.contigs = (const fl::ContigDev*)(M + s_cdev.off);
-    bs.blk_contig = (const uint32_t*)(M + s_bc.off); bs.blk_start = (const uint32_t*)(M + s_bs.off); bs.blk_end = (const uint32_t*)(M + s_be.off);
-    bs.blk_pos0 = (const uint32_t*)(M + s_p0.off); bs.blk_span = (const uint32_t*)(M + s_sp.off);
-    bs.blk_read_off = (const uint64_t*)(M + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
+    bs.contigs = (const fl::ContigDev*)(M0 + s_cdev.off);
+    bs.blk_contig = (const uint32_t*)(M0 + s_bc.off); bs.blk_start = (const uint32_t*)(M0 + s_bs.off); bs.blk_end = (const uint32_t*)(M0 + s_be.off);
+    bs.blk_pos0 = (const uint32_t*)(M0 + s_p0.off); bs.blk_span = (const uint32_t*)(M0 + s_sp.off);
+    bs.blk_read_off = (const uint64_t*)(M0 + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
 
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
     rc = run(ctx, any_q0, bs, jobs, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
@@ -606,6 +626,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
         if (e == hipSuccess) e = hipMemcpyAsync(R->ploidies_tried, M + s_tried.off, 4ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(R->mec, M + s_mec.off, 8ull * n_blocks * P, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && tot) e = hipMemcpyAsync(R->part, M + s_out.off, tot, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && tot) e = hipMemcpyAsync(R->read_id, M + s_rids.off, 4ull * tot, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(diag, M + s_diag.off, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&steps, M + s_steps.off, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -615,7 +636,6 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     if (e != hipSuccess) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, std::string("phase_blocks: ") + hipGetErrorString(e)); }
     if (diag[1]) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
     memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
-    if (tot) memcpy(R->read_id, rids.data(), 4ull * tot);
     R->min_prune_margin = margin;
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
     ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
