@@ -303,11 +303,13 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             a.cand_gain_pool = ctx->opt_gain.as<uint64_t>(); a.cand_key_pool = ctx->opt_key.as<uint32_t>();
             a.moves_pool = ctx->opt_moves.as<uint32_t>(); a.cand_cap = cand_cap;
             a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
+            a.prof = (unsigned long long*)(d_diag + 4);
             const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
             const size_t hist_bytes = (size_t)span_max * p * A * 8;
-            const bool hl = hist_bytes + moved_bytes <= 56 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
-            const size_t lds = moved_bytes + (hl ? hist_bytes : 0) + 16;
-            if (hl) slots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((150 * 1024) / (lds + 14 * 1024))));
+            const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
+            const bool hl = hist_bytes + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
+            const size_t lds = moved_bytes + meta_bytes + (hl ? hist_bytes : 0) + 16;
+            slots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((156 * 1024) / (lds + 8 * 1024))));
             if (lds > 48 * 1024) {
                 if (hl) HIPCHK(hipFuncSetAttribute((const void*)fl::optimize_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 else HIPCHK(hipFuncSetAttribute((const void*)fl::optimize_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -559,7 +561,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg(tot + 16),
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
               s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(16), s_margin = seg(16),
-              s_diag = seg(16), s_steps = seg(16);
+              s_diag = seg(16 + 8 * 32), s_steps = seg(16);
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
     char* M = ctx->misc.as<char>();
     th = T.begin(K_H2D);
@@ -572,7 +574,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     HIPCHK(hipMemsetAsync(M + s_best.off, 0, s_best.bytes, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_tried.off, 0, s_tried.bytes, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_out.off, 0, s_out.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_diag.off, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_diag.off, 0, 16 + 8 * 32, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_steps.off, 0, 16, ctx->stream));
     const double inf = std::numeric_limits<double>::infinity();
     HIPCHK(hipMemcpyAsync(M + s_margin.off, &inf, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -635,6 +637,9 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, std::string("phase_blocks: ") + hipGetErrorString(e)); }
     if (diag[1]) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
+#ifdef FLORIA_PROF
+    { unsigned long long prof[32]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
+#endif
     memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
     R->min_prune_margin = margin;
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);

@@ -18,7 +18,8 @@
 namespace fl {
 
 constexpr int OPT_THREADS = 256;
-constexpr int OPT_SORT_LDS = 1024;        // candidates sorted in LDS up to this many
+constexpr int OPT_SORT_LDS = 512;
+constexpr int OPT_META_MAX = 4096;        // reads per block whose (cell offset, length, partition) are staged in LDS        // candidates sorted in LDS up to this many
 constexpr int NUM_ITER_OPTIMIZE = 20;     // constants.rs:3
 constexpr int OPT_U = 8;                  // cells per software-pipelined batch of the distance loop
 
@@ -42,7 +43,24 @@ struct OptArgs {
     double*   mec;               // [n_blocks*max_ploidy]   mec_vector[p-1]
     double*   num_alleles;       // [n_blocks*max_ploidy]
     uint32_t* iters;             // [n_blocks*max_ploidy]   optimisation rounds run (diagnostic)
+    unsigned long long* prof;    // [16] cycle counters per phase (only with -DFLORIA_PROF)
 };
+#ifdef FLORIA_PROF
+#define OPT_TICK(ph) do { __syncthreads(); if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[ph], _t - t_last); t_last = _t; } } while (0)
+#else
+#define OPT_TICK(ph) do {} while (0)
+#endif
+
+// all-reduce (sum) over each row of 16 lanes with DPP (no LDS crossbar): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t row16_sum_u64(uint64_t v) {
+    v += dpp_u64<0xB1>(v); v += dpp_u64<0x4E>(v); v += dpp_u64<0x141>(v); v += dpp_u64<0x140>(v);
+    return v;
+}
 
 __device__ __forceinline__ bool cand_before(uint64_t ga, uint32_t ka, uint64_t gb, uint32_t kb) {
     return ga > gb || (ga == gb && ka < kb);
@@ -85,7 +103,11 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t p = g.ploidy, PA = p * A;
     const uint32_t moved_bytes = (((g.n_max + 31) / 32) * 4 + 15) & ~15u;
-    uint64_t* hist = HL ? (uint64_t*)(smem + moved_bytes) : g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
+    const uint32_t meta_n = g.n_max <= (uint32_t)OPT_META_MAX ? g.n_max : 0;            // 0 = read the metadata from HBM every time
+    const uint32_t meta_bytes = (meta_n * 8 + 15) & ~15u;
+    uint32_t* m_cb = (uint32_t*)(smem + moved_bytes);
+    uint32_t* m_lk = m_cb + meta_n;                                                   // cell count | partition << 24
+    uint64_t* hist = HL ? (uint64_t*)(smem + moved_bytes + meta_bytes) : g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
     double* dist = g.dist_pool + (uint64_t)blockIdx.x * g.n_max * p;
     uint64_t* cgain = g.cand_gain_pool + (uint64_t)blockIdx.x * g.cand_cap;
     uint32_t* ckey = g.cand_key_pool + (uint64_t)blockIdx.x * g.cand_cap;
@@ -107,20 +129,42 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         const uint8_t* pin = g.part_in + roff;
         uint8_t* part = g.part_out + roff;
         const uint32_t ncell = span * PA;
+#ifdef FLORIA_PROF
+        unsigned long long t_last = clock64();
+#endif
 
         // ---- hap_block_from_partition (utils_frags.rs:177-184): phred sums and unit counts in one cell -----
         for (uint32_t x = tid; x < ncell; x += OPT_THREADS) hist[x] = 0;
         if (tid < MAX_PLOIDY) s_size[tid] = 0;
         __syncthreads();
+        // stage (first cell, #cells, partition) of every read once: the chain reads[i] -> read_off[r] -> cells is then one hop
+        const bool meta = meta_n != 0;
         for (uint32_t i = tid; i < n; i += OPT_THREADS) {
             const uint32_t r = reads[i], k = pin[i];
             part[i] = (uint8_t)k;
             atomicAdd(&s_size[k], 1u);
-            const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
-            for (uint32_t c = cb; c < ce; ++c) {
-                const uint32_t aq = cd.cell_aq[c];
-                atomicAdd((unsigned long long*)&hist[(uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A + (aq >> 8)],
-                          (unsigned long long)((1ull << CNT_SHIFT) | c_w24[aq & 0xff]));
+            if (meta) { const uint32_t cb = cd.read_off[r]; m_cb[i] = cb; m_lk[i] = (cd.read_off[r + 1] - cb) | (k << 24); }
+        }
+        __syncthreads();
+        auto read_meta = [&](uint32_t i, uint32_t& cb, uint32_t& len, uint32_t& k) {
+            if (meta) { cb = m_cb[i]; const uint32_t lk = m_lk[i]; len = lk & 0xffffffu; k = lk >> 24; }
+            else { const uint32_t r = reads[i]; cb = cd.read_off[r]; len = cd.read_off[r + 1] - cb; k = part[i]; }
+        };
+        // 16 lanes per read (4 reads per wavefront, 16 per workgroup pass): 64-B coalesced cell segments, up to 8 cells
+        // per lane loaded before the first atomic
+        const uint32_t grp = tid >> 4, sub = tid & 15;
+        const uint32_t n16 = (n + 15) & ~15u;
+        for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
+            uint32_t cb = 0, len = 0, k = 0;
+            if (i < n) read_meta(i, cb, len, k);
+            for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {
+                uint32_t sn[8], aqs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aq[cb + c] : 0xffffffffu; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (aqs[u] != 0xffffffffu)
+                        atomicAdd((unsigned long long*)&hist[(uint64_t)(sn[u] - pos0) * PA + k * A + (aqs[u] >> 8)], (unsigned long long)((1ull << CNT_SHIFT) | c_w24[aqs[u] & 0xff]));
             }
         }
         __syncthreads();
@@ -159,46 +203,56 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
 
+        OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
         if (not_empty) {
             mec_stats(true);
+            OPT_TICK(1);     // first stats
             double prev_score = s_score;
             for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
                 iters_done = it + 1;
                 if (p == 1) break;      // one partition: opt_iterate has no target (j != i), new_part == best_part, not accepted
                 // ---- opt_iterate (:292-358): distance of every read to every partition ------------------------
-                for (uint32_t pair = tid; pair < n * p; pair += OPT_THREADS) {
-                    const uint32_t i = pair / p, k = pair - i * p;
-                    const uint32_t r = reads[i];
-                    const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
-                    uint64_t qd = 0; uint32_t m = 0;
-                    auto one = [&](const uint64_t* cp, uint32_t aq) {
-                        const uint32_t al = aq >> 8;
-                        uint64_t mx = 0, va = 0;
+                // 16 lanes per read: every lane classifies its cells against all p partitions (p x 16 B of one histogram row),
+                // packed partial (diff Q24 << 16 | #eps) per partition, DPP row all-reduce, lane k of the row stores
+                for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
+                    uint32_t cb = 0, len = 0, kk = 0;
+                    if (i < n) read_meta(i, cb, len, kk);
+                    uint64_t acc[MAX_PLOIDY];
 #pragma unroll
-                        for (int x = 0; x < A; ++x) { const uint64_t q = cp[x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
-                        m += mx == 0 ? 1u : 0u;
-                        qd += (mx != 0 && va != mx) ? (uint64_t)c_w24[aq & 0xff] : 0ull;
-                    };
-                    uint32_t c = cb;
-                    for (; c + OPT_U <= ce; c += OPT_U) {            // OPT_U independent (cell -> histogram) load chains in flight
-                        uint32_t sn[OPT_U], aqs[OPT_U];
+                    for (int k = 0; k < MAX_PLOIDY; ++k) acc[k] = 0;
+                    for (uint32_t c0 = sub; c0 < len; c0 += 16 * 4) {
+                        uint32_t sn[4], aqs[4];
 #pragma unroll
-                        for (int u = 0; u < OPT_U; ++u) { sn[u] = cd.cell_snp[c + u]; aqs[u] = cd.cell_aq[c + u]; }
-                        uint64_t hv[OPT_U][A];
+                        for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aq[cb + c] : 0xffffffffu; }
 #pragma unroll
-                        for (int u = 0; u < OPT_U; ++u) {
-                            const uint64_t* cp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
+                        for (int u = 0; u < 4; ++u) {
+                            if (aqs[u] != 0xffffffffu) {
+                                const uint32_t al = aqs[u] >> 8;
+                                const uint64_t w = c_w24[aqs[u] & 0xff];
+                                const uint64_t* row = hist + (uint64_t)(sn[u] - pos0) * PA;
 #pragma unroll
-                            for (int x = 0; x < A; ++x) hv[u][x] = cp[x];
+                                for (int k = 0; k < MAX_PLOIDY; ++k) {
+                                    if ((uint32_t)k < p) {
+                                        uint64_t mx = 0, va = 0;
+#pragma unroll
+                                        for (int x = 0; x < A; ++x) { const uint64_t q = row[k * A + x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
+                                        acc[k] += mx == 0 ? 1ull : ((va != mx) ? (w << 16) : 0ull);
+                                    }
+                                }
+                            }
                         }
-#pragma unroll
-                        for (int u = 0; u < OPT_U; ++u) one(hv[u], aqs[u]);
                     }
-                    for (; c < ce; ++c) one(hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + k * A, cd.cell_aq[c]);
-                    dist[pair] = qm_to_f64(qd, m, g.eps);
+#pragma unroll
+                    for (int k = 0; k < MAX_PLOIDY; ++k) {
+                        if ((uint32_t)k < p) {
+                            const uint64_t t = row16_sum_u64(acc[k]);
+                            if (sub == (uint32_t)k && i < n) dist[i * p + k] = qm_to_f64(t >> 16, t & 0xffff, g.eps);
+                        }
+                    }
                 }
+                OPT_TICK(2);     // dist
                 if (tid == 0) { s_ncand = 0; s_nmoves = 0; }
                 for (uint32_t x = tid; x < (n + 31) / 32; x += OPT_THREADS) s_moved[x] = 0;
                 __syncthreads();
@@ -215,6 +269,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 }
                 __syncthreads();
                 const uint32_t M = s_ncand;
+                OPT_TICK(3);     // candidates
                 if (M == 0) break;          // new_part == best_part -> new_score == prev_score -> not accepted (:114-126)
                 uint32_t M2 = 1;
                 while (M2 < M) M2 <<= 1;
@@ -228,6 +283,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     __syncthreads();
                     bitonic_sort(cgain, ckey, M2, tid, OPT_THREADS);
                 }
+                OPT_TICK(4);     // sort
                 // ---- serial application (:336-356) --------------------------------------------------------------
                 if (tid == 0) {
                     uint32_t number_of_moves = M / 10;
@@ -247,6 +303,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 }
                 __syncthreads();
                 const uint32_t nm = s_nmoves;
+                OPT_TICK(5);     // serial apply
                 // apply to histogram + partition (direction +1), or undo (direction -1)
                 auto apply_moves = [&](bool undo) {
                     for (uint32_t x = wid; x < nm; x += OPT_THREADS / 64) {
@@ -267,7 +324,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     __syncthreads();
                 };
                 apply_moves(false);
+                OPT_TICK(6);     // moves
                 mec_stats(true);
+                OPT_TICK(7);     // round stats
                 const double new_score = s_score;
                 if (new_score > prev_score) prev_score = new_score;
                 else {                                   // rejected: keep best_part / prev_hap_block
@@ -279,7 +338,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             }
         }
         // ---- get_mec_stats_epsilon_no_phred of the optimised partition (graph_processing.rs:156-162) -----------
+        OPT_TICK(8);
         mec_stats(false);
+        OPT_TICK(9);     // final stats
         if (tid == 0) {
             double mecv = 0.0, na = 0.0;
             for (uint32_t k = 0; k < p; ++k) {
