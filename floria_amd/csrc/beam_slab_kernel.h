@@ -23,7 +23,29 @@
 namespace fl {
 
 constexpr int SLAB_TILE = 256;
-constexpr int SLAB_NS_MAX = 512;      // ploidy * (ploidy*beam) slabs per resident job
+
+// segmented all-reduce (sum) over aligned groups of Gs = 2,4,8,16 lanes with DPP row operations
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_mov64(uint64_t v) { return ((uint64_t)dpp_mov<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_mov<CTRL>((uint32_t)v); }
+__device__ __forceinline__ uint64_t seg_sum_u64(uint64_t v, uint32_t Gs) {
+    if (Gs >= 2) v += dpp_mov64<0xB1>(v);      // quad_perm [1,0,3,2]
+    if (Gs >= 4) v += dpp_mov64<0x4E>(v);      // quad_perm [2,3,0,1]
+    if (Gs >= 8) v += dpp_mov64<0x141>(v);     // row_half_mirror
+    if (Gs >= 16) v += dpp_mov64<0x140>(v);    // row_mirror
+    return v;
+}
+__device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
+    if (Gs >= 2) v += dpp_mov<0xB1>(v);
+    if (Gs >= 4) v += dpp_mov<0x4E>(v);
+    if (Gs >= 8) v += dpp_mov<0x141>(v);
+    if (Gs >= 16) v += dpp_mov<0x140>(v);
+    return v;
+}
+constexpr int SLAB_NS_MAX = 512;
+#ifndef FLORIA_SLAB_U
+#define FLORIA_SLAB_U 4
+#endif
+constexpr int SLAB_U = FLORIA_SLAB_U;      // ploidy * (ploidy*beam) slabs per resident job
 
 struct SlabLds {
     uint32_t off_coff, off_caw, off_crp1, off_crp2;
@@ -50,6 +72,12 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
     L.total = o;
     return L;
 }
+
+#ifdef FLORIA_PROF
+#define BEAM_TICK(ph) do { const unsigned long long _t = clock64(); t_acc[ph] += _t - t_last; t_last = _t; } while (0)
+#else
+#define BEAM_TICK(ph) do {} while (0)
+#endif
 
 template <int A, bool Q0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_WAVES, FLORIA_FAST_WAVES)))
@@ -90,6 +118,9 @@ void beam_slab_kernel(BeamArgs g) {
     const int seg0 = (int)(my_sl * p);
     double min_margin = 1e300;
     uint32_t n_fallback = 0;
+#ifdef FLORIA_PROF
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
+#endif
 
     for (;;) {
         uint32_t job = 0;
@@ -119,41 +150,63 @@ void beam_slab_kernel(BeamArgs g) {
         uint64_t ev_s = 0, ev_h1 = 0, ev_h2 = 0, ev_q = 0;
         uint32_t ev_m = 0, ev_pk = 0;
         RegHeap H; H.hp_s = 0; H.hp_id = 0; H.len = 0;
-        uint32_t r_next = n > 0 ? reads[0] : 0;
+        // software pipeline over reads: metadata two reads ahead, the first tile's cells one read ahead
+        struct Meta { uint32_t cbeg, L, first, last; uint64_t tw1, tw2; };
+        auto load_meta = [&](uint32_t r) { Meta m; m.cbeg = cd.read_off[r]; m.L = cd.read_off[r + 1] - m.cbeg; m.first = cd.first[r]; m.last = cd.last[r];
+                                           m.tw1 = cd.tw[2 * (uint64_t)r]; m.tw2 = cd.tw[2 * (uint64_t)r + 1]; return m; };
+        uint32_t pf_snp[SLAB_TILE / 64], pf_aq[SLAB_TILE / 64];
+        auto load_cells = [&](const Meta& m) {
+#pragma unroll
+            for (int u = 0; u < SLAB_TILE / 64; ++u) {
+                const uint32_t c = lane + 64 * u;
+                const bool v = c < m.L;
+                pf_snp[u] = v ? cd.cell_snp[m.cbeg + c] : 0;
+                pf_aq[u] = v ? cd.cell_aq[m.cbeg + c] : 0;
+            }
+        };
+        Meta m_cur = load_meta(reads[0]);
+        Meta m_next = m_cur;
+        if (n > 1) m_next = load_meta(reads[1]);
+        uint32_t r_next2 = n > 2 ? reads[2] : 0;
+        load_cells(m_cur);
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t r = uni(r_next);
-            if (i + 1 < n) r_next = reads[i + 1];
-            const uint32_t cbeg = uni(cd.read_off[r]), L = uni(cd.read_off[r + 1]) - cbeg;
-            const uint32_t first_rel = uni(cd.first[r]) - pos0;
-            const int32_t  last_rel = (int32_t)(uni(cd.last[r]) - pos0);
+            const uint32_t cbeg = uni(m_cur.cbeg), L = uni(m_cur.L);
+            const uint32_t first_rel = uni(m_cur.first) - pos0;
+            const int32_t  last_rel = (int32_t)(uni(m_cur.last) - pos0);
+            const uint64_t tw1 = ((uint64_t)uni((uint32_t)(m_cur.tw1 >> 32)) << 32) | uni((uint32_t)m_cur.tw1);
+            const uint64_t tw2 = ((uint64_t)uni((uint32_t)(m_cur.tw2 >> 32)) << 32) | uni((uint32_t)m_cur.tw2);
+            // metadata of read i+2 is requested now and consumed two steps later
+            Meta m_next2 = m_next;
+            if (i + 2 < n) m_next2 = load_meta(uni(r_next2));
+            if (i + 3 < n) r_next2 = reads[i + 3];
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
             const uint32_t ntiles = (L + SLAB_TILE - 1) / SLAB_TILE;
             uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);
             uint32_t* st_m = ST_m(cur); uint16_t* st_sl = ST_sl(cur);
 
-            uint64_t tw1 = 0, tw2 = 0, rpb1 = 0, rpb2 = 0;
+            uint64_t rpb1 = 0, rpb2 = 0;
             uint32_t nin = 0;
-            auto stage_tile = [&](uint32_t t, bool with_tw) {
+            auto stage_tile = [&](uint32_t t, bool from_regs) {
                 __syncthreads();
                 uint32_t cnt_in = 0;
                 uint64_t b1 = 0, b2 = 0;
-                for (uint32_t c = lane; c < SLAB_TILE; c += 64) {
+#pragma unroll
+                for (int u = 0; u < SLAB_TILE / 64; ++u) {
+                    const uint32_t c = lane + 64 * u;
                     const uint32_t cc = t * SLAB_TILE + c;
                     bool in = false;
                     if (cc < L) {
-                        const uint32_t pr = cd.cell_snp[cbeg + cc] - pos0;
-                        const uint32_t aq = cd.cell_aq[cbeg + cc];
+                        const uint32_t snp = from_regs ? pf_snp[u] : cd.cell_snp[cbeg + cc];
+                        const uint32_t aq = from_regs ? pf_aq[u] : (uint32_t)cd.cell_aq[cbeg + cc];
+                        const uint32_t pr = snp - pos0;
                         const uint32_t al = aq >> 8;
-                        const uint32_t w = c_w24[aq & 0xff];
-                        const uint32_t idx = pr * A + al;
                         c_off[c] = pr * pos_bytes;
-                        c_aw[c] = (al << 28) | w;
+                        c_aw[c] = (al << 28) | c_w24[aq & 0xff];
                         in = (int32_t)pr <= hi_rel;
-                        if (with_tw) { tw1 += g.Rq1[idx] * (uint64_t)w; tw2 += g.Rq2[idx] * (uint64_t)w; }
                         if (Q0) {
-                            const uint64_t r1 = g.Rp1[idx], r2 = g.Rp2[idx];
+                            const uint64_t r1 = g.Rp1[hash_idx(snp, al)], r2 = g.Rp2[hash_idx(snp, al)];
                             c_rp1[c] = r1; c_rp2[c] = r2;
                             if (!in) { b1 += r1; b2 += r2; }
                         }
@@ -164,20 +217,14 @@ void beam_slab_kernel(BeamArgs g) {
                 if (Q0) { rpb1 = wave_sum_u64(b1); rpb2 = wave_sum_u64(b2); }
                 __syncthreads();
             };
-            if (ntiles > 1) {
-                for (uint32_t c = lane; c < L; c += 64) {
-                    const uint32_t pr = cd.cell_snp[cbeg + c] - pos0;
-                    const uint32_t aq = cd.cell_aq[cbeg + c];
-                    const uint32_t idx = pr * A + (aq >> 8);
-                    const uint64_t w = c_w24[aq & 0xff];
-                    tw1 += g.Rq1[idx] * w; tw2 += g.Rq2[idx] * w;
-                }
-            } else stage_tile(0, true);
-            tw1 = wave_sum_u64(tw1); tw2 = wave_sum_u64(tw2);
+            if (ntiles == 1) stage_tile(0, true);
+            BEAM_TICK(0);
 
             // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
             uint32_t Gs = 1;
             while (Gs < 16 && nlive * (Gs * 2) <= 64) Gs *= 2;
+            const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
+            const bool trunc = tend >= (int32_t)start_rel;            // some written position leaves the hash window this step
             const uint32_t per = 64 / Gs;                       // slabs per pass
             for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
                 const uint32_t li = l0 + lane / Gs, sub = lane % Gs;
@@ -186,7 +233,6 @@ void beam_slab_kernel(BeamArgs g) {
                 uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
                 uint32_t m = 0;
                 {   // positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel]
-                    const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
                     for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
                         if (act) {
 #pragma unroll
@@ -194,15 +240,16 @@ void beam_slab_kernel(BeamArgs g) {
                                 const uint64_t v = *(const uint64_t*)(pool + (slab_off + (uint32_t)pr * pos_bytes + al * 8));
                                 if (v) {
                                     const uint64_t qv = Q0 ? (v & QMASK63) : v;
-                                    t1 += g.Rq1[pr * A + al] * qv; t2 += g.Rq2[pr * A + al] * qv;
-                                    if (Q0) { t1 += g.Rp1[pr * A + al]; t2 += g.Rp2[pr * A + al]; }
+                                    const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al);
+                                    t1 += g.Rq1[hx] * qv; t2 += g.Rq2[hx] * qv;
+                                    if (Q0) { t1 += g.Rp1[hx]; t2 += g.Rp2[hx]; }
                                 }
                             }
                         }
                     }
                 }
                 uint32_t ps = 0, pd = 0;
-                auto cell = [&](const ulonglong2* vv, uint32_t aw, uint32_t c) {
+                auto cell = [&](const ulonglong2* vv, uint32_t aw, uint32_t c, bool valid) {
                     const uint32_t al = aw >> 28;
                     const uint32_t w = aw & 0x0fffffffu;
                     bool nonempty, same;
@@ -224,54 +271,46 @@ void beam_slab_kernel(BeamArgs g) {
                     }
                     ps += (nonempty && same) ? w : 0u;
                     pd += (nonempty && !same) ? w : 0u;
-                    m += nonempty ? 0u : 1u;
-                    if (Q0) { const bool np = !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
+                    m += (valid && !nonempty) ? 1u : 0u;
+                    if (Q0) { const bool np = valid && !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
                 };
                 for (uint32_t t = 0; t < ntiles; ++t) {
                     if (ntiles > 1) stage_tile(t, false);
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
                     if (act) {
-                        uint32_t c = sub;
-                        for (; c + 3 * Gs < nin; c += 4 * Gs) {              // 4 independent loads in flight per lane
-                            uint32_t offs[4], aws[4];
+                        for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_U * Gs) {       // SLAB_U independent loads in flight per lane
+                            uint32_t offs[SLAB_U], aws[SLAB_U];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) { offs[u] = c_off[c + u * Gs]; aws[u] = c_aw[c + u * Gs]; }
-                            ulonglong2 vv[4][A / 2];
+                            for (int u = 0; u < SLAB_U; ++u) {      // invalid slots read cell 0 of the slab with weight 0: no branches
+                                const uint32_t c = c0 + u * Gs; const bool v = c < nin; const uint32_t cx = v ? c : 0;
+                                offs[u] = c_off[cx]; aws[u] = v ? c_aw[cx] : 0;
+                            }
+                            ulonglong2 vv[SLAB_U][A / 2];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < SLAB_U; ++u) {
                                 const char* cp = pool + (slab_off + offs[u]);
 #pragma unroll
                                 for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
                             }
                             ps = 0; pd = 0;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) cell(vv[u], aws[u], c + u * Gs);
-                            qs += ps; qd += pd;
-                        }
-                        for (; c < nin; c += Gs) {
-                            ulonglong2 vv[A / 2];
-                            const char* cp = pool + (slab_off + c_off[c]);
-#pragma unroll
-                            for (int x = 0; x < A / 2; ++x) vv[x] = *(const ulonglong2*)(cp + 16 * x);
-                            ps = 0; pd = 0;
-                            cell(vv, c_aw[c], c);
+                            for (int u = 0; u < SLAB_U; ++u) cell(vv[u], aws[u], c0 + u * Gs, c0 + u * Gs < nin);
                             qs += ps; qd += pd;
                         }
                         if (sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }   // cells beyond hi_rel (:45-48)
                     }
                 }
-                // segmented butterfly over the Gs lanes of a slab
-                for (uint32_t o = Gs >> 1; o > 0; o >>= 1) {
-                    qs += shfl_u64(qs, (int)(lane ^ o)); qd += shfl_u64(qd, (int)(lane ^ o)); m += __shfl(m, (int)(lane ^ o));
-                    t1 += shfl_u64(t1, (int)(lane ^ o)); t2 += shfl_u64(t2, (int)(lane ^ o));
-                    if (Q0) { np1 += shfl_u64(np1, (int)(lane ^ o)); np2 += shfl_u64(np2, (int)(lane ^ o)); }
-                }
+                // segmented all-reduce over the Gs lanes of a slab (DPP, no LDS crossbar)
+                qs = seg_sum_u64(qs, Gs); qd = seg_sum_u64(qd, Gs); m = seg_sum_u32(m, Gs);
+                if (trunc) { t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs); }
+                if (Q0) { np1 = seg_sum_u64(np1, Gs); np2 = seg_sum_u64(np2, Gs); }
                 if (act && sub == 0) {
                     r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m; r_t1[li] = t1; r_t2[li] = t2;
                     if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
                 }
             }
             __syncthreads();
+            BEAM_TICK(1);
 
             // ---- B: per (state, partition) pair: p-value, log-sum-exp, pruning, child (:74-134) -----------------------
             uint64_t evalid = 0;
@@ -298,9 +337,8 @@ void beam_slab_kernel(BeamArgs g) {
                 for (uint32_t j = 0; j < p; ++j) {
                     const double o = shfl_f64(pv, seg0 + (int)j);
                     mx = (j == 0) ? o : (o > mx ? o : mx);
-                    ts1 += shfl_u64(t1, seg0 + (int)j);
-                    ts2 += shfl_u64(t2, seg0 + (int)j);
                 }
+                if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
                 for (uint32_t j = 0; j < p; ++j) sum += exp(shfl_f64(pv, seg0 + (int)j) - mx);
                 const double lse = mx + log(sum);
                 bool pass = false;
@@ -333,6 +371,7 @@ void beam_slab_kernel(BeamArgs g) {
                 }
             }
 
+            BEAM_TICK(2);
             // ---- M: survivors (lane j = heap slot j = next state j) and their slabs -----------------------------------
             const uint32_t nnext = H.len;
             const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
@@ -387,6 +426,7 @@ void beam_slab_kernel(BeamArgs g) {
                 nx_sl[lane * p + kj] = newid[u_old];
                 slot_hist[beam_hist_off(i, LM, B) + lane] = pj | (kj << 16);
             }
+            BEAM_TICK(3);
             // copies of the written window [first_rel, hi_rel] for the new versions that could not go in place
             if (ncopy && hi_rel >= (int32_t)first_rel) {
                 const uint32_t cnt2 = ((uint32_t)(hi_rel - (int32_t)first_rel + 1) * A) >> 1;
@@ -426,6 +466,7 @@ void beam_slab_kernel(BeamArgs g) {
                 }
             }
             __syncthreads();
+            BEAM_TICK(4);
             // add the read ONCE per distinct new version (types_structs.rs:368-373)
             {
                 const uint64_t lmask = __ballot(lead);
@@ -458,7 +499,10 @@ void beam_slab_kernel(BeamArgs g) {
                     }
                 }
             }
+            m_cur = m_next; m_next = m_next2;
+            if (i + 1 < n) load_cells(m_cur);            // overlaps the read-modify-writes above; consumed by the next step's staging
             __syncthreads();
+            BEAM_TICK(5);
             cur ^= 1;
             nstates = nnext;
             nlive = nl;
@@ -470,15 +514,27 @@ void beam_slab_kernel(BeamArgs g) {
             H.hp_id = lane;
             uint32_t ecur = H.sorted_first();
             uint8_t* out = g.part_out + roff;
-            for (int32_t i = (int32_t)n - 1; i >= 0; --i) {
-                const uint32_t rec = slot_hist[beam_hist_off((uint32_t)i, LM, B) + ecur];
-                if (lane == 0) out[i] = (uint8_t)(rec >> 16);
-                ecur = uni(rec & 0xffff);
+            for (int32_t i = (int32_t)n - 1; i >= 0; i -= 8) {                 // 8 traceback rows per memory round trip
+                uint32_t row[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) row[u] = (i - u >= 0) ? slot_hist[beam_hist_off((uint32_t)(i - u), LM, B) + lane] : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i - u >= 0) {
+                        const uint32_t rec = rl32(row[u], ecur);
+                        if (lane == 0) out[i - u] = (uint8_t)(rec >> 16);
+                        ecur = rec & 0xffff;
+                    }
+                }
             }
             if (lane == 0) atomicAdd(g.steps_done, (unsigned long long)n);
         }
         __syncthreads();
+        BEAM_TICK(6);
     }
+#ifdef FLORIA_PROF
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g.prof[16 + i], t_acc[i]);
+#endif
     min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);
     if (lane == 0) {

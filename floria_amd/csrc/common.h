@@ -25,9 +25,15 @@ struct ContigDev {
     const uint32_t* last;       // [n_reads]
     const uint32_t* cell_snp;   // [n_cells] 1-based SNP index
     const uint16_t* cell_aq;    // [n_cells] allele << 8 | qual
+    const uint64_t* tw;         // [2*n_reads] per-read hash constants: sum over cells of Rq{1,2}[hash_idx(snp, allele)] * w
     uint32_t        n_reads;
     uint32_t        pad;
 };
+
+// Index of (absolute SNP position, allele) in the linear-hash multiplier tables.  Any window of <= HASH_M consecutive
+// positions maps injectively, and the index does not depend on the block, so a read's hash constant is precomputed once.
+constexpr uint32_t HASH_M = 65536;
+__host__ __device__ __forceinline__ uint32_t hash_idx(uint32_t snp, uint32_t allele) { return ((snp & (HASH_M - 1)) << 2) | allele; }
 
 // One batch of SNP blocks (the work units of graph_processing.rs:345-362).
 struct BlockSet {

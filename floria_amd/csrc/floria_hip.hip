@@ -86,6 +86,8 @@ struct floria_hip_ctx {
     DevBuf d_binom;
     DevBuf d_hash;            // Rq1 | Rp1 | Rq2 | Rp2, each hash_len u64
     uint32_t hash_len = 0;
+    std::vector<uint64_t> h_rq1, h_rq2;   // host copies of the Rq tables (per-read hash constants are computed at upload)
+    uint32_t w24[256];
     uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
     // scratch pools
     DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
@@ -100,7 +102,7 @@ struct floria_hip_contig {
     uint32_t n_alleles = 2;     // 2 or 4 (kernel template)
     bool has_q0 = false;        // some cell has qual 0 (weight 0): presence != (weight sum > 0)
     std::vector<uint32_t> h_first, h_last, h_read_off;
-    DevBuf d_read_off, d_first, d_last, d_snp, d_aq;
+    DevBuf d_read_off, d_first, d_last, d_snp, d_aq, d_tw;
     fl::ContigDev dev{};
 };
 
@@ -179,7 +181,7 @@ int ensure_binom(floria_hip_ctx* ctx, double eps, uint32_t nmax) {
 
 int ensure_hash(floria_hip_ctx* ctx, uint32_t len) {
     if (ctx->hash_len >= len && ctx->d_hash.p) return 0;
-    len = std::max<uint32_t>(len + len / 4, 4096);
+    len = std::max<uint32_t>(len, 4 * fl::HASH_M);
     std::vector<uint64_t> t((size_t)len * 4);
     uint64_t s = 0x1577f10a1aull;
     for (uint32_t i = 0; i < len; ++i) {
@@ -193,6 +195,8 @@ int ensure_hash(floria_hip_ctx* ctx, uint32_t len) {
     HIPCHK(hipMemcpyAsync(ctx->d_hash.p, t.data(), t.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hash_len = len;
+    ctx->h_rq1.assign(t.begin(), t.begin() + len);
+    ctx->h_rq2.assign(t.begin() + 2 * (size_t)len, t.begin() + 3 * (size_t)len);
     return 0;
 }
 
@@ -259,6 +263,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
             memcpy(a.Rk1, ctx->Rk1, sizeof(a.Rk1)); memcpy(a.Rk2, ctx->Rk2, sizeof(a.Rk2));
             a.part_out = d_beam_part; a.min_margin_bits = d_margin; a.diag = d_diag; a.steps_done = d_steps;
+            a.prof = (unsigned long long*)(d_diag + 4);
             const fl::BeamLds LY = fl::beam_lds_layout(LM);
             if (LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
             if (LY.total > 48 * 1024)
@@ -371,10 +376,12 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         w24[q] = (uint32_t)s;
         if ((double)w24[q] != s) { delete c; return fail(FLORIA_E_DEVICE, "quality weight is not a multiple of 2^-24"); }
     }
+    memcpy(c->w24, w24, sizeof(w24));
     e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_w24), w24, sizeof(w24));
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(FLORIA_E_DEVICE, std::string("weight LUT upload: ") + hipGetErrorString(e)); }
     uint64_t s = 0xf10a1a2024ull;
     for (int k = 0; k < FLORIA_MAX_PLOIDY; ++k) { c->Rk1[k] = splitmix64(s) | 1ull; c->Rk2[k] = splitmix64(s) | 1ull; }
+    if (int rc = ensure_hash(c, 4 * fl::HASH_M)) { (void)hipStreamDestroy(c->stream); delete c; return rc; }
     *out = c;
     return 0;
 }
@@ -452,7 +459,18 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     c->h_last.assign(p->last, p->last + p->n_reads);
     c->h_read_off.assign(p->read_off, p->read_off + p->n_reads + (p->n_reads ? 1 : 0));
     std::vector<uint16_t> aq(nc);
-    for (uint64_t i = 0; i < nc; ++i) { aq[i] = (uint16_t)((p->allele[i] << 8) | p->qual[i]); if (p->qual[i] == 0) c->has_q0 = true; }
+    std::vector<uint64_t> tw((size_t)p->n_reads * 2, 0);
+    for (uint32_t r = 0; r < p->n_reads; ++r) {
+        uint64_t t1 = 0, t2 = 0;
+        for (uint64_t i = p->read_off[r]; i < p->read_off[r + 1]; ++i) {
+            aq[i] = (uint16_t)((p->allele[i] << 8) | p->qual[i]);
+            if (p->qual[i] == 0) c->has_q0 = true;
+            const uint32_t idx = fl::hash_idx(p->snp[i], p->allele[i]);
+            const uint64_t w = ctx->w24[p->qual[i]];
+            t1 += ctx->h_rq1[idx] * w; t2 += ctx->h_rq2[idx] * w;
+        }
+        tw[2 * (size_t)r] = t1; tw[2 * (size_t)r + 1] = t2;
+    }
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         int r2 = b.ensure(std::max<size_t>(bytes, 16));
         if (r2) return r2;
@@ -464,16 +482,17 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     if (!rc) rc = up(c->d_last, p->last, (size_t)p->n_reads * 4);
     if (!rc) rc = up(c->d_snp, p->snp, nc * 4);
     if (!rc) rc = up(c->d_aq, aq.data(), nc * 2);
+    if (!rc) rc = up(c->d_tw, tw.data(), tw.size() * 8);
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(FLORIA_E_DEVICE, "upload sync failed");
     if (rc) { floria_hip_contig_free(c); return rc; }
     c->dev.read_off = c->d_read_off.as<uint32_t>(); c->dev.first = c->d_first.as<uint32_t>(); c->dev.last = c->d_last.as<uint32_t>();
-    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aq = c->d_aq.as<uint16_t>(); c->dev.n_reads = p->n_reads;
+    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aq = c->d_aq.as<uint16_t>(); c->dev.tw = c->d_tw.as<uint64_t>(); c->dev.n_reads = p->n_reads;
     *out = c;
     return 0;
 }
 void floria_hip_contig_free(floria_hip_contig* c) {
     if (!c) return;
-    for (DevBuf* b : {&c->d_read_off, &c->d_first, &c->d_last, &c->d_snp, &c->d_aq}) b->release();
+    for (DevBuf* b : {&c->d_read_off, &c->d_first, &c->d_last, &c->d_snp, &c->d_aq, &c->d_tw}) b->release();
     delete c;
 }
 
@@ -554,6 +573,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return cnt[a] > cnt[b2]; });
 
     rc = ensure_binom(ctx, prm->epsilon, len_max); if (rc) return rc;
+    if (span_max > fl::HASH_M) return fail(FLORIA_E_UNSUPPORTED, "a block's reads span more than 65536 SNPs");
     rc = ensure_hash(ctx, span_max * nall); if (rc) return rc;
 
     // ---- device staging of the per-call arrays ----------------------------------------------------------------------
