@@ -24,7 +24,7 @@ constexpr int FAST_TILE = 256;
 #define FLORIA_FAST_UNROLL 8
 #endif
 #ifndef FLORIA_FAST_WAVES
-#define FLORIA_FAST_WAVES 2
+#define FLORIA_FAST_WAVES 3
 #endif
 constexpr int FAST_UNROLL = FLORIA_FAST_UNROLL;
 
@@ -54,6 +54,11 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l) { return ((uint
 __device__ __forceinline__ void wl32(uint32_t& v, uint32_t x, uint32_t l) { v = (threadIdx.x == l) ? x : v; }
 __device__ __forceinline__ void wl64(uint64_t& v, uint64_t x, uint32_t l) { v = (threadIdx.x == l) ? x : v; }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// scalar (SMEM) load of read-only data at a wave-uniform address: the value lands in SGPRs, costs no VGPR and is
+// tracked by lgkmcnt, so it can be requested a whole beam step before it is used
+template <class T> __device__ __forceinline__ T sload(const T* p) {
+    return *(const __attribute__((address_space(4))) T*)(uintptr_t)p;
+}
 
 // Scores are non-negative f64 (sums of non-negative terms), so their IEEE bit patterns order like the values:
 // the heap compares u64 bit patterns.  Heap slot j lives in lane j: (hp_s, hp_id).
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
     const uint32_t S = 64 / p;
     const uint32_t my_sl = lane / p, my_k = lane % p;
     const bool lane_pair = my_sl < S;
-    const uint64_t rk1 = g.Rk1[my_k], rk2 = g.Rk2[my_k];
+    const uint64_t rk1 = c_rk1[my_k], rk2 = c_rk2[my_k];
     const int seg0 = (int)(my_sl * p);
     double min_margin = 1e300;
     uint32_t n_fallback = 0;
@@ -466,8 +471,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
             }
             __syncthreads();
             cur ^= 1;
-            st = (FastState*)(smem + LY.off_st[cur]);
-            nx = (FastState*)(smem + LY.off_st[cur ^ 1]);
+            st = (FastState*)(smem + (cur ? LY.off_st[1] : LY.off_st[0]));
+            nx = (FastState*)(smem + (cur ? LY.off_st[0] : LY.off_st[1]));
             nstates = nnext;
             hi_rel = new_hi;
             start_rel = first_rel;

@@ -43,7 +43,6 @@ struct BeamArgs {
     uint32_t  binom_nmax;
     double    eps, div_factor, cutoff;
     const uint64_t *Rq1, *Rp1, *Rq2, *Rp2;   // [span_max*A] random multipliers of the linear state hash
-    uint64_t  Rk1[MAX_PLOIDY], Rk2[MAX_PLOIDY];
     uint8_t*  part_out;            // [blk_read_off[n_blocks]] partition of every read of every block
     unsigned long long* min_margin_bits;
     uint32_t* diag;                // [0] = count of binom evaluations beyond the table, [1] = free-list underflow
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
     const uint32_t S = 64 / p;                                   // states per lane chunk
     const uint32_t my_sl = lane / p, my_k = lane % p;            // lane <-> (state-in-chunk, partition)
     const bool lane_pair = my_sl < S;
-    const uint64_t rk1 = g.Rk1[my_k], rk2 = g.Rk2[my_k];
+    const uint64_t rk1 = c_rk1[my_k], rk2 = c_rk2[my_k];
     double min_margin = 1e300;
     uint32_t n_fallback = 0;
 
@@ -430,8 +429,8 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
             __syncthreads();
             // swap current/next
             cur ^= 1;
-            st = (StateRec*)(smem + LY.off_st[cur]);
-            nx = (StateRec*)(smem + LY.off_st[cur ^ 1]);
+            st = (StateRec*)(smem + (cur ? LY.off_st[1] : LY.off_st[0]));
+            nx = (StateRec*)(smem + (cur ? LY.off_st[0] : LY.off_st[1]));
             nstates = nnext;
             hi_rel = new_hi;
             start_rel = first_rel;

@@ -114,7 +114,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t S = 64 / p;
     const uint32_t my_sl = lane / p, my_k = lane % p;
     const bool lane_pair = my_sl < S;
-    const uint64_t rk1 = g.Rk1[my_k], rk2 = g.Rk2[my_k];
+    const uint64_t rk1 = c_rk1[my_k], rk2 = c_rk2[my_k];
     const int seg0 = (int)(my_sl * p);
     double min_margin = 1e300;
     uint32_t n_fallback = 0;
@@ -136,11 +136,12 @@ void beam_slab_kernel(BeamArgs g) {
         const uint32_t pos0 = g.bs.blk_pos0[b];
 
         int cur = 0;
-        auto ST_q = [&](int w) { return (uint64_t*)(smem + LY.off_q[w]); };
-        auto ST_h1 = [&](int w) { return (uint64_t*)(smem + LY.off_h1[w]); };
-        auto ST_h2 = [&](int w) { return (uint64_t*)(smem + LY.off_h2[w]); };
-        auto ST_m = [&](int w) { return (uint32_t*)(smem + LY.off_m[w]); };
-        auto ST_sl = [&](int w) { return (uint16_t*)(smem + LY.off_sl[w]); };
+        // (select between the two static carve-outs; indexing LY.off_*[cur] dynamically would put LY in scratch)
+        auto ST_q = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_q[1] : LY.off_q[0])); };
+        auto ST_h1 = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_h1[1] : LY.off_h1[0])); };
+        auto ST_h2 = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_h2[1] : LY.off_h2[0])); };
+        auto ST_m = [&](int w) { return (uint32_t*)(smem + (w ? LY.off_m[1] : LY.off_m[0])); };
+        auto ST_sl = [&](int w) { return (uint16_t*)(smem + (w ? LY.off_sl[1] : LY.off_sl[0])); };
         uint32_t nstates = 1, nlive = 1;
         // root: every partition points at slab 0, which is logically empty (nothing written: hi_rel = -1)
         if (lane == 0) { ST_q(0)[0] = 0; ST_h1(0)[0] = 0; ST_h2(0)[0] = 0; ST_m(0)[0] = 0; live_id[0] = 0; s2l[0] = 0; }
@@ -152,8 +153,8 @@ void beam_slab_kernel(BeamArgs g) {
         RegHeap H; H.hp_s = 0; H.hp_id = 0; H.len = 0;
         // software pipeline over reads: metadata two reads ahead, the first tile's cells one read ahead
         struct Meta { uint32_t cbeg, L, first, last; uint64_t tw1, tw2; };
-        auto load_meta = [&](uint32_t r) { Meta m; m.cbeg = cd.read_off[r]; m.L = cd.read_off[r + 1] - m.cbeg; m.first = cd.first[r]; m.last = cd.last[r];
-                                           m.tw1 = cd.tw[2 * (uint64_t)r]; m.tw2 = cd.tw[2 * (uint64_t)r + 1]; return m; };
+        auto load_meta = [&](uint32_t r) { Meta m; m.cbeg = sload(cd.read_off + r); m.L = sload(cd.read_off + r + 1) - m.cbeg; m.first = sload(cd.first + r); m.last = sload(cd.last + r);
+                                           m.tw1 = sload(cd.tw + 2 * (uint64_t)r); m.tw2 = sload(cd.tw + 2 * (uint64_t)r + 1); return m; };
         uint32_t pf_snp[SLAB_TILE / 64], pf_aq[SLAB_TILE / 64];
         auto load_cells = [&](const Meta& m) {
 #pragma unroll
@@ -164,23 +165,22 @@ void beam_slab_kernel(BeamArgs g) {
                 pf_aq[u] = v ? cd.cell_aq[m.cbeg + c] : 0;
             }
         };
-        Meta m_cur = load_meta(reads[0]);
+        Meta m_cur = load_meta(sload(reads));
         Meta m_next = m_cur;
-        if (n > 1) m_next = load_meta(reads[1]);
-        uint32_t r_next2 = n > 2 ? reads[2] : 0;
+        if (n > 1) m_next = load_meta(sload(reads + 1));
+        uint32_t r_next2 = n > 2 ? sload(reads + 2) : 0;
         load_cells(m_cur);
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t cbeg = uni(m_cur.cbeg), L = uni(m_cur.L);
-            const uint32_t first_rel = uni(m_cur.first) - pos0;
-            const int32_t  last_rel = (int32_t)(uni(m_cur.last) - pos0);
-            const uint64_t tw1 = ((uint64_t)uni((uint32_t)(m_cur.tw1 >> 32)) << 32) | uni((uint32_t)m_cur.tw1);
-            const uint64_t tw2 = ((uint64_t)uni((uint32_t)(m_cur.tw2 >> 32)) << 32) | uni((uint32_t)m_cur.tw2);
+            const uint32_t cbeg = m_cur.cbeg, L = m_cur.L;
+            const uint32_t first_rel = m_cur.first - pos0;
+            const int32_t  last_rel = (int32_t)(m_cur.last - pos0);
+            const uint64_t tw1 = m_cur.tw1, tw2 = m_cur.tw2;
             // metadata of read i+2 is requested now and consumed two steps later
             Meta m_next2 = m_next;
-            if (i + 2 < n) m_next2 = load_meta(uni(r_next2));
-            if (i + 3 < n) r_next2 = reads[i + 3];
+            if (i + 2 < n) m_next2 = load_meta(r_next2);
+            if (i + 3 < n) r_next2 = sload(reads + i + 3);
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
             const uint32_t ntiles = (L + SLAB_TILE - 1) / SLAB_TILE;
             uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);
@@ -355,6 +355,7 @@ void beam_slab_kernel(BeamArgs g) {
                     ch2 = (st_h2[a] - ts2) + rk2 * (tw2 + (Q0 ? np2 : 0));
                 }
                 uint64_t passmask = __ballot(pass);
+                BEAM_TICK(7);
                 while (passmask) {
                     const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
                     passmask &= passmask - 1;
@@ -369,9 +370,9 @@ void beam_slab_kernel(BeamArgs g) {
                     H.push(s_s, id);
                     if (H.len > limit) evalid &= ~(1ull << H.pop());
                 }
+                BEAM_TICK(2);
             }
 
-            BEAM_TICK(2);
             // ---- M: survivors (lane j = heap slot j = next state j) and their slabs -----------------------------------
             const uint32_t nnext = H.len;
             const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;

@@ -51,6 +51,9 @@ struct BlockSet {
 
 // quality weight LUT (Q24), uploaded once per context
 __constant__ uint32_t c_w24[256];
+// per-partition multipliers of the linear state hash (a by-value kernel-argument array indexed by lane would be
+// copied to scratch)
+__constant__ uint64_t c_rk1[MAX_PLOIDY], c_rk2[MAX_PLOIDY];
 
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);

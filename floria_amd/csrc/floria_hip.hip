@@ -247,7 +247,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         {
             const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
             const uint64_t hist_stride = (uint64_t)fl::beam_hist_off(n_max, LM, B) + LM;
-            uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * 4 * FLORIA_FAST_WAVES;
+            const fl::SlabLds SL0 = fl::slab_lds_layout(LM, p, any_q0);
+            const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL0.total + 256)));
+            uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * FLORIA_FAST_WAVES, by_lds);
             slots = std::min(slots, n_jobs);
             const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
             while (slots > 1 && (state_bytes + hist_stride * 4) * slots > budget) slots /= 2;
@@ -261,7 +263,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
             const uint64_t* H = ctx->d_hash.as<uint64_t>();
             a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
-            memcpy(a.Rk1, ctx->Rk1, sizeof(a.Rk1)); memcpy(a.Rk2, ctx->Rk2, sizeof(a.Rk2));
             a.part_out = d_beam_part; a.min_margin_bits = d_margin; a.diag = d_diag; a.steps_done = d_steps;
             a.prof = (unsigned long long*)(d_diag + 4);
             const fl::BeamLds LY = fl::beam_lds_layout(LM);
@@ -381,6 +382,9 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(FLORIA_E_DEVICE, std::string("weight LUT upload: ") + hipGetErrorString(e)); }
     uint64_t s = 0xf10a1a2024ull;
     for (int k = 0; k < FLORIA_MAX_PLOIDY; ++k) { c->Rk1[k] = splitmix64(s) | 1ull; c->Rk2[k] = splitmix64(s) | 1ull; }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_rk1), c->Rk1, sizeof(c->Rk1));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_rk2), c->Rk2, sizeof(c->Rk2));
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(FLORIA_E_DEVICE, std::string("hash multiplier upload: ") + hipGetErrorString(e)); }
     if (int rc = ensure_hash(c, 4 * fl::HASH_M)) { (void)hipStreamDestroy(c->stream); delete c; return rc; }
     *out = c;
     return 0;
