@@ -293,9 +293,18 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         }
         // ---- optimise + MEC stats ----------------------------------------------------------------------------------
         {
-            uint32_t slots = std::min<uint32_t>((uint32_t)ctx->n_cu * 4, n_jobs);
             uint64_t cand_cap = 1;
             while (cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) cand_cap <<= 1;
+            const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
+            const uint32_t threads = mean_n >= 384 ? 1024 : (mean_n >= 96 ? 512 : 128);
+            const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
+            const size_t hist_bytes = (size_t)span_max * p * A * 8;
+            const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
+            const bool hl = hist_bytes + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
+            const size_t lds = moved_bytes + meta_bytes + (hl ? hist_bytes : 0) + 16;
+            uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads));
+            per_cu = std::min<uint32_t>(per_cu, 8);
+            const uint32_t slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, n_jobs);
             int rc = ctx->opt_hist.ensure((uint64_t)slots * span_max * p * A * 8); if (rc) return rc;
             rc = ctx->opt_dist.ensure((uint64_t)slots * n_max * p * 8); if (rc) return rc;
             rc = ctx->opt_gain.ensure((uint64_t)slots * cand_cap * 8); if (rc) return rc;
@@ -310,22 +319,18 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             a.moves_pool = ctx->opt_moves.as<uint32_t>(); a.cand_cap = cand_cap;
             a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
             a.prof = (unsigned long long*)(d_diag + 4);
-            const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
-            const size_t hist_bytes = (size_t)span_max * p * A * 8;
-            const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
-            const bool hl = hist_bytes + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
-            const size_t lds = moved_bytes + meta_bytes + (hl ? hist_bytes : 0) + 16;
-            slots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((156 * 1024) / (lds + 8 * 1024))));
-            if (lds > 48 * 1024) {
-                if (hl) HIPCHK(hipFuncSetAttribute((const void*)fl::optimize_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                else HIPCHK(hipFuncSetAttribute((const void*)fl::optimize_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            }
             HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
             int t = T.begin(K_OPT);
-            if (hl) hipLaunchKernelGGL((fl::optimize_kernel<A, true>), dim3(slots), dim3(fl::OPT_THREADS), lds, ctx->stream, a);
-            else hipLaunchKernelGGL((fl::optimize_kernel<A, false>), dim3(slots), dim3(fl::OPT_THREADS), lds, ctx->stream, a);
+            auto launch = [&](auto kern) -> hipError_t {
+                if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
+                hipLaunchKernelGGL(kern, dim3(slots), dim3(threads), lds, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t le;
+            if (hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
+            else    le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512>) : launch(fl::optimize_kernel<A, false, 128>);
             T.end(t);
-            HIPCHK(hipGetLastError());
+            if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));
             ctx->timing.optimize_launches++;
         }
         // ---- stop rule --------------------------------------------------------------------------------------------------

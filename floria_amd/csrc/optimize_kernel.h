@@ -17,7 +17,8 @@
 
 namespace fl {
 
-constexpr int OPT_THREADS = 256;
+// workgroup size is a template parameter (128 / 512 / 1024): one job's LDS histogram is shared by that many threads;
+// the host picks it from the batch's mean reads per block
 constexpr int OPT_SORT_LDS = 512;
 constexpr int OPT_META_MAX = 4096;        // reads per block whose (cell offset, length, partition) are staged in LDS        // candidates sorted in LDS up to this many
 constexpr int NUM_ITER_OPTIMIZE = 20;     // constants.rs:3
@@ -88,7 +89,7 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 
 // HL = the job's histogram slab lives in LDS (span_max*ploidy*A*8 bytes fit): distance loads, the build/move atomics and the
 // MEC reductions then never leave the CU; only the reads' cells stream from HBM/L2.
-template <int A, bool HL>
+template <int A, bool HL, int OPT_THREADS>
 __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
     __shared__ uint64_t s_gain[OPT_SORT_LDS];
