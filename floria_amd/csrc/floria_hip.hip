@@ -703,130 +703,185 @@ void floria_hip_block_result_free(floria_block_result* r) {
 }
 
 // ---- S2 --------------------------------------------------------------------------------------------------------
-int floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* c, const uint64_t* grp_off, const uint32_t* grp_read,
-                        const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
-    if (!ctx || !c || !out || (n_groups && (!grp_off || !grp_range))) return fail(FLORIA_E_INVALID, "null argument");
-    if (c->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
+// process_reads_for_final_parts for MANY contigs in one launch (one wavefront per contig): the reference calls it once
+// per contig from its serial contig loop (floria.rs:229,359-366); the chain is sequential inside a contig and independent
+// across contigs.
+int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
+                              const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
+                              const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups*** out) {
+    if (!ctx || !out || (n_contigs && !contigs) || (n_groups && (!grp_off || !grp_range))) return fail(FLORIA_E_INVALID, "null argument");
     *out = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->timing = floria_timing{};
-    const uint32_t N = c->n_reads;
-    const uint32_t A = c->n_alleles;
-    // read -> groups (part_block_manip.rs:185-193); groups are sets
-    std::vector<std::pair<uint32_t, uint32_t>> pairs;
-    std::vector<uint32_t> g_p0(n_groups, UINT32_MAX), g_p1(n_groups, 0);
-    for (uint32_t g = 0; g < n_groups; ++g)
-        for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
-            const uint32_t r = grp_read[i];
-            if (r >= N) return fail(FLORIA_E_INVALID, "group read id out of range");
-            pairs.push_back({r, g});
-            g_p0[g] = std::min(g_p0[g], c->h_first[r]); g_p1[g] = std::max(g_p1[g], c->h_last[r]);
-        }
-    std::sort(pairs.begin(), pairs.end());
-    pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
-    std::vector<uint64_t> r2g_off(N + 1, 0), hist_off(n_groups + 1, 0);
-    std::vector<uint32_t> r2g(pairs.size());
-    for (auto& pr : pairs) r2g_off[pr.first + 1]++;
-    for (uint32_t r = 0; r < N; ++r) r2g_off[r + 1] += r2g_off[r];
-    for (size_t i = 0; i < pairs.size(); ++i) r2g[i] = pairs[i].second;
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        const uint64_t w = g_p0[g] == UINT32_MAX ? 0 : (uint64_t)(g_p1[g] - g_p0[g] + 1) * A;
-        hist_off[g + 1] = hist_off[g] + w;
-        if (g_p0[g] == UINT32_MAX) g_p0[g] = 0;
+    uint32_t A = 2;
+    for (uint32_t i = 0; i < n_contigs; ++i) {
+        if (!contigs[i] || contigs[i]->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
+        A = std::max(A, contigs[i]->n_alleles);
     }
-    std::vector<int32_t> assign(N, -1);
-    if (N && n_groups) {
+    // groups of each contig, in input order (contig-local group id = rank among the contig's groups)
+    std::vector<std::vector<uint32_t>> cg(n_contigs);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t ci = grp_contig ? grp_contig[g] : 0;
+        if (ci >= n_contigs) return fail(FLORIA_E_INVALID, "grp_contig out of range");
+        cg[ci].push_back(g);
+    }
+    std::vector<uint64_t> r2g_off_base(n_contigs), r2g_base(n_contigs), grp_base(n_contigs), assign_base(n_contigs);
+    std::vector<uint64_t> r2g_off_all, hist_off_all;
+    std::vector<uint32_t> r2g_all, gpos0_all;
+    std::vector<fl::ContigDev> cdev(n_contigs);
+    uint64_t hist_cells = 0, n_assign = 0;
+    for (uint32_t ci = 0; ci < n_contigs; ++ci) {
+        const floria_hip_contig* c = contigs[ci];
+        cdev[ci] = c->dev;
+        const uint32_t N = c->n_reads;
+        std::vector<std::pair<uint32_t, uint32_t>> pairs;                      // (read, local group): read -> groups, part_block_manip.rs:185-193
+        std::vector<uint32_t> p0(cg[ci].size(), UINT32_MAX), p1(cg[ci].size(), 0);
+        for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
+            const uint32_t g = cg[ci][lg];
+            for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
+                const uint32_t r = grp_read[i];
+                if (r >= N) return fail(FLORIA_E_INVALID, "group read id out of range");
+                pairs.push_back({r, lg});
+                p0[lg] = std::min(p0[lg], c->h_first[r]); p1[lg] = std::max(p1[lg], c->h_last[r]);
+            }
+        }
+        std::sort(pairs.begin(), pairs.end());
+        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());       // groups are sets
+        r2g_off_base[ci] = r2g_off_all.size(); r2g_base[ci] = r2g_all.size(); grp_base[ci] = gpos0_all.size(); assign_base[ci] = n_assign;
+        std::vector<uint64_t> off(N + 1, 0);
+        for (auto& pr : pairs) off[pr.first + 1]++;
+        for (uint32_t r = 0; r < N; ++r) off[r + 1] += off[r];
+        r2g_off_all.insert(r2g_off_all.end(), off.begin(), off.end());
+        for (auto& pr : pairs) r2g_all.push_back(pr.second);
+        for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
+            hist_off_all.push_back(hist_cells);
+            gpos0_all.push_back(p0[lg] == UINT32_MAX ? 0 : p0[lg]);
+            hist_cells += p0[lg] == UINT32_MAX ? 0 : (uint64_t)(p1[lg] - p0[lg] + 1) * A;
+        }
+        n_assign += N;
+    }
+    std::vector<int32_t> assign(n_assign, -1);
+    if (n_assign && n_groups) {
         struct Seg { size_t off, bytes; };
         size_t cursor = 0;
         auto seg = [&](size_t bytes) { Seg s{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return s; };
-        Seg s_cd = seg(sizeof(fl::ContigDev)), s_ro = seg(8ull * (N + 1)), s_r2g = seg(4ull * r2g.size() + 4), s_ho = seg(8ull * (n_groups + 1)),
-            s_p0 = seg(4ull * n_groups + 4), s_hist = seg(8ull * hist_off[n_groups] + 8), s_as = seg(4ull * N + 4), s_zero = seg(64), s_q = seg(16);
+        const Seg s_cd = seg(sizeof(fl::ContigDev) * n_contigs), s_rob = seg(8ull * n_contigs), s_rb = seg(8ull * n_contigs), s_gb = seg(8ull * n_contigs),
+                  s_ab = seg(8ull * n_contigs), s_ro = seg(8ull * r2g_off_all.size() + 8), s_r2g = seg(4ull * r2g_all.size() + 4),
+                  s_ho = seg(8ull * hist_off_all.size() + 8), s_p0 = seg(4ull * gpos0_all.size() + 4), s_hist = seg(8ull * hist_cells + 8),
+                  s_as = seg(4ull * n_assign + 4), s_q = seg(16);
         int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
         char* M = ctx->misc.as<char>();
         EventTimer T(ctx->stream);
         int th = T.begin(K_H2D);
-        HIPCHK(hipMemcpyAsync(M + s_cd.off, &c->dev, sizeof(fl::ContigDev), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(M + s_ro.off, r2g_off.data(), 8ull * (N + 1), hipMemcpyHostToDevice, ctx->stream));
-        if (!r2g.empty()) HIPCHK(hipMemcpyAsync(M + s_r2g.off, r2g.data(), 4ull * r2g.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(M + s_ho.off, hist_off.data(), 8ull * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(M + s_p0.off, g_p0.data(), 4ull * n_groups, hipMemcpyHostToDevice, ctx->stream));
+        auto h2d = [&](Seg sg, const void* src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(M + sg.off, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; };
+        HIPCHK(h2d(s_cd, cdev.data(), sizeof(fl::ContigDev) * n_contigs));
+        HIPCHK(h2d(s_rob, r2g_off_base.data(), 8ull * n_contigs)); HIPCHK(h2d(s_rb, r2g_base.data(), 8ull * n_contigs));
+        HIPCHK(h2d(s_gb, grp_base.data(), 8ull * n_contigs)); HIPCHK(h2d(s_ab, assign_base.data(), 8ull * n_contigs));
+        HIPCHK(h2d(s_ro, r2g_off_all.data(), 8ull * r2g_off_all.size())); HIPCHK(h2d(s_r2g, r2g_all.data(), 4ull * r2g_all.size()));
+        HIPCHK(h2d(s_ho, hist_off_all.data(), 8ull * hist_off_all.size())); HIPCHK(h2d(s_p0, gpos0_all.data(), 4ull * gpos0_all.size()));
         HIPCHK(hipMemsetAsync(M + s_hist.off, 0, s_hist.bytes, ctx->stream));
-        HIPCHK(hipMemsetAsync(M + s_zero.off, 0, 64, ctx->stream));
         HIPCHK(hipMemsetAsync(M + s_q.off, 0, 16, ctx->stream));
         T.end(th);
         fl::ReassignArgs a{};
-        a.contigs = (const fl::ContigDev*)(M + s_cd.off); a.n_contigs = 1;
-        a.r2g_off_base = (const uint64_t*)(M + s_zero.off); a.r2g_off = (const uint64_t*)(M + s_ro.off);
-        a.r2g_base = (const uint64_t*)(M + s_zero.off); a.r2g = (const uint32_t*)(M + s_r2g.off);
-        a.grp_base = (const uint64_t*)(M + s_zero.off); a.grp_hist_off = (const uint64_t*)(M + s_ho.off); a.grp_pos0 = (const uint32_t*)(M + s_p0.off);
-        a.hist = (uint64_t*)(M + s_hist.off); a.assign = (int32_t*)(M + s_as.off); a.assign_base = (const uint64_t*)(M + s_zero.off);
+        a.contigs = (const fl::ContigDev*)(M + s_cd.off); a.n_contigs = n_contigs;
+        a.r2g_off_base = (const uint64_t*)(M + s_rob.off); a.r2g_off = (const uint64_t*)(M + s_ro.off);
+        a.r2g_base = (const uint64_t*)(M + s_rb.off); a.r2g = (const uint32_t*)(M + s_r2g.off);
+        a.grp_base = (const uint64_t*)(M + s_gb.off); a.grp_hist_off = (const uint64_t*)(M + s_ho.off); a.grp_pos0 = (const uint32_t*)(M + s_p0.off);
+        a.hist = (uint64_t*)(M + s_hist.off); a.assign = (int32_t*)(M + s_as.off); a.assign_base = (const uint64_t*)(M + s_ab.off);
         a.eps = epsilon; a.queue_head = (uint32_t*)(M + s_q.off);
+        const uint32_t grid = std::min<uint32_t>(n_contigs, (uint32_t)ctx->n_cu * 16);
         int tk = T.begin(K_REASSIGN);
-        if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(1), dim3(64), 0, ctx->stream, a);
+        if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
         T.end(tk);
         HIPCHK(hipGetLastError());
         int td = T.begin(K_D2H);
-        HIPCHK(hipMemcpyAsync(assign.data(), M + s_as.off, 4ull * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(assign.data(), M + s_as.off, 4ull * n_assign, hipMemcpyDeviceToHost, ctx->stream));
         T.end(td);
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->timing.reassign_ms = T.sum(K_REASSIGN); ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
     }
-    // ---- host bookkeeping: rebuild groups, separate_broken_haplogroups (:27-98), sort_parts (:276-288) ----------
-    std::vector<std::vector<uint32_t>> parts(n_groups);
-    std::vector<std::pair<uint32_t, uint32_t>> ranges(n_groups);
-    for (uint32_t g = 0; g < n_groups; ++g) ranges[g] = {grp_range[2 * g], grp_range[2 * g + 1]};
-    for (uint32_t r = 0; r < N; ++r) if (assign[r] >= 0) parts[assign[r]].push_back(r);       // ascending id
-    {
-        const auto& F = c->h_first; const auto& L = c->h_last;
-        std::vector<std::pair<size_t, std::vector<uint32_t>>> all_breaks;
-        const size_t n0 = ranges.size();
-        for (size_t i = 0; i < n0; ++i) {
-            uint32_t latest = 0;
-            std::vector<uint32_t> breaks;
-            for (uint32_t r : parts[i]) {                                // sorted by first_position (ids ascend)
-                if (latest != 0 && F[r] > latest && latest >= ranges[i].first && latest < ranges[i].second) breaks.push_back(latest);
-                if (L[r] > latest) latest = L[r];
-            }
-            if (!breaks.empty()) all_breaks.push_back({i, std::move(breaks)});
-        }
-        std::vector<std::vector<uint32_t>> new_parts;
-        std::vector<std::pair<uint32_t, uint32_t>> new_ranges;
-        for (auto& bi : all_breaks) {
-            size_t spot = 0;
-            uint32_t break_start = ranges[bi.first].first, end_spot = bi.second[0];
-            std::vector<uint32_t> np;
-            for (uint32_t r : parts[bi.first]) {
-                if (L[r] <= end_spot) np.push_back(r);
-                else {                                                   // :69-84: this read is not re-inserted
-                    new_parts.push_back(std::move(np)); np.clear();
-                    new_ranges.push_back({break_start, end_spot});
-                    break_start = end_spot + 1;
-                    ++spot;
-                    end_spot = spot != bi.second.size() ? bi.second[spot] : UINT32_MAX;
+    // ---- host bookkeeping per contig: rebuild groups, separate_broken_haplogroups (:27-98), sort_parts (:276-288) ----
+    floria_groups** arr = (floria_groups**)calloc(std::max(1u, n_contigs), sizeof(floria_groups*));
+    if (!arr) return fail(FLORIA_E_NOMEM, "calloc");
+    for (uint32_t ci = 0; ci < n_contigs; ++ci) {
+        const floria_hip_contig* c = contigs[ci];
+        const uint32_t N = c->n_reads, ng = (uint32_t)cg[ci].size();
+        std::vector<std::vector<uint32_t>> parts(ng);
+        std::vector<std::pair<uint32_t, uint32_t>> ranges(ng);
+        for (uint32_t lg = 0; lg < ng; ++lg) ranges[lg] = {grp_range[2 * cg[ci][lg]], grp_range[2 * cg[ci][lg] + 1]};
+        const int32_t* as = assign.data() + assign_base[ci];
+        for (uint32_t r = 0; r < N; ++r) if (as[r] >= 0) parts[as[r]].push_back(r);       // ascending id
+        {
+            const auto& F = c->h_first; const auto& L = c->h_last;
+            std::vector<std::pair<size_t, std::vector<uint32_t>>> all_breaks;
+            const size_t n0 = ranges.size();
+            for (size_t i = 0; i < n0; ++i) {
+                uint32_t latest = 0;
+                std::vector<uint32_t> breaks;
+                for (uint32_t r : parts[i]) {                                // sorted by first_position (ids ascend)
+                    if (latest != 0 && F[r] > latest && latest >= ranges[i].first && latest < ranges[i].second) breaks.push_back(latest);
+                    if (L[r] > latest) latest = L[r];
                 }
+                if (!breaks.empty()) all_breaks.push_back({i, std::move(breaks)});
             }
-            new_parts.push_back(std::move(np));
-            new_ranges.push_back({break_start, ranges[bi.first].second});
+            std::vector<std::vector<uint32_t>> new_parts;
+            std::vector<std::pair<uint32_t, uint32_t>> new_ranges;
+            for (auto& bi : all_breaks) {
+                size_t spot = 0;
+                uint32_t break_start = ranges[bi.first].first, end_spot = bi.second[0];
+                std::vector<uint32_t> np;
+                for (uint32_t r : parts[bi.first]) {
+                    if (L[r] <= end_spot) np.push_back(r);
+                    else {                                                   // :69-84: this read is not re-inserted
+                        new_parts.push_back(std::move(np)); np.clear();
+                        new_ranges.push_back({break_start, end_spot});
+                        break_start = end_spot + 1;
+                        ++spot;
+                        end_spot = spot != bi.second.size() ? bi.second[spot] : UINT32_MAX;
+                    }
+                }
+                new_parts.push_back(std::move(np));
+                new_ranges.push_back({break_start, ranges[bi.first].second});
+            }
+            for (auto& bi : all_breaks) parts[bi.first].clear();
+            for (size_t i = 0; i < new_parts.size(); ++i) { parts.push_back(std::move(new_parts[i])); ranges.push_back(new_ranges[i]); }
         }
-        for (auto& bi : all_breaks) parts[bi.first].clear();
-        for (size_t i = 0; i < new_parts.size(); ++i) { parts.push_back(std::move(new_parts[i])); ranges.push_back(new_ranges[i]); }
+        std::vector<size_t> idx(parts.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return ranges[x] < ranges[y]; });
+        floria_groups* G = (floria_groups*)calloc(1, sizeof(floria_groups));
+        if (!G) { floria_hip_groups_array_free(arr, n_contigs); return fail(FLORIA_E_NOMEM, "calloc"); }
+        arr[ci] = G;
+        G->n_groups = (uint32_t)parts.size();
+        G->grp_off = (uint64_t*)calloc(parts.size() + 1, 8);
+        G->range = (uint32_t*)calloc(2 * parts.size() + 2, 4);
+        uint64_t tot = 0;
+        for (size_t k = 0; k < idx.size(); ++k) { G->grp_off[k] = tot; tot += parts[idx[k]].size(); G->range[2 * k] = ranges[idx[k]].first; G->range[2 * k + 1] = ranges[idx[k]].second; }
+        G->grp_off[idx.size()] = tot;
+        G->grp_read = (uint32_t*)malloc(4 * (tot + 1));
+        for (size_t k = 0; k < idx.size(); ++k) std::copy(parts[idx[k]].begin(), parts[idx[k]].end(), G->grp_read + G->grp_off[k]);
     }
-    std::vector<size_t> idx(parts.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ranges[a] < ranges[b]; });
-    floria_groups* G = (floria_groups*)calloc(1, sizeof(floria_groups));
-    if (!G) return fail(FLORIA_E_NOMEM, "calloc");
-    G->n_groups = (uint32_t)parts.size();
-    G->grp_off = (uint64_t*)calloc(parts.size() + 1, 8);
-    G->range = (uint32_t*)calloc(2 * parts.size() + 2, 4);
-    uint64_t tot = 0;
-    for (size_t k = 0; k < idx.size(); ++k) { G->grp_off[k] = tot; tot += parts[idx[k]].size(); G->range[2 * k] = ranges[idx[k]].first; G->range[2 * k + 1] = ranges[idx[k]].second; }
-    G->grp_off[idx.size()] = tot;
-    G->grp_read = (uint32_t*)malloc(4 * (tot + 1));
-    for (size_t k = 0; k < idx.size(); ++k) std::copy(parts[idx[k]].begin(), parts[idx[k]].end(), G->grp_read + G->grp_off[k]);
-    *out = G;
+    *out = arr;
     return 0;
+}
+
+int floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* c, const uint64_t* grp_off, const uint32_t* grp_read,
+                        const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
+    if (!c || !out) return fail(FLORIA_E_INVALID, "null argument");
+    *out = nullptr;
+    const floria_hip_contig* arr[1] = {c};
+    floria_groups** res = nullptr;
+    int rc = floria_hip_reassign_batch(ctx, arr, 1, nullptr, grp_off, grp_read, grp_range, n_groups, epsilon, &res);
+    if (rc) return rc;
+    *out = res[0];
+    free(res);
+    return 0;
+}
+void floria_hip_groups_array_free(floria_groups** arr, uint32_t n) {
+    if (!arr) return;
+    for (uint32_t i = 0; i < n; ++i) floria_hip_groups_free(arr[i]);
+    free(arr);
 }
 void floria_hip_groups_free(floria_groups* g) { if (g) { free(g->grp_off); free(g->grp_read); free(g->range); free(g); } }
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "floria_hip_block_ranges", "floria_hip_ranges_free", "floria_hip_contig_upload", "floria_hip_contig_free",
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
-    "floria_hip_set_slots",
+    "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
 ]
 
 
@@ -50,7 +50,8 @@ def load():
         L = C.CDLL(_SO)
         L.floria_hip_last_error.restype = C.c_char_p
         L.floria_hip_version.restype = C.c_char_p
-        for s in ("floria_hip_destroy", "floria_hip_ranges_free", "floria_hip_contig_free", "floria_hip_block_result_free", "floria_hip_groups_free"):
+        for s in ("floria_hip_destroy", "floria_hip_ranges_free", "floria_hip_contig_free", "floria_hip_block_result_free", "floria_hip_groups_free",
+                  "floria_hip_groups_array_free"):
             getattr(L, s).restype = None
         L.floria_hip_destroy.argtypes = [C.c_void_p]
         L.floria_hip_contig_free.argtypes = [C.c_void_p]
@@ -167,6 +168,22 @@ class FloriaHip:
         return res
 
     # S2 --------------------------------------------------------------------------------------------
+    def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon):
+        """process_reads_for_final_parts for many resident contigs in one launch -> list of _capi.Groups (contig order)."""
+        arr = (C.c_void_p * len(contigs))(*[c._h for c in contigs])
+        gc = np.ascontiguousarray(grp_contig, np.uint32)
+        off = np.zeros(len(groups) + 1, np.uint64)
+        off[1:] = np.cumsum([len(g) for g in groups])
+        reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
+        rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+        out = C.POINTER(C.POINTER(capi.CGroups))()
+        _check(load().floria_hip_reassign_batch(self._h, arr, C.c_uint32(len(contigs)), capi.ptr(gc, C.c_uint32), capi.ptr(off, C.c_uint64),
+                                                capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), C.c_double(epsilon),
+                                                C.byref(out)))
+        res = [capi.Groups(out[i].contents) for i in range(len(contigs))]
+        load().floria_hip_groups_array_free(out, C.c_uint32(len(contigs)))
+        return res
+
     def reassign(self, contig, groups, ranges, epsilon):
         """process_reads_for_final_parts (part_block_manip.rs:174-274): groups = list of read-id arrays,
         ranges = [(start,end)] -> _capi.Groups"""

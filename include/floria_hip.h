@@ -169,6 +169,13 @@ int  floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* contig,
                          floria_groups** out);
 void floria_hip_groups_free(floria_groups* g);
 
+/* S2 for many contigs in one launch (one wavefront per contig; the chain is sequential inside a contig and independent
+ * across contigs).  grp_contig[g] indexes `contigs`; *out is an array of n_contigs floria_groups* in contig order. */
+int  floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
+                               const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
+                               const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups*** out);
+void floria_hip_groups_array_free(floria_groups** arr, uint32_t n_contigs);
+
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */

@@ -181,3 +181,25 @@ def test_reassign_with_coverage_gap_splits_group(gpu_ctx, hip_lib, oracle_mod):
     gg = gpu_ctx.reassign(pile, groups, ranges, EPS)
     assert np.array_equal(go.range, gg.range) and np.array_equal(go.grp_off, gg.grp_off) and np.array_equal(go.grp_read, gg.grp_read)
     assert gg.n_groups >= 3        # group (1,10) is split at the coverage break after SNP 4
+
+
+def test_reassign_batch_equals_per_contig_oracle(gpu_ctx, hip_lib, oracle_mod):
+    # S2 for several contigs in one launch == the oracle called contig by contig (floria.rs:229,359-366)
+    contigs = [synth.make_config_contig(4, i, 0.4) for i in range(5)]
+    res = [gpu_ctx.upload(c.pileup) for c in contigs]
+    par = hip_lib.make_params(EPS)
+    all_groups, all_ranges, gc, per = [], [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+        r = gpu_ctx.phase_blocks(res[i], s, e, par)
+        g, rg = groups_from_blocks(r, s, e)
+        per.append((g, rg))
+        all_groups += g; all_ranges += rg; gc += [i] * len(g)
+    out = gpu_ctx.reassign_batch(res, gc, all_groups, all_ranges, EPS)
+    assert len(out) == len(contigs)
+    for i, c in enumerate(contigs):
+        go = oracle_mod.reassign(c.pileup, per[i][0], per[i][1], EPS)
+        assert go.n_groups == out[i].n_groups
+        assert np.array_equal(go.range, out[i].range) and np.array_equal(go.grp_off, out[i].grp_off) and np.array_equal(go.grp_read, out[i].grp_read)
+    for r in res:
+        r.free()
