@@ -30,7 +30,14 @@ class CParams(C.Structure):
 class CBlockResult(C.Structure):
     _fields_ = [("n_blocks", C.c_uint32), ("max_ploidy", C.c_uint32), ("best_ploidy", u32p),
                 ("ploidies_tried", u32p), ("read_off", u64p), ("read_id", u32p), ("part", u8p),
-                ("mec", f64p), ("min_prune_margin", C.c_double)]
+                ("mec", f64p), ("min_prune_margin", C.c_double), ("batch_token", C.c_uint64)]
+
+
+i32p = C.POINTER(C.c_int32)
+
+
+class CHapGraph(C.Structure):
+    _fields_ = [("n_blocks", C.c_uint32), ("node_off", u64p), ("node_cov", f64p), ("pred", i32p), ("edge_off", u64p), ("edge_w", u32p)]
 
 
 class CGroups(C.Structure):
@@ -75,6 +82,7 @@ class BlockResult:
         self.part = np_from(c.part, tot, np.uint8)
         self.mec = np_from(c.mec, nb * mp, np.float64).reshape(nb, mp)
         self.min_prune_margin = float(c.min_prune_margin)
+        self.batch_token = int(c.batch_token)
 
     def block(self, b):
         lo, hi = int(self.read_off[b]), int(self.read_off[b + 1])
@@ -84,6 +92,17 @@ class BlockResult:
         """List of read-id arrays, one per haplotype (the `Vec<FxHashSet<&Frag>>` of the reference)."""
         ids, part = self.block(b)
         return [ids[part == k] for k in range(int(self.best_ploidy[b]))]
+
+
+class HapGraph:
+    def __init__(self, c):
+        nb = c.n_blocks
+        self.n_blocks = nb
+        self.node_off = np_from(c.node_off, nb + 1, np.uint64)
+        self.node_cov = np_from(c.node_cov, int(self.node_off[nb]) if nb else 0, np.float64)
+        self.pred = np_from(c.pred, nb, np.int32)
+        self.edge_off = np_from(c.edge_off, nb + 1, np.uint64)
+        self.edge_w = np_from(c.edge_w, int(self.edge_off[nb]) if nb else 0, np.uint32)
 
 
 class Groups:

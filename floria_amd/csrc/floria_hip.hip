@@ -30,6 +30,7 @@
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
 #include "blocks_kernel.h"
+#include "graph_kernel.h"
 
 static_assert(FLORIA_MAX_PLOIDY == fl::MAX_PLOIDY, "ploidy limits out of sync");
 
@@ -92,6 +93,14 @@ struct floria_hip_ctx {
     // scratch pools
     DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
     floria_timing timing{};
+    // device-resident copy of the last S1 batch (floria_hip_hap_graph)
+    uint64_t batch_token = 0, token_counter = 0;
+    fl::BlockSet last_bs{};
+    const uint8_t* last_part = nullptr;
+    const uint32_t* last_best = nullptr;
+    uint32_t last_nall = 2;
+    std::vector<uint32_t> last_bc, last_start, last_end;
+    DevBuf graph_buf, graph_hist, graph_sort;
 };
 
 struct floria_hip_contig {
@@ -399,7 +408,7 @@ void floria_hip_destroy(floria_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0}) b->release();
+    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0, &c->graph_buf, &c->graph_hist, &c->graph_sort}) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -516,6 +525,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     if (!(prm->epsilon > 0.0 && prm->epsilon < 1.0)) return fail(FLORIA_E_INVALID, "epsilon must be in (0,1)");
     HIPCHK(hipSetDevice(ctx->device));
     ctx->timing = floria_timing{};
+    ctx->batch_token = 0;
     const uint32_t P = prm->max_ploidy;
 
     // ---- block read lists: find_reads_in_interval on the device (blocks_kernel.h) -------------------------------
@@ -675,6 +685,9 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
     ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
     for (uint32_t b = 0; b < n_blocks; ++b) { ctx->timing.beam_launch_bytes += blk_bytes[b] * R->ploidies_tried[b]; ctx->timing.jobs += R->ploidies_tried[b]; }
+    ctx->batch_token = R->batch_token = ++ctx->token_counter;
+    ctx->last_bs = bs; ctx->last_part = (const uint8_t*)(M + s_out.off); ctx->last_best = (const uint32_t*)(M + s_best.off); ctx->last_nall = nall;
+    ctx->last_bc = bc; ctx->last_start.assign(blk_start, blk_start + n_blocks); ctx->last_end.assign(blk_end, blk_end + n_blocks);
     *out = R;
     return 0;
 }
@@ -702,6 +715,84 @@ void floria_hip_block_result_free(floria_block_result* r) {
     free(r->best_ploidy); free(r->ploidies_tried); free(r->read_off); free(r->read_id); free(r->part); free(r->mec); free(r);
 }
 
+// ---- hap-graph nodes + edges on the resident batch ------------------------------------------------
+int floria_hip_hap_graph(floria_hip_ctx* ctx, const floria_block_result* res, floria_hap_graph** out) {
+    if (!ctx || !res || !out) return fail(FLORIA_E_INVALID, "null argument");
+    *out = nullptr;
+    if (!ctx->batch_token || res->batch_token != ctx->batch_token) return fail(FLORIA_E_INVALID, "the batch is no longer resident: call floria_hip_hap_graph directly after phase_blocks");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t nb = res->n_blocks;
+    floria_hap_graph* G = (floria_hap_graph*)calloc(1, sizeof(floria_hap_graph));
+    if (!G) return fail(FLORIA_E_NOMEM, "calloc");
+    G->n_blocks = nb;
+    G->node_off = (uint64_t*)calloc(nb + 1, 8); G->edge_off = (uint64_t*)calloc(nb + 1, 8); G->pred = (int32_t*)calloc(nb + 1, 4);
+    uint32_t range_max = 1, pmax = 1;
+    {
+        std::vector<int32_t> last_of_contig;                    // process_chunks: columns = non-empty blocks in block order (graph_processing.rs:306-323)
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t ci = ctx->last_bc[b];
+            if (ci >= last_of_contig.size()) last_of_contig.resize(ci + 1, -1);
+            const uint32_t p2 = res->best_ploidy[b];
+            G->pred[b] = -1;
+            G->node_off[b + 1] = G->node_off[b] + p2;
+            G->edge_off[b + 1] = G->edge_off[b];
+            if (p2) {
+                G->pred[b] = last_of_contig[ci];
+                if (G->pred[b] >= 0) G->edge_off[b + 1] += (uint64_t)res->best_ploidy[G->pred[b]] * p2;
+                last_of_contig[ci] = (int32_t)b;
+                range_max = std::max(range_max, ctx->last_end[b] - ctx->last_start[b] + 1);
+                pmax = std::max(pmax, p2);
+            }
+        }
+    }
+    const uint64_t n_nodes = G->node_off[nb], n_edges = G->edge_off[nb];
+    G->node_cov = (double*)calloc(n_nodes + 1, 8); G->edge_w = (uint32_t*)calloc(n_edges + 1, 4);
+    if (!G->node_off || !G->edge_off || !G->pred || !G->node_cov || !G->edge_w) { floria_hip_hap_graph_free(G); return fail(FLORIA_E_NOMEM, "calloc"); }
+    if (nb == 0) { *out = G; return 0; }
+    const uint32_t A = ctx->last_nall;
+    struct Seg { size_t off, bytes; };
+    size_t cursor = 0;
+    auto seg = [&](size_t bytes) { Seg sg{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return sg; };
+    const Seg s_pred = seg(4ull * nb), s_noff = seg(8ull * (nb + 1)), s_eoff = seg(8ull * (nb + 1)), s_cov = seg(8ull * n_nodes + 8), s_ew = seg(4ull * n_edges + 4);
+    int rc = ctx->graph_buf.ensure(cursor + 256);
+    const size_t hist_bytes = (size_t)range_max * pmax * A * 8;
+    const bool in_lds = hist_bytes <= 40 * 1024;
+    uint64_t sort_cap = 1;
+    while (sort_cap < (uint64_t)range_max * A) sort_cap <<= 1;
+    if (!rc && !in_lds) rc = ctx->graph_hist.ensure((uint64_t)nb * hist_bytes);
+    if (!rc && (uint64_t)range_max * A > (uint64_t)fl::GRAPH_SORT_CAP) rc = ctx->graph_sort.ensure((uint64_t)nb * sort_cap * 8);
+    if (rc) { floria_hip_hap_graph_free(G); return rc; }
+    char* B = ctx->graph_buf.as<char>();
+    hipError_t e = hipMemcpyAsync(B + s_pred.off, G->pred, 4ull * nb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(B + s_noff.off, G->node_off, 8ull * (nb + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(B + s_eoff.off, G->edge_off, 8ull * (nb + 1), hipMemcpyHostToDevice, ctx->stream);
+    fl::GraphArgs a{};
+    a.bs = ctx->last_bs; a.best_ploidy = ctx->last_best; a.part = ctx->last_part;
+    a.pred = (const int32_t*)(B + s_pred.off); a.node_off = (const uint64_t*)(B + s_noff.off); a.edge_off = (const uint64_t*)(B + s_eoff.off);
+    a.node_cov = (double*)(B + s_cov.off); a.edge_w = (uint32_t*)(B + s_ew.off);
+    a.hist_pool = ctx->graph_hist.as<uint64_t>(); a.sort_pool = ctx->graph_sort.as<uint64_t>(); a.sort_cap = sort_cap;
+    a.range_max = range_max; a.hist_in_lds = in_lds ? 1 : 0; a.hist_stride = hist_bytes / 8;
+    EventTimer T(ctx->stream);
+    int tk = T.begin(K_SEL);
+    if (e == hipSuccess) {
+        if (A == 2) hipLaunchKernelGGL(fl::graph_kernel<2>, dim3(nb), dim3(fl::GRAPH_THREADS), in_lds ? hist_bytes : 0, ctx->stream, a);
+        else hipLaunchKernelGGL(fl::graph_kernel<4>, dim3(nb), dim3(fl::GRAPH_THREADS), in_lds ? hist_bytes : 0, ctx->stream, a);
+        e = hipGetLastError();
+    }
+    T.end(tk);
+    if (e == hipSuccess && n_nodes) e = hipMemcpyAsync(G->node_cov, B + s_cov.off, 8ull * n_nodes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && n_edges) e = hipMemcpyAsync(G->edge_w, B + s_ew.off, 4ull * n_edges, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { floria_hip_hap_graph_free(G); return fail(FLORIA_E_DEVICE, std::string("hap_graph: ") + hipGetErrorString(e)); }
+    ctx->timing.select_ms = T.sum(K_SEL);
+    *out = G;
+    return 0;
+}
+void floria_hip_hap_graph_free(floria_hap_graph* g) {
+    if (!g) return;
+    free(g->node_off); free(g->node_cov); free(g->pred); free(g->edge_off); free(g->edge_w); free(g);
+}
+
 // ---- S2 --------------------------------------------------------------------------------------------------------
 // process_reads_for_final_parts for MANY contigs in one launch (one wavefront per contig): the reference calls it once
 // per contig from its serial contig loop (floria.rs:229,359-366); the chain is sequential inside a contig and independent
@@ -713,6 +804,7 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
     *out = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->timing = floria_timing{};
+    ctx->batch_token = 0;                      // misc is about to be overwritten
     uint32_t A = 2;
     for (uint32_t i = 0; i < n_contigs; ++i) {
         if (!contigs[i] || contigs[i]->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");

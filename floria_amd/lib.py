@@ -24,6 +24,7 @@ SYMBOLS = [
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
     "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
+    "floria_hip_hap_graph", "floria_hip_hap_graph_free",
 ]
 
 
@@ -51,7 +52,7 @@ def load():
         L.floria_hip_last_error.restype = C.c_char_p
         L.floria_hip_version.restype = C.c_char_p
         for s in ("floria_hip_destroy", "floria_hip_ranges_free", "floria_hip_contig_free", "floria_hip_block_result_free", "floria_hip_groups_free",
-                  "floria_hip_groups_array_free"):
+                  "floria_hip_groups_array_free", "floria_hip_hap_graph_free"):
             getattr(L, s).restype = None
         L.floria_hip_destroy.argtypes = [C.c_void_p]
         L.floria_hip_contig_free.argtypes = [C.c_void_p]
@@ -166,6 +167,18 @@ class FloriaHip:
         res = capi.BlockResult(out.contents) if copy_out else None
         load().floria_hip_block_result_free(out)
         return res
+
+    def hap_graph(self, res):
+        """HapNode::new coverage + update_hap_graph out_weights (graph_processing.rs:22-100) for the batch that produced
+        `res`; must directly follow the phase_blocks* call on this context (the batch is still resident in HBM)."""
+        bp = np.ascontiguousarray(res.best_ploidy, np.uint32)
+        c = capi.CBlockResult()
+        c.n_blocks = res.n_blocks; c.max_ploidy = res.max_ploidy; c.best_ploidy = capi.ptr(bp, C.c_uint32); c.batch_token = res.batch_token
+        out = C.POINTER(capi.CHapGraph)()
+        _check(load().floria_hip_hap_graph(self._h, C.byref(c), C.byref(out)))
+        g = capi.HapGraph(out.contents)
+        load().floria_hip_hap_graph_free(out)
+        return g
 
     # S2 --------------------------------------------------------------------------------------------
     def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon):

@@ -86,7 +86,20 @@ typedef struct {
     double*   mec;             /* [n_blocks*max_ploidy] */
     double    min_prune_margin;/* min |p_k - lse - ln(PROB_CUTOFF)| over all pruning decisions
                                   (global_clustering.rs:98); parity certificate, see DESIGN.md */
+    uint64_t  batch_token;     /* identifies the device-resident copy of this batch (floria_hip_hap_graph) */
 } floria_block_result;
+
+/* Hap-graph columns of the batch: HapNode::new's coverage statistic (types_structs.rs:179-193) for
+ * every node (block b has best_ploidy[b] nodes) and update_hap_graph's out_weights (graph_processing.rs:28-47) for every
+ * consecutive pair of non-empty blocks of a contig, BEFORE the >= MIN_SHARED_READS_UNAMBIG (2.0) filter of :51. */
+typedef struct {
+    uint32_t  n_blocks;
+    uint64_t* node_off;        /* [n_blocks+1] */
+    double*   node_cov;        /* [node_off[n_blocks]] */
+    int32_t*  pred;            /* [n_blocks] previous non-empty block of the same contig, -1 if none */
+    uint64_t* edge_off;        /* [n_blocks+1]; block b holds best_ploidy[pred[b]] x best_ploidy[b] counts, row-major */
+    uint32_t* edge_w;          /* [edge_off[n_blocks]] */
+} floria_hap_graph;
 
 /* Haplogroups (S2 in/out): group g holds reads grp_read[grp_off[g]..grp_off[g+1]) and spans the
  * inclusive SNP range (range[2g], range[2g+1]).  Output groups are sorted by range
@@ -175,6 +188,12 @@ int  floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* con
                                const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
                                const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups*** out);
 void floria_hip_groups_array_free(floria_groups** arr, uint32_t n_contigs);
+
+/* Nodes and edges of the hap graph for the batch `res` came from.  Must be called on the same context directly after the
+ * floria_hip_phase_blocks* call that produced `res` (the block lists and partitions are still resident in HBM);
+ * returns FLORIA_E_INVALID if the resident copy has been overwritten by a later call. */
+int  floria_hip_hap_graph(floria_hip_ctx* ctx, const floria_block_result* res, floria_hap_graph** out);
+void floria_hip_hap_graph_free(floria_hap_graph* g);
 
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 

@@ -654,6 +654,40 @@ void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32
     parts.swap(np); ranges.swap(nr);
 }
 
+// ---- HapNode::new (types_structs.rs:168-209) and update_hap_graph (graph_processing.rs:22-100) -----------------------
+// hap_map: phred histogram of the node's reads restricted to the block's SNP endpoints (:172-177);
+// cov = allele counts sorted ascending, element [len*2/3] (:187-193).
+struct NodeO { std::vector<uint32_t> frags; Hap hap_map; double cov; };
+NodeO hap_node_new(const Pile& P, const std::vector<uint32_t>& frag_set, uint32_t lo, uint32_t hi) {
+    NodeO n; n.frags = frag_set;
+    for (uint32_t r : frag_set)
+        for (uint32_t c = P.beg(r); c < P.end(r); ++c) {
+            const uint32_t pos = P.p->snp[c];
+            if (pos <= hi && pos >= lo) site_add(n.hap_map.entry(pos), P.p->allele[c], g_w.q24[P.p->qual[c]]);
+        }
+    std::vector<uint64_t> counts;
+    n.hap_map.for_each([&](uint32_t, const Site& s) { for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s.present >> a) & 1) counts.push_back(s.q[a]); });
+    std::sort(counts.begin(), counts.end());
+    n.cov = counts.empty() ? 0.0 : (double)counts[counts.size() * 2 / 3] * 0x1p-24;
+    return n;
+}
+// distance_read_haplo (utils_frags.rs:77-108): only `diff` is consumed by update_hap_graph (:35 `_same`); a tie between the
+// read's allele and the consensus never counts as diff (:95-101); result is rounded (:107)
+uint64_t distance_read_haplo_diff(const Pile& P, uint32_t r, const Hap& hap) {
+    uint64_t diff = 0;
+    for (uint32_t c = P.beg(r); c < P.end(r); ++c) {
+        const Site* s = hap.find(P.p->snp[c]);
+        if (!s) continue;                                               // :80-82
+        uint64_t mx = 0;
+        for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) mx = std::max(mx, s->q[a]);
+        const uint8_t a = P.p->allele[c];
+        const bool has = (s->present >> a) & 1;
+        if (has && s->q[a] == mx) continue;                             // consensus or tied with it
+        diff += g_w.q24[P.p->qual[c]];
+    }
+    return (diff + (1ull << 23)) >> 24;                                 // f64::round, non-negative
+}
+
 int validate(const floria_pileup* p) {
     if (!p || (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last))) { g_err = "null pileup field"; return FLORIA_E_INVALID; }
     for (uint32_t r = 0; r < p->n_reads; ++r) {
@@ -822,6 +856,47 @@ int floria_oracle_heap_trace(const double* scores, uint32_t n, uint32_t limit, i
     for (size_t i = 0; i < h.len(); ++i) heap_ids[i] = h.data[i].node;
     h.into_sorted_vec();
     for (size_t i = 0; i < h.len(); ++i) sorted_ids[i] = h.data[i].node;
+    return 0;
+}
+
+// HapNode::new + update_hap_graph for the non-empty blocks of one contig, given S1's result for exactly these blocks.
+// node_cov: one f64 per (non-empty block, partition) in block order; edge_w: for each consecutive pair of non-empty blocks
+// the row-major best[b] x best[b'] matrix of out_weights (graph_processing.rs:28-47) before the >= 2 filter (:51).
+int floria_oracle_hap_graph(const floria_pileup* pileup, const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
+                            const uint32_t* best_ploidy, const uint64_t* read_off, const uint32_t* read_id, const uint8_t* part,
+                            double* node_cov, uint32_t* edge_w) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    Pile P{pileup};
+    std::vector<std::vector<NodeO>> cols;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        if (best_ploidy[b] == 0) continue;                               // None -> no column (graph_processing.rs:355-361)
+        std::vector<std::vector<uint32_t>> sets(best_ploidy[b]);
+        for (uint64_t i = read_off[b]; i < read_off[b + 1]; ++i) sets[part[i]].push_back(read_id[i]);
+        std::vector<NodeO> col;
+        for (auto& fs : sets) col.push_back(hap_node_new(P, fs, blk_start[b], blk_end[b]));
+        cols.push_back(std::move(col));
+    }
+    size_t nc = 0, ne = 0;
+    for (auto& col : cols) for (auto& nd : col) node_cov[nc++] = nd.cov;
+    for (size_t i = 0; i + 1 < cols.size(); ++i) {
+        auto& b1 = cols[i]; auto& b2 = cols[i + 1];
+        for (auto& n1 : b1) {
+            std::vector<uint32_t> out_weights(b2.size(), 0);
+            for (uint32_t read : n1.frags) {
+                std::vector<std::pair<uint64_t, size_t>> sim;
+                size_t hap_id_in = SIZE_MAX;
+                for (size_t l = 0; l < b2.size(); ++l) {
+                    if (std::binary_search(b2[l].frags.begin(), b2[l].frags.end(), read)) hap_id_in = l;
+                    sim.push_back({distance_read_haplo_diff(P, read, b2[l].hap_map), l});
+                }
+                std::sort(sim.begin(), sim.end());
+                if (sim.size() > 1) { if (sim[0].first != sim[1].first && hap_id_in != SIZE_MAX) out_weights[hap_id_in] += 1; }
+                else if (hap_id_in != SIZE_MAX) out_weights[hap_id_in] += 1;
+            }
+            for (uint32_t w : out_weights) edge_w[ne++] = w;
+        }
+    }
     return 0;
 }
 

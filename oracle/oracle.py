@@ -126,3 +126,19 @@ def heap_trace(scores, limit):
 
 def binom(n, k, p, div=0.25):
     return lib().floria_oracle_binom(n, k, p, div)
+
+
+def hap_graph(pileup, blk_start, blk_end, res):
+    """HapNode::new cov + update_hap_graph out_weights for one contig's blocks, given S1's result `res` (BlockResult) for
+    exactly these blocks -> (node_cov [sum best_ploidy], edge_w [concatenated p1 x p2 matrices of consecutive non-empty blocks])."""
+    cp = pileup.as_c()
+    bs = np.ascontiguousarray(blk_start, np.uint32); be = np.ascontiguousarray(blk_end, np.uint32)
+    bp = np.ascontiguousarray(res.best_ploidy, np.uint32)
+    roff = np.ascontiguousarray(res.read_off, np.uint64); rid = np.ascontiguousarray(res.read_id, np.uint32); part = np.ascontiguousarray(res.part, np.uint8)
+    ne_blocks = [int(p) for p in bp if p]
+    cov = np.zeros(sum(ne_blocks) + 1, np.float64)
+    ew = np.zeros(sum(a * b for a, b in zip(ne_blocks[:-1], ne_blocks[1:])) + 1, np.uint32)
+    _check(lib().floria_oracle_hap_graph(C.byref(cp), capi.ptr(bs, C.c_uint32), capi.ptr(be, C.c_uint32), C.c_uint32(len(bs)), capi.ptr(bp, C.c_uint32),
+                                         capi.ptr(roff, C.c_uint64), capi.ptr(rid, C.c_uint32), capi.ptr(part, C.c_uint8),
+                                         capi.ptr(cov, C.c_double), capi.ptr(ew, C.c_uint32)))
+    return cov[:-1], ew[:-1]

@@ -203,3 +203,35 @@ def test_reassign_batch_equals_per_contig_oracle(gpu_ctx, hip_lib, oracle_mod):
         assert np.array_equal(go.range, out[i].range) and np.array_equal(go.grp_off, out[i].grp_off) and np.array_equal(go.grp_read, out[i].grp_read)
     for r in res:
         r.free()
+
+
+@pytest.mark.parametrize("cfg,n_contigs,scale", [(1, 1, 1.0), (4, 3, 0.6), (3, 2, 0.2)])
+def test_hap_graph_nodes_and_edges(gpu_ctx, hip_lib, oracle_mod, cfg, n_contigs, scale):
+    # HapNode::new coverage + update_hap_graph edge weights on the batch that is still resident
+    C = synth.CONFIGS[cfg]
+    contigs = [synth.make_config_contig(cfg, i, scale) for i in range(n_contigs)]
+    res = [gpu_ctx.upload(c.pileup) for c in contigs]
+    bc, bs, be, per = [], [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, C["block_length"])
+        per.append((s, e, len(bs)))
+        bc += [i] * len(s); bs += list(s); be += list(e)
+    r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, hip_lib.make_params(EPS))
+    g = gpu_ctx.hap_graph(r)
+    assert np.array_equal(np.diff(g.node_off), r.best_ploidy)
+    for i, c in enumerate(contigs):
+        s, e, b0 = per[i]
+        ro = oracle_mod.phase_blocks(c.pileup, s, e, oracle_mod.make_params(EPS), threads=4)
+        cov, ew = oracle_mod.hap_graph(c.pileup, s, e, ro)
+        lo, hi = int(g.node_off[b0]), int(g.node_off[b0 + len(s)])
+        assert np.array_equal(cov.view(np.uint64), g.node_cov[lo:hi].view(np.uint64)), f"contig {i} node cov"
+        elo, ehi = int(g.edge_off[b0]), int(g.edge_off[b0 + len(s)])
+        assert np.array_equal(ew, g.edge_w[elo:ehi]), f"contig {i} edge weights"
+        assert g.pred[b0] == -1                          # no edge across contigs
+    assert g.edge_w.sum() > 0
+    # the resident copy is invalidated by the next call on the context
+    gpu_ctx.phase_blocks(res[0], per[0][0], per[0][1], hip_lib.make_params(EPS))
+    with pytest.raises(hip_lib.FloriaHipError):
+        gpu_ctx.hap_graph(r)
+    for x in res:
+        x.free()
