@@ -124,3 +124,23 @@ def test_dyadic_epsilon_mec_is_integer_plus_m_eps(oracle_mod):
     for b in range(2):
         ids, part = r.block(b)
         assert np.all(part < r.best_ploidy[b]) and np.array_equal(ids, np.sort(ids))
+
+
+def test_kat4_hap_graph_edges_by_hand(oracle_mod):
+    # update_hap_graph (graph_processing.rs:22-100) + HapNode::new (types_structs.rs:168-209), derived by hand:
+    # reads 0,1 carry allele 0 and reads 2,3 allele 1 on SNPs 1..3 (q=30, w = 0.999); blocks (1,2) and (2,3), both phased
+    # into {0,1} | {2,3}.  Node maps of block 2 hold SNPs 2,3 only.  Read 0 vs node 0: no diff; vs node 1: its allele is
+    # absent at both SNPs -> diff = 2w = 1.998 -> rounds to 2: unambiguous, and read 0 sits in node 0 -> weight[0][0] += 1.
+    from types import SimpleNamespace
+    p = Pileup.from_reads([([1, 2, 3], [a] * 3, [30] * 3) for a in (0, 0, 1, 1)])
+    res = SimpleNamespace(best_ploidy=np.array([2, 2], np.uint32), read_off=np.array([0, 4, 8], np.uint64),
+                          read_id=np.array([0, 1, 2, 3, 0, 1, 2, 3], np.uint32), part=np.array([0, 0, 1, 1, 0, 0, 1, 1], np.uint8))
+    cov, ew = oracle_mod.hap_graph(p, [1, 2], [2, 3], res)
+    w = oracle_mod.weight_q24()[30] / 2.0 ** 24
+    assert list(ew) == [2, 0, 0, 2]
+    assert np.allclose(cov, 2 * w, rtol=0, atol=0) and len(cov) == 4      # sorted counts [2w, 2w], element [2*2/3]
+    # ambiguity: with ONE node in the next block every contained read counts (:49-53)
+    res1 = SimpleNamespace(best_ploidy=np.array([2, 1], np.uint32), read_off=res.read_off, read_id=res.read_id,
+                           part=np.array([0, 0, 1, 1, 0, 0, 0, 0], np.uint8))
+    _, ew1 = oracle_mod.hap_graph(p, [1, 2], [2, 3], res1)
+    assert list(ew1) == [2, 2]
