@@ -65,10 +65,14 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
         L.off_q[i] = take(LM * 8); L.off_h1[i] = take(LM * 8); L.off_h2[i] = take(LM * 8); L.off_m[i] = take(LM * 4);
         L.off_sl[i] = take(NS * 2);
     }
-    L.off_live = take(NS * 2); L.off_s2l = take(NS * 2); L.off_ref = take(NS); L.off_leader = take(NS * 4);
-    L.off_newid = take(NS * 2); L.off_free = take(64 * 2); L.off_pk = take(64 * 4);
-    L.off_rqs = take(NS * 8); L.off_rqd = take(NS * 8); L.off_rm = take(NS * 4); L.off_rt1 = take(NS * 8); L.off_rt2 = take(NS * 8);
+    L.off_live = take(NS * 2); L.off_s2l = take(NS * 2);
+    L.off_free = take(64 * 2); L.off_pk = take(64 * 4);
+    L.off_rqs = take(NS * 8); L.off_rqd = take(NS * 8); L.off_rm = take(NS * 4);
+    L.off_rt1 = 0; L.off_rt2 = 0;                    // the window-exit hash terms live in HBM scratch (needed in ~1/4 of the steps)
     L.off_rnp1 = take(q0 ? NS * 8 : 0); L.off_rnp2 = take(q0 ? NS * 8 : 0);
+    // the materialisation tables are only live between phase B and the next phase A: they alias the r_qs array
+    // (leader 4 B + newid 2 B + ref 1 B = 7 B per slab <= 8 B)
+    L.off_leader = L.off_rqs; L.off_newid = L.off_rqs + NS * 4; L.off_ref = L.off_rqs + NS * 6;
     L.total = o;
     return L;
 }
@@ -100,8 +104,6 @@ void beam_slab_kernel(BeamArgs g) {
     uint64_t* r_qs = (uint64_t*)(smem + LY.off_rqs);
     uint64_t* r_qd = (uint64_t*)(smem + LY.off_rqd);
     uint32_t* r_m = (uint32_t*)(smem + LY.off_rm);
-    uint64_t* r_t1 = (uint64_t*)(smem + LY.off_rt1);
-    uint64_t* r_t2 = (uint64_t*)(smem + LY.off_rt2);
     uint64_t* r_np1 = (uint64_t*)(smem + LY.off_rnp1);
     uint64_t* r_np2 = (uint64_t*)(smem + LY.off_rnp2);
 
@@ -109,6 +111,8 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
     char* pool = (char*)(g.state_pool + (uint64_t)blockIdx.x * ((uint64_t)LM * g.span_max * p * A));
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
+    uint64_t* r_t1 = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS));      // tail of the slot's traceback region (host reserves it)
+    uint64_t* r_t2 = r_t1 + NS;
     const uint64_t lane_lt = (1ull << lane) - 1;
 
     const uint32_t S = 64 / p;
@@ -305,7 +309,8 @@ void beam_slab_kernel(BeamArgs g) {
                 if (trunc) { t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs); }
                 if (Q0) { np1 = seg_sum_u64(np1, Gs); np2 = seg_sum_u64(np2, Gs); }
                 if (act && sub == 0) {
-                    r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m; r_t1[li] = t1; r_t2[li] = t2;
+                    r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m;
+                    if (trunc) { r_t1[li] = t1; r_t2[li] = t2; }
                     if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
                 }
             }
@@ -325,7 +330,7 @@ void beam_slab_kernel(BeamArgs g) {
                     const uint32_t li = s2l[st_sl[a * p + my_k]];
                     const uint64_t qs = r_qs[li];
                     qd = r_qd[li]; m = r_m[li];
-                    t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2;
+                    if (trunc) { t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2; }
                     if (Q0) { np1 = r_np1[li]; np2 = r_np2[li]; }
                     const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
                     const uint64_t nn = (uint64_t)(same_f + diff_f), kk = (uint64_t)diff_f;

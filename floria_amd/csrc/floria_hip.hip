@@ -242,20 +242,27 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
               uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
               uint8_t* d_beam_part, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
               uint32_t* d_tried, uint32_t* d_queue, unsigned long long* d_margin, uint32_t* d_diag,
-              unsigned long long* d_steps, EventTimer& T) {
+              unsigned long long* d_steps, EventTimer& T, bool& p1_shortcut) {
     const uint32_t P = prm->max_ploidy, B = prm->beam;
+    p1_shortcut = false;
     const uint32_t n_jobs = (uint32_t)jobs.size();
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const double cutoff = std::log(PROB_CUTOFF);      // graph_processing.rs:146
     for (uint32_t p = 1; p <= P; ++p) {
+        (void)cutoff;
         if (n_jobs == 0) break;
         const uint32_t LM = p * B;
         if (LM > 65000) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam too large");
         // ---- beam search ---------------------------------------------------------------------------------------
-        {
+        // ploidy 1 has nothing to search: one state, one partition, every child passes (p_k - lse == 0 > ln 0.01), the
+        // partition is "all reads in haplotype 0" (global_clustering.rs:74-134 with ploidy == 1) -> a memset.
+        if (p == 1 && !getenv("FLORIA_HIP_NO_P1_SHORTCUT")) {
+            HIPCHK(hipMemsetAsync(d_beam_part, 0, tot_reads, ctx->stream));
+            p1_shortcut = true;
+        } else {
             const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
-            const uint64_t hist_stride = (uint64_t)fl::beam_hist_off(n_max, LM, B) + LM;
+            const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 4ull * LM * p;   // + slab kernel's window-exit hash terms
             const fl::SlabLds SL0 = fl::slab_lds_layout(LM, p, any_q0);
             const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL0.total + 256)));
             uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * FLORIA_FAST_WAVES, by_lds);
@@ -632,11 +639,12 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     bs.blk_pos0 = (const uint32_t*)(M0 + s_p0.off); bs.blk_span = (const uint32_t*)(M0 + s_sp.off);
     bs.blk_read_off = (const uint64_t*)(M0 + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
 
+    bool p1_shortcut = false;
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
     rc = run(ctx, any_q0, bs, jobs, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
              (uint8_t*)(M + s_bpart.off), (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
-             (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T);
+             (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     {
         int t = T.begin(K_SEL);
@@ -680,11 +688,15 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     { unsigned long long prof[32]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
 #endif
     memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
+    if (p1_shortcut && !jobs.empty()) margin = std::min(margin, std::fabs(0.0 - std::log(PROB_CUTOFF)));   // the ploidy-1 decisions: p_k - lse == 0
     R->min_prune_margin = margin;
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
     ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
     ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
-    for (uint32_t b = 0; b < n_blocks; ++b) { ctx->timing.beam_launch_bytes += blk_bytes[b] * R->ploidies_tried[b]; ctx->timing.jobs += R->ploidies_tried[b]; }
+    for (uint32_t b = 0; b < n_blocks; ++b) {          // a beam launch for ploidy p phases the blocks with tried >= p (ploidy 1 needs no launch)
+        const uint32_t launches_b = R->ploidies_tried[b] - ((p1_shortcut && R->ploidies_tried[b]) ? 1 : 0);
+        ctx->timing.beam_launch_bytes += blk_bytes[b] * launches_b; ctx->timing.jobs += R->ploidies_tried[b];
+    }
     ctx->batch_token = R->batch_token = ++ctx->token_counter;
     ctx->last_bs = bs; ctx->last_part = (const uint8_t*)(M + s_out.off); ctx->last_best = (const uint32_t*)(M + s_best.off); ctx->last_nall = nall;
     ctx->last_bc = bc; ctx->last_start.assign(blk_start, blk_start + n_blocks); ctx->last_end.assign(blk_end, blk_end + n_blocks);
