@@ -235,3 +235,41 @@ def test_hap_graph_nodes_and_edges(gpu_ctx, hip_lib, oracle_mod, cfg, n_contigs,
         gpu_ctx.hap_graph(r)
     for x in res:
         x.free()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_medium_pileups_all_beam_paths(gpu_ctx, hip_lib, oracle_mod, seed):
+    # medium blocks (hundreds of reads, deeper coverage, ties from identical reads) through the three beam kernels:
+    # shared-slab (default), per-state-slab (fast) and the generic LDS-heap kernel must all equal the oracle
+    rng = np.random.default_rng(5000 + seed)
+    ploidy = int(rng.integers(1, 6))
+    pile = random_pileup(rng, int(rng.integers(150, 600)), int(rng.integers(20, 120)), ploidy, max_len=int(rng.integers(3, 60)),
+                         alleles=2 if seed % 5 else 4, q0_frac=0.05 if seed % 6 == 0 else 0.0, err=float(rng.choice([0.0, 0.03, 0.1])),
+                         qlo=20 if seed % 4 == 0 else 5, qhi=20 if seed % 4 == 0 else 40)
+    S = int(pile.last.max())
+    s = np.array([1, max(1, S // 3)]); e = np.array([max(1, S // 2), S])
+    P, B = int(rng.integers(2, 6)), int(rng.integers(2, 11))
+    eps = [EPS, 0.04][seed % 2]
+    ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, B), threads=4)
+    try:
+        for path in ("slab", "fast", "generic"):
+            os.environ["FLORIA_HIP_BEAM"] = path
+            rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, B))
+            assert_block_results_equal(ro, rg, f"seed {seed} path {path}")
+            assert rg.min_prune_margin == ro.min_prune_margin
+    finally:
+        os.environ.pop("FLORIA_HIP_BEAM", None)
+
+
+def test_ploidy1_shortcut_equals_the_search(gpu_ctx, hip_lib):
+    # the ploidy-1 beam search has no choice to make; skipping its launch must not change anything
+    c = synth.make_config_contig(4, 7, 0.5)
+    s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+    a = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
+    os.environ["FLORIA_HIP_NO_P1_SHORTCUT"] = "1"
+    try:
+        b = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
+    finally:
+        os.environ.pop("FLORIA_HIP_NO_P1_SHORTCUT", None)
+    assert_block_results_equal(a, b, "p1 shortcut")
+    assert a.min_prune_margin == b.min_prune_margin
