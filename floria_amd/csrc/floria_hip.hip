@@ -142,24 +142,6 @@ int validate_pileup(const floria_pileup* p, uint32_t* max_len, uint32_t* max_all
     return 0;
 }
 
-// find_reads_in_interval (local_clustering.rs:12-59): reads with last >= start, first <= end and
-// last - first <= 10000; reads are sorted by first so the candidates are one binary-searched range.
-void reads_in_interval(const floria_hip_contig* c, uint32_t start, uint32_t end, std::vector<uint32_t>& out,
-                       uint32_t* pos0, uint32_t* pos1) {
-    const auto& F = c->h_first; const auto& L = c->h_last;
-    const uint32_t lo_first = start > 10000 ? start - 10000 : 0;
-    size_t lo = std::lower_bound(F.begin(), F.end(), lo_first) - F.begin();
-    size_t hi = std::upper_bound(F.begin(), F.end(), end) - F.begin();
-    uint32_t mn = UINT32_MAX, mx = 0;
-    for (size_t r = lo; r < hi; ++r) {
-        if (L[r] < start) continue;
-        if (L[r] - F[r] > 10000) continue;
-        out.push_back((uint32_t)r);
-        mn = std::min(mn, F[r]); mx = std::max(mx, L[r]);
-    }
-    *pos0 = mn; *pos1 = mx;
-}
-
 int ensure_binom(floria_hip_ctx* ctx, double eps, uint32_t nmax) {
     nmax = std::min(nmax, BINOM_NMAX_CAP);
     if (ctx->binom_eps == eps && ctx->binom_nmax >= nmax && ctx->d_binom.p) return 0;
