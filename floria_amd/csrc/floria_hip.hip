@@ -793,8 +793,10 @@ void floria_hip_hap_graph_free(floria_hap_graph* g) {
 // across contigs.
 int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
                               const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
-                              const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups*** out) {
+                              const uint32_t* grp_range, uint32_t n_groups, const uint32_t* read_order, const uint64_t* order_off,
+                              double epsilon, floria_groups*** out) {
     if (!ctx || !out || (n_contigs && !contigs) || (n_groups && (!grp_off || !grp_range))) return fail(FLORIA_E_INVALID, "null argument");
+    if ((read_order == nullptr) != (order_off == nullptr)) return fail(FLORIA_E_INVALID, "read_order and order_off go together");
     *out = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->timing = floria_timing{};
@@ -837,6 +839,15 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         std::vector<uint64_t> off(N + 1, 0);
         for (auto& pr : pairs) off[pr.first + 1]++;
         for (uint32_t r = 0; r < N; ++r) off[r + 1] += off[r];
+        if (read_order) {                                   // every read that sits in a group must be visited exactly once
+            std::vector<uint8_t> seen(N, 0);
+            for (uint64_t i = order_off[ci]; i < order_off[ci + 1]; ++i) {
+                const uint32_t r = read_order[i];
+                if (r >= N || seen[r]) return fail(FLORIA_E_INVALID, "read_order: id out of range or repeated");
+                seen[r] = 1;
+            }
+            for (uint32_t r = 0; r < N; ++r) if (off[r + 1] > off[r] && !seen[r]) return fail(FLORIA_E_INVALID, "read_order misses a read that sits in a group");
+        }
         r2g_off_all.insert(r2g_off_all.end(), off.begin(), off.end());
         for (auto& pr : pairs) r2g_all.push_back(pr.second);
         for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
@@ -854,7 +865,8 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         const Seg s_cd = seg(sizeof(fl::ContigDev) * n_contigs), s_rob = seg(8ull * n_contigs), s_rb = seg(8ull * n_contigs), s_gb = seg(8ull * n_contigs),
                   s_ab = seg(8ull * n_contigs), s_ro = seg(8ull * r2g_off_all.size() + 8), s_r2g = seg(4ull * r2g_all.size() + 4),
                   s_ho = seg(8ull * hist_off_all.size() + 8), s_p0 = seg(4ull * gpos0_all.size() + 4), s_hist = seg(8ull * hist_cells + 8),
-                  s_as = seg(4ull * n_assign + 4), s_q = seg(16);
+                  s_as = seg(4ull * n_assign + 4), s_q = seg(16), s_ord = seg(read_order ? 4ull * order_off[n_contigs] + 4 : 4),
+                  s_oo = seg(8ull * (n_contigs + 1));
         int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
         char* M = ctx->misc.as<char>();
         EventTimer T(ctx->stream);
@@ -867,6 +879,8 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         HIPCHK(h2d(s_ho, hist_off_all.data(), 8ull * hist_off_all.size())); HIPCHK(h2d(s_p0, gpos0_all.data(), 4ull * gpos0_all.size()));
         HIPCHK(hipMemsetAsync(M + s_hist.off, 0, s_hist.bytes, ctx->stream));
         HIPCHK(hipMemsetAsync(M + s_q.off, 0, 16, ctx->stream));
+        HIPCHK(hipMemsetAsync(M + s_as.off, 0xff, s_as.bytes, ctx->stream));            // -1 = not assigned
+        if (read_order) { HIPCHK(h2d(s_ord, read_order, 4ull * order_off[n_contigs])); HIPCHK(h2d(s_oo, order_off, 8ull * (n_contigs + 1))); }
         T.end(th);
         fl::ReassignArgs a{};
         a.contigs = (const fl::ContigDev*)(M + s_cd.off); a.n_contigs = n_contigs;
@@ -875,6 +889,7 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         a.grp_base = (const uint64_t*)(M + s_gb.off); a.grp_hist_off = (const uint64_t*)(M + s_ho.off); a.grp_pos0 = (const uint32_t*)(M + s_p0.off);
         a.hist = (uint64_t*)(M + s_hist.off); a.assign = (int32_t*)(M + s_as.off); a.assign_base = (const uint64_t*)(M + s_ab.off);
         a.eps = epsilon; a.queue_head = (uint32_t*)(M + s_q.off);
+        a.order = read_order ? (const uint32_t*)(M + s_ord.off) : nullptr; a.order_off = (const uint64_t*)(M + s_oo.off);
         const uint32_t grid = std::min<uint32_t>(n_contigs, (uint32_t)ctx->n_cu * 16);
         int tk = T.begin(K_REASSIGN);
         if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a);
@@ -952,17 +967,23 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
     return 0;
 }
 
-int floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* c, const uint64_t* grp_off, const uint32_t* grp_read,
-                        const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
+int floria_hip_reassign_ordered(floria_hip_ctx* ctx, const floria_hip_contig* c, const uint64_t* grp_off, const uint32_t* grp_read,
+                                const uint32_t* grp_range, uint32_t n_groups, const uint32_t* read_order, uint32_t n_order,
+                                double epsilon, floria_groups** out) {
     if (!c || !out) return fail(FLORIA_E_INVALID, "null argument");
     *out = nullptr;
     const floria_hip_contig* arr[1] = {c};
+    const uint64_t oo[2] = {0, n_order};
     floria_groups** res = nullptr;
-    int rc = floria_hip_reassign_batch(ctx, arr, 1, nullptr, grp_off, grp_read, grp_range, n_groups, epsilon, &res);
+    int rc = floria_hip_reassign_batch(ctx, arr, 1, nullptr, grp_off, grp_read, grp_range, n_groups, read_order, read_order ? oo : nullptr, epsilon, &res);
     if (rc) return rc;
     *out = res[0];
     free(res);
     return 0;
+}
+int floria_hip_reassign(floria_hip_ctx* ctx, const floria_hip_contig* c, const uint64_t* grp_off, const uint32_t* grp_read,
+                        const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
+    return floria_hip_reassign_ordered(ctx, c, grp_off, grp_read, grp_range, n_groups, nullptr, 0, epsilon, out);
 }
 void floria_hip_groups_array_free(floria_groups** arr, uint32_t n) {
     if (!arr) return;

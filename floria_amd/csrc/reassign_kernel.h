@@ -4,7 +4,9 @@
 // stitched haplogroup is removed from all of them (:195-200 — after which every histogram is empty) and
 // greedily re-inserted into the candidate with minimal (diff + 1, id, same) (:203-222), the histograms
 // being updated after every insertion (add_read_to_block, utils_frags.rs:465-474).  The chain is
-// sequentially dependent; reads are visited in ascending counter_id (DESIGN.md "Iteration order").
+// sequentially dependent and strongly order-sensitive (DESIGN.md "Iteration order"): reads are visited in the order the
+// caller passes (a Rust host passes its own read_to_parts_map iteration order and gets the reference's result), or in
+// ascending counter_id when none is given.
 // separate_broken_haplogroups / sort_parts (:27-98, :276-288) are integer bookkeeping done by the host.
 #pragma once
 #include "common.h"
@@ -25,6 +27,8 @@ struct ReassignArgs {
     uint64_t* hist;                 // zero-initialised, [sum window*A]
     int32_t*  assign;               // per contig reads: chosen contig-local group id or -1
     const uint64_t* assign_base;    // [n_contigs]
+    const uint32_t* order;          // optional caller-given visiting order of the reads (nullptr = ascending counter_id)
+    const uint64_t* order_off;      // [n_contigs+1] into order
     double eps;
     uint32_t* queue_head;
 };
@@ -42,9 +46,12 @@ __global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
         const uint32_t* r2g = g.r2g + g.r2g_base[ci];
         const uint64_t gb = g.grp_base[ci];
         int32_t* assign = g.assign + g.assign_base[ci];
-        for (uint32_t r = 0; r < cd.n_reads; ++r) {
+        const uint32_t* ord = g.order ? g.order + g.order_off[ci] : nullptr;
+        const uint32_t n_visit = g.order ? (uint32_t)(g.order_off[ci + 1] - g.order_off[ci]) : cd.n_reads;
+        for (uint32_t v = 0; v < n_visit; ++v) {
+            const uint32_t r = ord ? ord[v] : v;
             const uint64_t c0 = roff[r], c1 = roff[r + 1];
-            if (c0 == c1) { if (lane == 0) assign[r] = -1; continue; }
+            if (c0 == c1) continue;                              // assign[] was preset to -1
             const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
             uint32_t best = r2g[c0];
             if (c1 - c0 > 1) {

@@ -24,7 +24,7 @@ SYMBOLS = [
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
     "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
-    "floria_hip_hap_graph", "floria_hip_hap_graph_free",
+    "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered",
 ]
 
 
@@ -181,7 +181,7 @@ class FloriaHip:
         return g
 
     # S2 --------------------------------------------------------------------------------------------
-    def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon):
+    def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon, read_orders=None):
         """process_reads_for_final_parts for many resident contigs in one launch -> list of _capi.Groups (contig order)."""
         arr = (C.c_void_p * len(contigs))(*[c._h for c in contigs])
         gc = np.ascontiguousarray(grp_contig, np.uint32)
@@ -190,20 +190,27 @@ class FloriaHip:
         reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
         rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
         out = C.POINTER(C.POINTER(capi.CGroups))()
+        if read_orders is None:
+            po, poo = None, None
+        else:                                        # one visiting order (array of read ids) per contig
+            oo = np.zeros(len(contigs) + 1, np.uint64)
+            oo[1:] = np.cumsum([len(o) for o in read_orders])
+            ordv = np.ascontiguousarray(np.concatenate([np.asarray(o, np.uint32) for o in read_orders]) if len(read_orders) else np.zeros(0, np.uint32), np.uint32)
+            po, poo = capi.ptr(ordv, C.c_uint32), capi.ptr(oo, C.c_uint64)
         _check(load().floria_hip_reassign_batch(self._h, arr, C.c_uint32(len(contigs)), capi.ptr(gc, C.c_uint32), capi.ptr(off, C.c_uint64),
-                                                capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), C.c_double(epsilon),
-                                                C.byref(out)))
+                                                capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), po, poo,
+                                                C.c_double(epsilon), C.byref(out)))
         res = [capi.Groups(out[i].contents) for i in range(len(contigs))]
         load().floria_hip_groups_array_free(out, C.c_uint32(len(contigs)))
         return res
 
-    def reassign(self, contig, groups, ranges, epsilon):
+    def reassign(self, contig, groups, ranges, epsilon, read_order=None):
         """process_reads_for_final_parts (part_block_manip.rs:174-274): groups = list of read-id arrays,
         ranges = [(start,end)] -> _capi.Groups"""
         if isinstance(contig, Pileup):
             rc = self.upload(contig)
             try:
-                return self.reassign(rc, groups, ranges, epsilon)
+                return self.reassign(rc, groups, ranges, epsilon, read_order)
             finally:
                 rc.free()
         off = np.zeros(len(groups) + 1, np.uint64)
@@ -211,8 +218,13 @@ class FloriaHip:
         reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
         rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
         out = C.POINTER(capi.CGroups)()
-        _check(load().floria_hip_reassign(self._h, contig._h, capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
-                                          C.c_uint32(len(groups)), C.c_double(epsilon), C.byref(out)))
+        if read_order is None:
+            po, no = None, 0
+        else:
+            ordv = np.ascontiguousarray(read_order, np.uint32)
+            po, no = capi.ptr(ordv, C.c_uint32), len(ordv)
+        _check(load().floria_hip_reassign_ordered(self._h, contig._h, capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
+                                                  C.c_uint32(len(groups)), po, C.c_uint32(no), C.c_double(epsilon), C.byref(out)))
         g = capi.Groups(out.contents)
         load().floria_hip_groups_free(out)
         return g

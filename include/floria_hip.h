@@ -186,7 +186,16 @@ void floria_hip_groups_free(floria_groups* g);
  * across contigs).  grp_contig[g] indexes `contigs`; *out is an array of n_contigs floria_groups* in contig order. */
 int  floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
                                const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
-                               const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups*** out);
+                               const uint32_t* grp_range, uint32_t n_groups,
+                               const uint32_t* read_order, const uint64_t* order_off,   /* both NULL, or see below */
+                               double epsilon, floria_groups*** out);
+/* The greedy re-insertion is strongly order-dependent and the reference visits reads in the iteration order of its
+ * `read_to_parts_map: FxHashMap<&Frag, _>` (part_block_manip.rs:203).  A host that wants the reference's exact result passes
+ * that order: read_order[order_off[c] .. order_off[c+1]) = counter_ids of contig c's reads in visiting order (every read that
+ * sits in a group exactly once).  With NULL the reads are visited in ascending counter_id. */
+int  floria_hip_reassign_ordered(floria_hip_ctx* ctx, const floria_hip_contig* contig,
+                                 const uint64_t* grp_off, const uint32_t* grp_read, const uint32_t* grp_range, uint32_t n_groups,
+                                 const uint32_t* read_order, uint32_t n_order, double epsilon, floria_groups** out);
 void floria_hip_groups_array_free(floria_groups** arr, uint32_t n_contigs);
 
 /* Nodes and edges of the hap graph for the batch `res` came from.  Must be called on the same context directly after the

@@ -48,6 +48,9 @@ constexpr double PROB_CUTOFF       = 0.01;    // constants.rs:6
 // MERGE_SIMILAR_HAPLOGROUPS = false (:16)
 
 thread_local std::string g_err;
+// Sensitivity knob (tests only): 0 = canonical ascending counter_id at the order-dependent sites, 1 = DEscending.
+// The reference's FxHash order is some third permutation; comparing 0 vs 1 measures how often the order matters at all.
+std::atomic<int> g_order_mode{0};
 
 // ---- phred_scale (utils_frags.rs:702-711) ---------------------------------------------------------
 // prob = 1f32 - 10f32.powf(q as f32 / -10.), widened to f64.  Always k * 2^-24 (checked below).
@@ -404,7 +407,9 @@ std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<
     std::vector<Move> best_moves;
     for (int i = 0; i < ploidy; ++i) {
         if (partition[i].size() <= 1) continue;                                          // :300-302
-        for (uint32_t read : partition[i]) {                                             // canonical: ascending id (2)
+        std::vector<uint32_t> order_i(partition[i]);
+        if (g_order_mode.load()) std::reverse(order_i.begin(), order_i.end());
+        for (uint32_t read : order_i) {                                                  // canonical: ascending id (2)
             SD own = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[i]);
             double errors_read = qm_to_f64(own.diff, own.m, epsilon);
             for (int j = 0; j < ploidy; ++j) {
@@ -620,7 +625,8 @@ void separate_broken_haplogroups(const Pile& P, std::vector<std::vector<uint32_t
 }
 
 void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32_t>>& parts,
-                                   std::vector<std::pair<uint32_t, uint32_t>>& ranges, double epsilon) {
+                                   std::vector<std::pair<uint32_t, uint32_t>>& ranges, double epsilon,
+                                   const uint32_t* read_order = nullptr, uint32_t n_order = 0) {
     HapBlock block = hap_block_from_partition(P, parts, true);                              // :184
     std::vector<std::vector<uint32_t>> read_to_parts(P.n());                                 // :185-193
     for (size_t i = 0; i < parts.size(); ++i)
@@ -631,7 +637,9 @@ void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32
     for (uint32_t r = 0; r < P.n(); ++r)                                                     // :195-200
         for (uint32_t id : read_to_parts[r]) remove_read_from_block(P, block.blocks[id], r);
     for (auto& p : parts) p.clear();
-    for (uint32_t r = 0; r < P.n(); ++r) {                                                   // :203-222, canonical order (2)
+    const uint32_t n_visit = read_order ? n_order : P.n();
+    for (uint32_t rr = 0; rr < n_visit; ++rr) {                                               // :203-222, canonical order (2) unless the caller gives the map's order
+        const uint32_t r = read_order ? read_order[rr] : (g_order_mode.load() ? P.n() - 1 - rr : rr);
         if (read_to_parts[r].empty()) continue;
         bool have = false; double bd = 0, bs = 0; uint32_t bid = 0;
         for (uint32_t id : read_to_parts[r]) {
@@ -644,6 +652,7 @@ void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32
         parts[bid].push_back(r);
         add_read_to_block(P, block.blocks[bid], r);
     }
+    for (auto& pp : parts) std::sort(pp.begin(), pp.end());                                   // (no-op in canonical mode)
     separate_broken_haplogroups(P, parts, ranges);                                            // :231-233
     // sort_parts :276-288 — stable sort by range
     std::vector<size_t> idx(parts.size());
@@ -712,6 +721,7 @@ int validate(const floria_pileup* p) {
 extern "C" {
 
 const char* floria_oracle_last_error(void) { return g_err.c_str(); }
+void floria_oracle_set_order_mode(int m) { g_order_mode.store(m); }
 
 int floria_oracle_weight_q24(uint32_t* out256) { memcpy(out256, g_w.q24, sizeof(g_w.q24)); return 0; }
 
@@ -810,8 +820,16 @@ int floria_oracle_one_ploidy(const floria_pileup* pileup, uint32_t start, uint32
 }
 
 // S2
+int floria_oracle_reassign_ordered(const floria_pileup* pileup, const uint64_t* grp_off, const uint32_t* grp_read,
+                                   const uint32_t* grp_range, uint32_t n_groups, const uint32_t* read_order, uint32_t n_order,
+                                   double epsilon, floria_groups** out);
 int floria_oracle_reassign(const floria_pileup* pileup, const uint64_t* grp_off, const uint32_t* grp_read,
                            const uint32_t* grp_range, uint32_t n_groups, double epsilon, floria_groups** out) {
+    return floria_oracle_reassign_ordered(pileup, grp_off, grp_read, grp_range, n_groups, nullptr, 0, epsilon, out);
+}
+int floria_oracle_reassign_ordered(const floria_pileup* pileup, const uint64_t* grp_off, const uint32_t* grp_read,
+                                   const uint32_t* grp_range, uint32_t n_groups, const uint32_t* read_order, uint32_t n_order,
+                                   double epsilon, floria_groups** out) {
     int rc = validate(pileup);
     if (rc) return rc;
     Pile P{pileup};
@@ -826,7 +844,8 @@ int floria_oracle_reassign(const floria_pileup* pileup, const uint64_t* grp_off,
         parts[g].erase(std::unique(parts[g].begin(), parts[g].end()), parts[g].end());   // FxHashSet semantics
         ranges[g] = {grp_range[2 * g], grp_range[2 * g + 1]};
     }
-    process_reads_for_final_parts(P, parts, ranges, epsilon);
+    for (uint32_t i = 0; i < n_order; ++i) if (read_order && read_order[i] >= P.n()) { g_err = "read_order id out of range"; return FLORIA_E_INVALID; }
+    process_reads_for_final_parts(P, parts, ranges, epsilon, read_order, n_order);
     floria_groups* G = (floria_groups*)calloc(1, sizeof(floria_groups));
     G->n_groups = (uint32_t)parts.size();
     G->grp_off = (uint64_t*)calloc(parts.size() + 1, sizeof(uint64_t));

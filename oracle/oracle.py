@@ -97,7 +97,7 @@ def one_ploidy(pileup, start, end, ploidy, epsilon, beam=10):
     return rid[:k].copy(), pb[:k].copy(), po[:k].copy(), mec.value, na.value, it.value
 
 
-def reassign(pileup, groups, ranges, epsilon):
+def reassign(pileup, groups, ranges, epsilon, read_order=None):
     """groups: list of read-id arrays; ranges: [(start,end)] -> (list of arrays, [(start,end)])"""
     cp = pileup.as_c()
     off = np.zeros(len(groups) + 1, np.uint64)
@@ -106,8 +106,13 @@ def reassign(pileup, groups, ranges, epsilon):
     reads = np.ascontiguousarray(reads)
     rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
     out = C.POINTER(capi.CGroups)()
-    _check(lib().floria_oracle_reassign(C.byref(cp), capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
-                                        C.c_uint32(len(groups)), C.c_double(epsilon), C.byref(out)))
+    if read_order is None:
+        po, no = None, 0
+    else:
+        ordv = np.ascontiguousarray(read_order, np.uint32)
+        po, no = capi.ptr(ordv, C.c_uint32), len(ordv)
+    _check(lib().floria_oracle_reassign_ordered(C.byref(cp), capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
+                                                C.c_uint32(len(groups)), po, C.c_uint32(no), C.c_double(epsilon), C.byref(out)))
     g = capi.Groups(out.contents)
     lib().floria_oracle_groups_free(out)
     return g
@@ -142,3 +147,8 @@ def hap_graph(pileup, blk_start, blk_end, res):
                                          capi.ptr(roff, C.c_uint64), capi.ptr(rid, C.c_uint32), capi.ptr(part, C.c_uint8),
                                          capi.ptr(cov, C.c_double), capi.ptr(ew, C.c_uint32)))
     return cov[:-1], ew[:-1]
+
+
+def set_order_mode(mode):
+    """0 = canonical ascending counter_id at the iteration-order-dependent sites, 1 = descending (sensitivity tests only)."""
+    lib().floria_oracle_set_order_mode(C.c_int(mode))

@@ -273,3 +273,27 @@ def test_ploidy1_shortcut_equals_the_search(gpu_ctx, hip_lib):
         os.environ.pop("FLORIA_HIP_NO_P1_SHORTCUT", None)
     assert_block_results_equal(a, b, "p1 shortcut")
     assert a.min_prune_margin == b.min_prune_margin
+
+
+def test_reassign_with_caller_given_order(gpu_ctx, hip_lib, oracle_mod):
+    # the greedy chain is order-dependent (the reference visits reads in FxHashMap order, part_block_manip.rs:203); with the
+    # visiting order passed in, GPU and oracle agree for ANY order, and different orders really give different haplogroups
+    c = synth.make_config_contig(4, 1, 0.5)
+    s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+    r = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
+    groups, ranges = groups_from_blocks(r, s, e)
+    members = np.unique(np.concatenate(groups))
+    rng = np.random.default_rng(3)
+    outs = []
+    for trial in range(3):
+        order = rng.permutation(members).astype(np.uint32) if trial else members[::-1].copy()
+        go = oracle_mod.reassign(c.pileup, groups, ranges, EPS, read_order=order)
+        gg = gpu_ctx.reassign(c.pileup, groups, ranges, EPS, read_order=order)
+        assert np.array_equal(go.range, gg.range) and np.array_equal(go.grp_off, gg.grp_off) and np.array_equal(go.grp_read, gg.grp_read)
+        outs.append(gg.grp_read.tobytes() + gg.grp_off.tobytes())
+    assert len(set(outs)) > 1
+    # an order that misses a grouped read, or repeats one, is rejected
+    with pytest.raises(hip_lib.FloriaHipError):
+        gpu_ctx.reassign(c.pileup, groups, ranges, EPS, read_order=members[:-1])
+    with pytest.raises(hip_lib.FloriaHipError):
+        gpu_ctx.reassign(c.pileup, groups, ranges, EPS, read_order=np.concatenate([members, members[:1]]))
