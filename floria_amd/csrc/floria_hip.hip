@@ -27,6 +27,7 @@
 #include "beam_kernel.h"
 #include "beam_fast_kernel.h"
 #include "beam_slab_kernel.h"
+#include "beam_wide_kernel.h"
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
 #include "blocks_kernel.h"
@@ -244,7 +245,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             p1_shortcut = true;
         } else {
             const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
-            const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 4ull * LM * p;   // + slab kernel's window-exit hash terms
+            // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
+            const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));
             const fl::SlabLds SL0 = fl::slab_lds_layout(LM, p, any_q0);
             const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL0.total + 256)));
             uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * FLORIA_FAST_WAVES, by_lds);
@@ -268,15 +270,28 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             if (LY.total > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void*)fl::beam_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY.total));
             HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
-            const char* force = getenv("FLORIA_HIP_BEAM");       // dev/test knob: generic | fast | slab
-            const bool small = LM <= 63 && (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull;
+            const char* force = getenv("FLORIA_HIP_BEAM");       // dev/test knob: generic | fast | slab | wide
+            const bool fits32 = (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull;
+            const bool small = LM <= 63 && fits32;
+            const fl::WideLds WL = fl::wide_lds_layout(LM, p, any_q0);
+            bool wide = !small && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && WL.total <= 150 * 1024;
+            if (force && !strcmp(force, "wide") && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && WL.total <= 150 * 1024) wide = true;
+            if (force && strcmp(force, "wide")) wide = false;
             const fl::SlabLds SL = fl::slab_lds_layout(LM, p, any_q0);
             bool slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && SL.total <= 60 * 1024;
             bool fast = small;
             if (force && !strcmp(force, "generic")) { slab = false; fast = false; }
             if (force && !strcmp(force, "fast")) slab = false;
             int t = T.begin(K_BEAM);
-            if (slab) {
+            if (wide) {
+                const uint32_t wslots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (WL.total + 512))));
+                if (WL.total > 48 * 1024) {
+                    if (any_q0) HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
+                    else HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
+                }
+                if (any_q0) hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(wslots), dim3(64), WL.total, ctx->stream, a);
+                else hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(wslots), dim3(64), WL.total, ctx->stream, a);
+            } else if (slab) {
                 if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), SL.total, ctx->stream, a);
                 else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), SL.total, ctx->stream, a);
             } else if (fast) {

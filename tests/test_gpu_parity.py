@@ -240,7 +240,7 @@ def test_hap_graph_nodes_and_edges(gpu_ctx, hip_lib, oracle_mod, cfg, n_contigs,
 @pytest.mark.parametrize("seed", range(24))
 def test_random_medium_pileups_all_beam_paths(gpu_ctx, hip_lib, oracle_mod, seed):
     # medium blocks (hundreds of reads, deeper coverage, ties from identical reads) through the three beam kernels:
-    # shared-slab (default), per-state-slab (fast) and the generic LDS-heap kernel must all equal the oracle
+    # shared-slab (default), per-state-slab (fast), the generic LDS-heap kernel and the wide-beam shared-slab kernel must all equal the oracle
     rng = np.random.default_rng(5000 + seed)
     ploidy = int(rng.integers(1, 6))
     pile = random_pileup(rng, int(rng.integers(150, 600)), int(rng.integers(20, 120)), ploidy, max_len=int(rng.integers(3, 60)),
@@ -252,7 +252,7 @@ def test_random_medium_pileups_all_beam_paths(gpu_ctx, hip_lib, oracle_mod, seed
     eps = [EPS, 0.04][seed % 2]
     ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, B), threads=4)
     try:
-        for path in ("slab", "fast", "generic"):
+        for path in ("slab", "fast", "generic", "wide"):
             os.environ["FLORIA_HIP_BEAM"] = path
             rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, B))
             assert_block_results_equal(ro, rg, f"seed {seed} path {path}")
