@@ -32,6 +32,7 @@
 #include "reassign_kernel.h"
 #include "blocks_kernel.h"
 #include "graph_kernel.h"
+#include "stats_kernel.h"
 
 static_assert(FLORIA_MAX_PLOIDY == fl::MAX_PLOIDY, "ploidy limits out of sync");
 
@@ -800,6 +801,54 @@ int floria_hip_hap_graph(floria_hip_ctx* ctx, const floria_block_result* res, fl
 void floria_hip_hap_graph_free(floria_hap_graph* g) {
     if (!g) return;
     free(g->node_off); free(g->node_cov); free(g->pred); free(g->edge_off); free(g->edge_w); free(g);
+}
+
+// ---- haploset coverage / error statistics (first half) ---------------------------------------------
+int floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
+                              const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
+                              const uint32_t* grp_range, uint32_t n_groups, double* out4) {
+    if (!ctx || (n_contigs && !contigs) || (n_groups && (!grp_off || !grp_range || !out4))) return fail(FLORIA_E_INVALID, "null argument");
+    if (n_groups == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->batch_token = 0;
+    uint32_t A = 2;
+    std::vector<fl::ContigDev> cdev(n_contigs);
+    for (uint32_t i = 0; i < n_contigs; ++i) {
+        if (!contigs[i] || contigs[i]->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
+        A = std::max(A, contigs[i]->n_alleles); cdev[i] = contigs[i]->dev;
+    }
+    std::vector<uint32_t> gc(n_groups, 0);
+    std::vector<uint64_t> hoff(n_groups + 1, 0);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        gc[g] = grp_contig ? grp_contig[g] : 0;
+        if (gc[g] >= n_contigs) return fail(FLORIA_E_INVALID, "grp_contig out of range");
+        for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) if (grp_read[i] >= contigs[gc[g]]->n_reads) return fail(FLORIA_E_INVALID, "group read id out of range");
+        const uint32_t lo = grp_range[2 * g], hi = grp_range[2 * g + 1];
+        hoff[g + 1] = hoff[g] + (hi >= lo ? (uint64_t)(hi - lo + 1) * A : 0);
+    }
+    const uint64_t n_reads_tot = grp_off[n_groups];
+    struct Seg { size_t off, bytes; };
+    size_t cursor = 0;
+    auto seg = [&](size_t bytes) { Seg sg{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return sg; };
+    const Seg s_cd = seg(sizeof(fl::ContigDev) * n_contigs), s_gc = seg(4ull * n_groups), s_go = seg(8ull * (n_groups + 1)), s_gr = seg(4ull * n_reads_tot + 4),
+              s_rg = seg(8ull * n_groups), s_ho = seg(8ull * (n_groups + 1)), s_h = seg(4ull * hoff[n_groups] + 4), s_out = seg(32ull * n_groups);
+    int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
+    char* M = ctx->misc.as<char>();
+    auto h2d = [&](Seg sg, const void* src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(M + sg.off, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; };
+    HIPCHK(h2d(s_cd, cdev.data(), sizeof(fl::ContigDev) * n_contigs)); HIPCHK(h2d(s_gc, gc.data(), 4ull * n_groups));
+    HIPCHK(h2d(s_go, grp_off, 8ull * (n_groups + 1))); HIPCHK(h2d(s_gr, grp_read, 4ull * n_reads_tot));
+    HIPCHK(h2d(s_rg, grp_range, 8ull * n_groups)); HIPCHK(h2d(s_ho, hoff.data(), 8ull * (n_groups + 1)));
+    HIPCHK(hipMemsetAsync(M + s_h.off, 0, s_h.bytes, ctx->stream));
+    fl::StatsArgs a{};
+    a.contigs = (const fl::ContigDev*)(M + s_cd.off); a.grp_contig = (const uint32_t*)(M + s_gc.off); a.grp_off = (const uint64_t*)(M + s_go.off);
+    a.grp_read = (const uint32_t*)(M + s_gr.off); a.grp_range = (const uint32_t*)(M + s_rg.off); a.hist_off = (const uint64_t*)(M + s_ho.off);
+    a.hist = (uint32_t*)(M + s_h.off); a.out = (double*)(M + s_out.off); a.n_groups = n_groups;
+    if (A == 2) hipLaunchKernelGGL(fl::stats_kernel<2>, dim3(n_groups), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(fl::stats_kernel<4>, dim3(n_groups), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out4, M + s_out.off, 32ull * n_groups, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 // ---- S2 --------------------------------------------------------------------------------------------------------

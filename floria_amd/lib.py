@@ -24,7 +24,7 @@ SYMBOLS = [
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
     "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
-    "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered",
+    "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered", "floria_hip_haploset_stats",
 ]
 
 
@@ -179,6 +179,19 @@ class FloriaHip:
         g = capi.HapGraph(out.contents)
         load().floria_hip_hap_graph_free(out)
         return g
+
+    def haploset_stats(self, contigs, grp_contig, groups, ranges):
+        """get_errors_cov_from_frags (utils_frags.rs:596-655) per haploset -> float64 [n_groups, 4] = cov, err, total_err, total_cov."""
+        arr = (C.c_void_p * len(contigs))(*[c._h for c in contigs])
+        gc = np.ascontiguousarray(grp_contig, np.uint32)
+        off = np.zeros(len(groups) + 1, np.uint64)
+        off[1:] = np.cumsum([len(g) for g in groups])
+        reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
+        rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+        out = np.zeros((len(groups), 4), np.float64)
+        _check(load().floria_hip_haploset_stats(self._h, arr, C.c_uint32(len(contigs)), capi.ptr(gc, C.c_uint32), capi.ptr(off, C.c_uint64),
+                                                capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), capi.ptr(out, C.c_double)))
+        return out
 
     # S2 --------------------------------------------------------------------------------------------
     def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon, read_orders=None):

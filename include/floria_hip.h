@@ -204,6 +204,13 @@ void floria_hip_groups_array_free(floria_groups** arr, uint32_t n_contigs);
 int  floria_hip_hap_graph(floria_hip_ctx* ctx, const floria_block_result* res, floria_hap_graph** out);
 void floria_hip_hap_graph_free(floria_hap_graph* g);
 
+/* Coverage / error statistics of haplosets (utils_frags::get_errors_cov_from_frags, utils_frags.rs:596-655 — the COV and ERR
+ * fields of the vartig / haploset headers): out4[4g..4g+3] = (cov, err, total_err, total_cov) of group g over its inclusive SNP
+ * range.  err of an empty haploset is NaN, as in the reference (0/0). */
+int  floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
+                               const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
+                               const uint32_t* grp_range, uint32_t n_groups, double* out4);
+
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */

@@ -919,6 +919,38 @@ int floria_oracle_hap_graph(const floria_pileup* pileup, const uint32_t* blk_sta
     return 0;
 }
 
+// get_errors_cov_from_frags (utils_frags.rs:596-655) for one haploset: unit-count histogram over [lo, hi]; alleles visited in
+// ascending order (the reference's inner-map order; immaterial for biallelic sites).
+int floria_oracle_haploset_stats(const floria_pileup* pileup, const uint32_t* reads, uint32_t n, uint32_t lo, uint32_t hi, double* out4) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    Pile P{pileup};
+    std::vector<uint32_t> fs(reads, reads + n);
+    Hap hap_map = set_to_seq_dict(P, fs, false);                                   // :606
+    double errors = 0., total_support = 0., sum_support = 0.;
+    uint64_t nonzero = 0;
+    for (uint64_t pos = lo; pos <= hi && hi >= lo; ++pos) {                          // :612
+        double snp_support = 0., max_count_pos = 0.;
+        const Site* s = hap_map.find((uint32_t)pos);
+        if (s && s->present) {
+            nonzero++;
+            for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) {
+                const double count = (double)s->q[a];
+                if (count > snp_support) max_count_pos = count;                      // :622-624 (compares with the running sum)
+                snp_support += count;
+            }
+        }
+        total_support += snp_support;
+        errors += snp_support - max_count_pos;
+        sum_support += snp_support;
+    }
+    out4[0] = nonzero ? sum_support / (double)nonzero : 0.;                           // mean = true branch :641-647
+    out4[1] = errors / total_support;
+    out4[2] = errors;
+    out4[3] = total_support;
+    return 0;
+}
+
 double floria_oracle_binom(uint64_t n, uint64_t k, double p, double div) { return stable_binom_cdf_p_rev(n, k, p, div); }
 
 }  // extern "C"

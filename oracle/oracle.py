@@ -152,3 +152,12 @@ def hap_graph(pileup, blk_start, blk_end, res):
 def set_order_mode(mode):
     """0 = canonical ascending counter_id at the iteration-order-dependent sites, 1 = descending (sensitivity tests only)."""
     lib().floria_oracle_set_order_mode(C.c_int(mode))
+
+
+def haploset_stats(pileup, reads, lo, hi):
+    """get_errors_cov_from_frags for one haploset -> (cov, err, total_err, total_cov)."""
+    cp = pileup.as_c()
+    r = np.ascontiguousarray(reads, np.uint32)
+    out = np.zeros(4, np.float64)
+    _check(lib().floria_oracle_haploset_stats(C.byref(cp), capi.ptr(r, C.c_uint32), C.c_uint32(len(r)), C.c_uint32(lo), C.c_uint32(hi), capi.ptr(out, C.c_double)))
+    return out

@@ -297,3 +297,27 @@ def test_reassign_with_caller_given_order(gpu_ctx, hip_lib, oracle_mod):
         gpu_ctx.reassign(c.pileup, groups, ranges, EPS, read_order=members[:-1])
     with pytest.raises(hip_lib.FloriaHipError):
         gpu_ctx.reassign(c.pileup, groups, ranges, EPS, read_order=np.concatenate([members, members[:1]]))
+
+
+def test_haploset_stats(gpu_ctx, hip_lib, oracle_mod):
+    # get_errors_cov_from_frags (utils_frags.rs:596-655): COV / ERR of the output headers, per haploset after S2
+    contigs = [synth.make_config_contig(4, i, 0.4) for i in range(2)] + [synth.make_config_contig(3, 0, 0.2)]
+    res = [gpu_ctx.upload(c.pileup) for c in contigs]
+    groups, ranges, gc = [], [], []
+    for i, c in enumerate(contigs):
+        bl = 10000 if i < 2 else 500
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, bl)
+        r = gpu_ctx.phase_blocks(res[i], s, e, hip_lib.make_params(EPS))
+        g, rg = groups_from_blocks(r, s, e)
+        out = gpu_ctx.reassign(res[i], g, rg, EPS)
+        for k in range(out.n_groups):
+            groups.append(out.group(k)); ranges.append(tuple(int(x) for x in out.range[k])); gc.append(i)
+    groups.append(np.zeros(0, np.uint32)); ranges.append((3, 9)); gc.append(0)            # an empty haploset: err = 0/0 = NaN
+    st = gpu_ctx.haploset_stats(res, gc, groups, ranges)
+    assert st.shape == (len(groups), 4)
+    for k in range(len(groups)):
+        ref = oracle_mod.haploset_stats(contigs[gc[k]].pileup, groups[k], ranges[k][0], ranges[k][1])
+        assert np.array_equal(ref.view(np.uint64), st[k].view(np.uint64)) or (np.isnan(ref[1]) and np.isnan(st[k][1]) and np.array_equal(ref[[0, 2, 3]], st[k][[0, 2, 3]])), (k, ref, st[k])
+    assert np.isnan(st[-1][1]) and st[-1][0] == 0.0
+    for x in res:
+        x.free()

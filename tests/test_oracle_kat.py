@@ -144,3 +144,11 @@ def test_kat4_hap_graph_edges_by_hand(oracle_mod):
                            part=np.array([0, 0, 1, 1, 0, 0, 0, 0], np.uint8))
     _, ew1 = oracle_mod.hap_graph(p, [1, 2], [2, 3], res1)
     assert list(ew1) == [2, 2]
+
+
+def test_kat5_haploset_stats_by_hand(oracle_mod):
+    # utils_frags.rs:596-655 by hand: 3 reads over SNPs 1..3; SNP1 alleles {0:2, 1:1}, SNP2 {0:3}, SNP3 {1:1} (one read only)
+    p = Pileup.from_reads([([1, 2], [0, 0], [30, 30]), ([1, 2, 3], [0, 0, 1], [30, 30, 30]), ([1, 2], [1, 0], [30, 30])])
+    cov, err, total_err, total_cov = oracle_mod.haploset_stats(p, [0, 1, 2], 1, 4)
+    # supports 3, 3, 1 (SNP 4 uncovered): total 7 over 3 covered SNPs; errors = (3-2) + 0 + 0 = 1
+    assert total_cov == 7.0 and total_err == 1.0 and cov == 7.0 / 3.0 and err == 1.0 / 7.0
