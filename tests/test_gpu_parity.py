@@ -321,3 +321,25 @@ def test_haploset_stats(gpu_ctx, hip_lib, oracle_mod):
     assert np.isnan(st[-1][1]) and st[-1][0] == 0.0
     for x in res:
         x.free()
+
+
+def test_mixed_batch_alleles_and_q0(gpu_ctx, hip_lib, oracle_mod):
+    # one batch mixing a biallelic contig, a 4-allele contig and a contig with q=0 observations: the batch runs the
+    # (A=4, presence-tracking) kernel instantiation for everyone; results per contig must equal the oracle's
+    rng = np.random.default_rng(77)
+    piles = [random_pileup(rng, 300, 80, 3, max_len=40, alleles=2), random_pileup(rng, 250, 60, 3, max_len=30, alleles=4),
+             random_pileup(rng, 200, 50, 2, max_len=25, alleles=2, q0_frac=0.1)]
+    res = [gpu_ctx.upload(p) for p in piles]
+    bc, bs, be = [], [], []
+    for i, p in enumerate(piles):
+        S = int(p.last.max())
+        bc += [i, i]; bs += [1, S // 2]; be += [S // 2 + 5 if S // 2 + 5 <= S else S, S]
+    r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, hip_lib.make_params(EPS, 4, 8))
+    for i, p in enumerate(piles):
+        ro = oracle_mod.phase_blocks(p, bs[2 * i:2 * i + 2], be[2 * i:2 * i + 2], oracle_mod.make_params(EPS, 4, 8))
+        lo, hi = int(r.read_off[2 * i]), int(r.read_off[2 * i + 2])
+        assert np.array_equal(ro.best_ploidy, r.best_ploidy[2 * i:2 * i + 2])
+        assert np.array_equal(ro.read_id, r.read_id[lo:hi]) and np.array_equal(ro.part, r.part[lo:hi])
+        assert np.array_equal(ro.mec.view(np.uint64), r.mec[2 * i:2 * i + 2].view(np.uint64))
+    for x in res:
+        x.free()
