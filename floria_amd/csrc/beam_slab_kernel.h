@@ -222,6 +222,8 @@ void beam_slab_kernel(BeamArgs g) {
                 __syncthreads();
             };
             if (ntiles == 1) stage_tile(0, true);
+            if (i + 1 < n) load_cells(m_next);           // the prefetch registers are free again: request the next read's cells now,
+                                                         // their latency hides behind this step's slab loads
             BEAM_TICK(0);
 
             // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
@@ -489,24 +491,18 @@ void beam_slab_kernel(BeamArgs g) {
                         w = aw & 0x0fffffffu;
                         return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + c_off[c] + (aw >> 28) * 8));
                     };
-                    uint32_t x = lane;
-                    for (; x + 192 < items; x += 256) {
-                        uint32_t w0, w1, w2, w3;
-                        uint64_t *p0 = addr_of(x, w0), *p1 = addr_of(x + 64, w1), *p2 = addr_of(x + 128, w2), *p3 = addr_of(x + 192, w3);
-                        const uint64_t v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
-                        *p0 = Q0 ? ((v0 + w0) | PRESENT_BIT) : v0 + w0; *p1 = Q0 ? ((v1 + w1) | PRESENT_BIT) : v1 + w1;
-                        *p2 = Q0 ? ((v2 + w2) | PRESENT_BIT) : v2 + w2; *p3 = Q0 ? ((v3 + w3) | PRESENT_BIT) : v3 + w3;
-                    }
-                    for (; x < items; x += 64) {
-                        uint32_t w0;
-                        uint64_t* p0 = addr_of(x, w0);
-                        const uint64_t v0 = *p0;
-                        *p0 = Q0 ? ((v0 + w0) | PRESENT_BIT) : v0 + w0;
+                    for (uint32_t x = lane; x < items; x += 256) {          // 4 read-modify-writes in flight per lane; the tail
+                        uint32_t w[4]; uint64_t* ptr[4]; uint64_t v[4];     // slots load item 0 (harmless) and skip the store
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const uint32_t xx = x + 64 * u; ptr[u] = addr_of(xx < items ? xx : 0, w[u]); }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = *ptr[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (x + 64 * u < items) *ptr[u] = Q0 ? ((v[u] + w[u]) | PRESENT_BIT) : v[u] + w[u];
                     }
                 }
             }
             m_cur = m_next; m_next = m_next2;
-            if (i + 1 < n) load_cells(m_cur);            // overlaps the read-modify-writes above; consumed by the next step's staging
             __syncthreads();
             BEAM_TICK(5);
             cur ^= 1;
