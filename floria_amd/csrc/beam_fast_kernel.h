@@ -204,9 +204,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
                     bool in = false;
                     if (cc < L) {
                         const uint32_t pr = cd.cell_snp[cbeg + cc] - pos0;
-                        const uint32_t aq = cd.cell_aq[cbeg + cc];
-                        const uint32_t al = aq >> 8;
-                        const uint32_t w = c_w24[aq & 0xff];
+                        const uint32_t aq = cd.cell_aw[cbeg + cc];
+                        const uint32_t al = aq >> 28;
+                        const uint32_t w = (aq & 0x0fffffffu);
                         const uint32_t idx = pr * A + al;
                         c_off[c] = pr * pos_bytes;
                         c_aw[c] = (al << 28) | w;
@@ -227,9 +227,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
             if (ntiles > 1) {                           // rare: reads with > 256 SNPs; hash constant in its own pass
                 for (uint32_t c = lane; c < L; c += 64) {
                     const uint32_t pr = cd.cell_snp[cbeg + c] - pos0;
-                    const uint32_t aq = cd.cell_aq[cbeg + c];
-                    const uint32_t idx = pr * A + (aq >> 8);
-                    const uint64_t w = c_w24[aq & 0xff];
+                    const uint32_t aq = cd.cell_aw[cbeg + c];
+                    const uint32_t idx = pr * A + (aq >> 28);
+                    const uint64_t w = (aq & 0x0fffffffu);
                     tw1 += g.Rq1[idx] * w; tw2 += g.Rq2[idx] * w;
                 }
             } else stage_tile(0, true);

@@ -214,9 +214,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
             uint64_t tw1 = 0, tw2 = 0;
             for (uint32_t c = lane; c < L; c += 64) {
                 uint32_t pr = cd.cell_snp[cbeg + c] - pos0;
-                uint32_t aq = cd.cell_aq[cbeg + c];
-                uint64_t w = c_w24[aq & 0xff];
-                uint32_t idx = pr * A + (aq >> 8);
+                uint32_t aq = cd.cell_aw[cbeg + c];
+                uint64_t w = (aq & 0x0fffffffu);
+                uint32_t idx = pr * A + (aq >> 28);
                 tw1 += g.Rq1[idx] * w;
                 tw2 += g.Rq2[idx] * w;
             }
@@ -234,10 +234,10 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                     uint32_t cc = t * BEAM_TILE + c;
                     if (cc < L) {
                         uint32_t pr = cd.cell_snp[cbeg + cc] - pos0;
-                        uint32_t aq = cd.cell_aq[cbeg + cc];
-                        uint32_t al = aq >> 8;
+                        uint32_t aq = cd.cell_aw[cbeg + cc];
+                        uint32_t al = aq >> 28;
                         c_pos[c] = pr;
-                        c_aw[c] = (al << 28) | c_w24[aq & 0xff];
+                        c_aw[c] = (al << 28) | (aq & 0x0fffffffu);
                         c_rp1[c] = g.Rp1[pr * A + al];
                         c_rp2[c] = g.Rp2[pr * A + al];
                     }

@@ -166,7 +166,7 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint32_t c = lane + 64 * u;
                 const bool v = c < m.L;
                 pf_snp[u] = v ? cd.cell_snp[m.cbeg + c] : 0;
-                pf_aq[u] = v ? cd.cell_aq[m.cbeg + c] : 0;
+                pf_aq[u] = v ? cd.cell_aw[m.cbeg + c] : 0;
             }
         };
         Meta m_cur = load_meta(sload(reads));
@@ -203,11 +203,11 @@ void beam_slab_kernel(BeamArgs g) {
                     bool in = false;
                     if (cc < L) {
                         const uint32_t snp = from_regs ? pf_snp[u] : cd.cell_snp[cbeg + cc];
-                        const uint32_t aq = from_regs ? pf_aq[u] : (uint32_t)cd.cell_aq[cbeg + cc];
+                        const uint32_t aq = from_regs ? pf_aq[u] : (uint32_t)cd.cell_aw[cbeg + cc];
                         const uint32_t pr = snp - pos0;
-                        const uint32_t al = aq >> 8;
+                        const uint32_t al = aq >> 28;
                         c_off[c] = pr * pos_bytes;
-                        c_aw[c] = (al << 28) | c_w24[aq & 0xff];
+                        c_aw[c] = (al << 28) | (aq & 0x0fffffffu);
                         in = (int32_t)pr <= hi_rel;
                         if (Q0) {
                             const uint64_t r1 = g.Rp1[hash_idx(snp, al)], r2 = g.Rp2[hash_idx(snp, al)];

@@ -160,10 +160,10 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                     bool in = false;
                     if (cc < L) {
                         const uint32_t snp = cd.cell_snp[cbeg + cc];
-                        const uint32_t aq = cd.cell_aq[cbeg + cc];
-                        const uint32_t pr = snp - pos0, al = aq >> 8;
+                        const uint32_t aq = cd.cell_aw[cbeg + cc];
+                        const uint32_t pr = snp - pos0, al = aq >> 28;
                         c_off[c] = pr * pos_bytes;
-                        c_aw[c] = (al << 28) | c_w24[aq & 0xff];
+                        c_aw[c] = (al << 28) | (aq & 0x0fffffffu);
                         in = (int32_t)pr <= hi_rel;
                         if (Q0) {
                             const uint64_t r1 = g.Rp1[hash_idx(snp, al)], r2 = g.Rp2[hash_idx(snp, al)];

@@ -24,7 +24,7 @@ struct ContigDev {
     const uint32_t* first;      // [n_reads]
     const uint32_t* last;       // [n_reads]
     const uint32_t* cell_snp;   // [n_cells] 1-based SNP index
-    const uint16_t* cell_aq;    // [n_cells] allele << 8 | qual
+    const uint32_t* cell_aw;    // [n_cells] allele << 28 | Q24 quality weight (w(q) <= 2^24), precomputed at upload
     const uint64_t* tw;         // [2*n_reads] per-read hash constants: sum over cells of Rq{1,2}[hash_idx(snp, allele)] * w
     uint32_t        n_reads;
     uint32_t        pad;
@@ -49,8 +49,6 @@ struct BlockSet {
     uint32_t         pad;
 };
 
-// quality weight LUT (Q24), uploaded once per context
-__constant__ uint32_t c_w24[256];
 // per-partition multipliers of the linear state hash (a by-value kernel-argument array indexed by lane would be
 // copied to scratch)
 __constant__ uint64_t c_rk1[MAX_PLOIDY], c_rk2[MAX_PLOIDY];

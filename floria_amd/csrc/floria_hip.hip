@@ -397,8 +397,6 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         if ((double)w24[q] != s) { delete c; return fail(FLORIA_E_DEVICE, "quality weight is not a multiple of 2^-24"); }
     }
     memcpy(c->w24, w24, sizeof(w24));
-    e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_w24), w24, sizeof(w24));
-    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(FLORIA_E_DEVICE, std::string("weight LUT upload: ") + hipGetErrorString(e)); }
     uint64_t s = 0xf10a1a2024ull;
     for (int k = 0; k < FLORIA_MAX_PLOIDY; ++k) { c->Rk1[k] = splitmix64(s) | 1ull; c->Rk2[k] = splitmix64(s) | 1ull; }
     e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_rk1), c->Rk1, sizeof(c->Rk1));
@@ -481,12 +479,12 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     c->h_first.assign(p->first, p->first + p->n_reads);
     c->h_last.assign(p->last, p->last + p->n_reads);
     c->h_read_off.assign(p->read_off, p->read_off + p->n_reads + (p->n_reads ? 1 : 0));
-    std::vector<uint16_t> aq(nc);
+    std::vector<uint32_t> aq(nc);     // allele << 28 | Q24 weight of the cell (weights are < 2^24)
     std::vector<uint64_t> tw((size_t)p->n_reads * 2, 0);
     for (uint32_t r = 0; r < p->n_reads; ++r) {
         uint64_t t1 = 0, t2 = 0;
         for (uint64_t i = p->read_off[r]; i < p->read_off[r + 1]; ++i) {
-            aq[i] = (uint16_t)((p->allele[i] << 8) | p->qual[i]);
+            aq[i] = ((uint32_t)p->allele[i] << 28) | ctx->w24[p->qual[i]];
             if (p->qual[i] == 0) c->has_q0 = true;
             const uint32_t idx = fl::hash_idx(p->snp[i], p->allele[i]);
             const uint64_t w = ctx->w24[p->qual[i]];
@@ -504,12 +502,12 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     if (!rc) rc = up(c->d_first, p->first, (size_t)p->n_reads * 4);
     if (!rc) rc = up(c->d_last, p->last, (size_t)p->n_reads * 4);
     if (!rc) rc = up(c->d_snp, p->snp, nc * 4);
-    if (!rc) rc = up(c->d_aq, aq.data(), nc * 2);
+    if (!rc) rc = up(c->d_aq, aq.data(), nc * 4);
     if (!rc) rc = up(c->d_tw, tw.data(), tw.size() * 8);
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(FLORIA_E_DEVICE, "upload sync failed");
     if (rc) { floria_hip_contig_free(c); return rc; }
     c->dev.read_off = c->d_read_off.as<uint32_t>(); c->dev.first = c->d_first.as<uint32_t>(); c->dev.last = c->d_last.as<uint32_t>();
-    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aq = c->d_aq.as<uint16_t>(); c->dev.tw = c->d_tw.as<uint64_t>(); c->dev.n_reads = p->n_reads;
+    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aw = c->d_aq.as<uint32_t>(); c->dev.tw = c->d_tw.as<uint64_t>(); c->dev.n_reads = p->n_reads;
     *out = c;
     return 0;
 }

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(GRAPH_THREADS) void graph_kernel(GraphArgs g) {
             const uint32_t r = reads[i], k = part[i];
             const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
             for (uint32_t c = cb + sub; c < ce; c += 16) {
-                const uint32_t sn = cd.cell_snp[c], aq = cd.cell_aq[c];
+                const uint32_t sn = cd.cell_snp[c], aq = cd.cell_aw[c];
                 if (sn >= lo && sn <= hi)
-                    atomicAdd((unsigned long long*)&hist[(uint64_t)(sn - lo) * PA + k * A + (aq >> 8)], (unsigned long long)((1ull << CNT_SHIFT) | c_w24[aq & 0xff]));
+                    atomicAdd((unsigned long long*)&hist[(uint64_t)(sn - lo) * PA + k * A + (aq >> 28)], (unsigned long long)((1ull << CNT_SHIFT) | (aq & 0x0fffffffu)));
             }
         }
     }
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(GRAPH_THREADS) void graph_kernel(GraphArgs g) {
         for (int l = 0; l < MAX_PLOIDY; ++l) acc[l] = 0;
         if (common) {
             for (uint32_t c = cb + sub; c < ce; c += 16) {
-                const uint32_t sn = cd.cell_snp[c], aq = cd.cell_aq[c], al = aq >> 8;
+                const uint32_t sn = cd.cell_snp[c], aq = cd.cell_aw[c], al = aq >> 28;
                 if (sn < lo || sn > hi) continue;                    // outside the block: not a key of any node's hap_map
-                const uint64_t w = c_w24[aq & 0xff];
+                const uint64_t w = (aq & 0x0fffffffu);
                 const uint64_t* row = hist + (uint64_t)(sn - lo) * PA;
 #pragma unroll
                 for (int l = 0; l < MAX_PLOIDY; ++l) {

@@ -161,11 +161,11 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {
                 uint32_t sn[8], aqs[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aq[cb + c] : 0xffffffffu; }
+                for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aw[cb + c] : 0xffffffffu; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (aqs[u] != 0xffffffffu)
-                        atomicAdd((unsigned long long*)&hist[(uint64_t)(sn[u] - pos0) * PA + k * A + (aqs[u] >> 8)], (unsigned long long)((1ull << CNT_SHIFT) | c_w24[aqs[u] & 0xff]));
+                        atomicAdd((unsigned long long*)&hist[(uint64_t)(sn[u] - pos0) * PA + k * A + (aqs[u] >> 28)], (unsigned long long)((1ull << CNT_SHIFT) | (aqs[u] & 0x0fffffffu)));
             }
         }
         __syncthreads();
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     for (uint32_t c0 = sub; c0 < len; c0 += 16 * 4) {
                         uint32_t sn[4], aqs[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aq[cb + c] : 0xffffffffu; }
+                        for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aw[cb + c] : 0xffffffffu; }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (aqs[u] != 0xffffffffu) {
-                                const uint32_t al = aqs[u] >> 8;
-                                const uint64_t w = c_w24[aqs[u] & 0xff];
+                                const uint32_t al = aqs[u] >> 28;
+                                const uint64_t w = (aqs[u] & 0x0fffffffu);
                                 const uint64_t* row = hist + (uint64_t)(sn[u] - pos0) * PA;
 #pragma unroll
                                 for (int k = 0; k < MAX_PLOIDY; ++k) {
@@ -314,9 +314,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         const uint32_t r = reads[rl];
                         const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
                         for (uint32_t c = cb + lane; c < ce; c += 64) {
-                            const uint32_t aq = cd.cell_aq[c];
-                            const unsigned long long d = (1ull << CNT_SHIFT) | c_w24[aq & 0xff];
-                            uint64_t* cp = hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + (aq >> 8);
+                            const uint32_t aq = cd.cell_aw[c];
+                            const unsigned long long d = (1ull << CNT_SHIFT) | (aq & 0x0fffffffu);
+                            uint64_t* cp = hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + (aq >> 28);
                             atomicAdd((unsigned long long*)(cp + from * A), 0ull - d);
                             atomicAdd((unsigned long long*)(cp + to * A), d);
                         }

@@ -63,14 +63,14 @@ __global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
                     const uint32_t p0 = g.grp_pos0[gb + gid];
                     uint64_t qs = 0, qd = 0; uint32_t m = 0;
                     for (uint32_t c = cb + lane; c < ce; c += 64) {          // utils_frags.rs:32-75
-                        const uint32_t aq = cd.cell_aq[c], al = aq >> 8;
+                        const uint32_t aq = cd.cell_aw[c], al = aq >> 28;
                         const uint64_t* cp = h + (uint64_t)(cd.cell_snp[c] - p0) * A;
                         uint64_t mx = 0, va = 0;
 #pragma unroll
                         for (int a = 0; a < A; ++a) { const uint64_t q = cp[a]; mx = q > mx ? q : mx; va = (a == (int)al) ? q : va; }
                         if (mx == 0) m += 1;
-                        else if (va == mx) qs += c_w24[aq & 0xff];
-                        else qd += c_w24[aq & 0xff];
+                        else if (va == mx) qs += (aq & 0x0fffffffu);
+                        else qd += (aq & 0x0fffffffu);
                     }
                     qs = wave_sum_u64(qs); qd = wave_sum_u64(qd); m = wave_sum_u32(m);
                     const double kd = qm_to_f64(qd, m, g.eps) + 1.;              // (diff + 1., id, same) :211
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
                 uint64_t* h = g.hist + g.grp_hist_off[gb + best];
                 const uint32_t p0 = g.grp_pos0[gb + best];
                 for (uint32_t c = cb + lane; c < ce; c += 64) {
-                    const uint32_t aq = cd.cell_aq[c];
-                    h[(uint64_t)(cd.cell_snp[c] - p0) * A + (aq >> 8)] += c_w24[aq & 0xff];
+                    const uint32_t aq = cd.cell_aw[c];
+                    h[(uint64_t)(cd.cell_snp[c] - p0) * A + (aq >> 28)] += (aq & 0x0fffffffu);
                 }
             }
             if (lane == 0) assign[r] = (int32_t)best;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void stats_kernel(StatsArgs g) {
             const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
             for (uint32_t c = cb + sub; c < ce; c += 16) {
                 const uint32_t sn = cd.cell_snp[c];
-                if (sn >= lo && sn <= hi) atomicAdd(&hist[(uint64_t)(sn - lo) * A + (cd.cell_aq[c] >> 8)], 1u);
+                if (sn >= lo && sn <= hi) atomicAdd(&hist[(uint64_t)(sn - lo) * A + (cd.cell_aw[c] >> 28)], 1u);
             }
         }
         __syncthreads();
