@@ -348,7 +348,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
                     ts1 += shfl_u64(t1, seg0 + (int)j);
                     ts2 += shfl_u64(t2, seg0 + (int)j);
                 }
-                for (uint32_t j = 0; j < p; ++j) sum += exp(shfl_f64(pv, seg0 + (int)j) - mx);
+                const double ex = exp(pv - mx);              // own term once; summed in the reference's order j = 0..p-1
+                for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
                 const double lse = mx + log(sum);
                 bool pass = false;
                 uint64_t ch1 = 0, ch2 = 0, cq = 0, cs = 0;

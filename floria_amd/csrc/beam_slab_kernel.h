@@ -23,6 +23,8 @@
 namespace fl {
 
 constexpr int SLAB_TILE = 256;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 // segmented all-reduce (sum) over aligned groups of Gs = 2,4,8,16 lanes with DPP row operations
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
@@ -59,7 +61,8 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
     const uint32_t NS = LM * p;
     uint32_t o = 0;
     auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15) & ~15u; return r; };
-    L.off_coff = take(SLAB_TILE * 4); L.off_caw = take(SLAB_TILE * 4);
+    // cells of a read (first tile: raw SNP index and attribute word), double-buffered: read i+1 arrives by LDS-DMA during step i
+    L.off_coff = take(2 * SLAB_TILE * 4); L.off_caw = take(2 * SLAB_TILE * 4);
     L.off_crp1 = take(q0 ? SLAB_TILE * 8 : 0); L.off_crp2 = take(q0 ? SLAB_TILE * 8 : 0);
     for (int i = 0; i < 2; ++i) {
         L.off_q[i] = take(LM * 8); L.off_h1[i] = take(LM * 8); L.off_h2[i] = take(LM * 8); L.off_m[i] = take(LM * 4);
@@ -90,10 +93,10 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t lane = threadIdx.x;
     const uint32_t p = g.ploidy, B = g.beam, LM = p * B, NS = LM * p;
     const SlabLds LY = slab_lds_layout(LM, p, Q0);
-    uint32_t* c_off = (uint32_t*)(smem + LY.off_coff);
-    uint32_t* c_aw  = (uint32_t*)(smem + LY.off_caw);
-    uint64_t* c_rp1 = (uint64_t*)(smem + LY.off_crp1);
-    uint64_t* c_rp2 = (uint64_t*)(smem + LY.off_crp2);
+    uint32_t* const c_snp_base = (uint32_t*)(smem + LY.off_coff);
+    uint32_t* const c_aw_base  = (uint32_t*)(smem + LY.off_caw);
+    uint64_t* const c_rp1 = (uint64_t*)(smem + LY.off_crp1);       // q=0 pileups only: presence-hash words of the current tile
+    uint64_t* const c_rp2 = (uint64_t*)(smem + LY.off_crp2);
     uint16_t* live_id = (uint16_t*)(smem + LY.off_live);
     uint16_t* s2l = (uint16_t*)(smem + LY.off_s2l);
     uint8_t*  ref = (uint8_t*)(smem + LY.off_ref);
@@ -113,6 +116,7 @@ void beam_slab_kernel(BeamArgs g) {
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
     uint64_t* r_t1 = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS));      // tail of the slot's traceback region (host reserves it)
     uint64_t* r_t2 = r_t1 + NS;
+    uint64_t* dummy = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS - 128));      // 64 scratch words for branch-free tails
     const uint64_t lane_lt = (1ull << lane) - 1;
 
     const uint32_t S = 64 / p;
@@ -124,6 +128,7 @@ void beam_slab_kernel(BeamArgs g) {
     uint32_t n_fallback = 0;
 #ifdef FLORIA_PROF
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
+    const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
 #endif
 
     for (;;) {
@@ -155,62 +160,74 @@ void beam_slab_kernel(BeamArgs g) {
         uint64_t ev_s = 0, ev_h1 = 0, ev_h2 = 0, ev_q = 0;
         uint32_t ev_m = 0, ev_pk = 0;
         RegHeap H; H.hp_s = 0; H.hp_id = 0; H.len = 0;
-        // software pipeline over reads: metadata two reads ahead, the first tile's cells one read ahead
-        struct Meta { uint32_t cbeg, L, first, last; uint64_t tw1, tw2; };
-        auto load_meta = [&](uint32_t r) { Meta m; m.cbeg = sload(cd.read_off + r); m.L = sload(cd.read_off + r + 1) - m.cbeg; m.first = sload(cd.first + r); m.last = sload(cd.last + r);
-                                           m.tw1 = sload(cd.tw + 2 * (uint64_t)r); m.tw2 = sload(cd.tw + 2 * (uint64_t)r + 1); return m; };
-        uint32_t pf_snp[SLAB_TILE / 64], pf_aq[SLAB_TILE / 64];
-        auto load_cells = [&](const Meta& m) {
-#pragma unroll
-            for (int u = 0; u < SLAB_TILE / 64; ++u) {
-                const uint32_t c = lane + 64 * u;
-                const bool v = c < m.L;
-                pf_snp[u] = v ? cd.cell_snp[m.cbeg + c] : 0;
-                pf_aq[u] = v ? cd.cell_aw[m.cbeg + c] : 0;
+        // software pipeline over reads (every request is issued in the shadow of phase A's slab loads):
+        //   step i top:   LDS buffer i&1 holds read i's cells (raw snp / attribute words, written by LDS-DMA during step i-1),
+        //                 SGPRs hold cell metadata (offset, length) of reads i, i+1 and step metadata of reads i, i+1
+        //   step i, in A: LDS-DMA of read i+1's cells into buffer (i+1)&1 (two global_load_lds_dwordx4: no VGPRs, no ds_write),
+        //                 scalar loads of the metadata of read i+2 and of the id of read i+3
+        // Metadata travels through the VECTOR memory pipe (scalar loads share lgkmcnt with LDS and would stall every LDS wait of
+        // the step): lanes 0..7 fetch the packed 32-B record of a read one step before it is needed, v_readlane turns it into SGPRs;
+        // read ids come 64 at a time (lane j = reads[base + j]).
+        struct CellMeta { uint32_t cbeg, L; };
+        struct StepMeta { uint32_t first, last; uint64_t tw1, tw2; };
+        auto load_rec = [&](uint32_t r) -> uint32_t { return lane < 8 ? cd.meta[8 * (uint64_t)r + lane] : 0u; };
+        auto rec_cm = [&](uint32_t v) { CellMeta m; m.cbeg = rl32(v, 0); m.L = rl32(v, 1); return m; };
+        auto rec_sm = [&](uint32_t v) { StepMeta m; m.first = rl32(v, 2); m.last = rl32(v, 3);
+                                        m.tw1 = ((uint64_t)rl32(v, 5) << 32) | rl32(v, 4); m.tw2 = ((uint64_t)rl32(v, 7) << 32) | rl32(v, 6); return m; };
+        // lane l moves cells 4l..4l+3 (16 B) of each array; the LDS image is lane-linear = cell order.  The last lane may read up to
+        // 3 cells past the read (the next read's cells or the arrays' 16-B tail padding, see floria_hip_contig_upload); never used.
+        auto dma_cells = [&](uint32_t w, const CellMeta& m) {
+            if (m.L <= (uint32_t)SLAB_TILE && 4 * lane < m.L) {
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(cd.cell_snp + m.cbeg + 4 * lane), (lds_void*)(c_snp_base + w * SLAB_TILE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(cd.cell_aw + m.cbeg + 4 * lane), (lds_void*)(c_aw_base + w * SLAB_TILE), 16, 0, 0);
             }
         };
-        Meta m_cur = load_meta(sload(reads));
-        Meta m_next = m_cur;
-        if (n > 1) m_next = load_meta(sload(reads + 1));
-        uint32_t r_next2 = n > 2 ? sload(reads + 2) : 0;
-        load_cells(m_cur);
+        uint64_t rpb1 = 0, rpb2 = 0;
+        uint32_t rid_vec = lane < n ? reads[lane] : 0;                  // ids of reads [0, 64)
+        uint32_t rec_n2 = 0;                                             // record of read i+2 (in flight during step i)
+        CellMeta cm_cur, cm_next;
+        StepMeta sm_cur, sm_next;
+        {
+            const uint32_t rec0 = load_rec(rl32(rid_vec, 0));
+            const uint32_t rec1 = load_rec(rl32(rid_vec, n > 1 ? 1 : 0));
+            cm_cur = rec_cm(rec0); sm_cur = rec_sm(rec0);
+            cm_next = rec_cm(rec1); sm_next = rec_sm(rec1);
+        }
+        __syncthreads();
+        dma_cells(0, cm_cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t cbeg = m_cur.cbeg, L = m_cur.L;
-            const uint32_t first_rel = m_cur.first - pos0;
-            const int32_t  last_rel = (int32_t)(m_cur.last - pos0);
-            const uint64_t tw1 = m_cur.tw1, tw2 = m_cur.tw2;
-            // metadata of read i+2 is requested now and consumed two steps later
-            Meta m_next2 = m_next;
-            if (i + 2 < n) m_next2 = load_meta(r_next2);
-            if (i + 3 < n) r_next2 = sload(reads + i + 3);
+            const uint32_t cbeg = cm_cur.cbeg, L = cm_cur.L;
+            const uint32_t first_rel = sm_cur.first - pos0;
+            const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
+            const uint64_t tw1 = sm_cur.tw1, tw2 = sm_cur.tw2;
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
             const uint32_t ntiles = (L + SLAB_TILE - 1) / SLAB_TILE;
+            const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
             uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);
             uint32_t* st_m = ST_m(cur); uint16_t* st_sl = ST_sl(cur);
+            uint32_t* const c_snp = c_snp_base + (i & 1) * SLAB_TILE;
+            uint32_t* const c_aw  = c_aw_base + (i & 1) * SLAB_TILE;
 
-            uint64_t rpb1 = 0, rpb2 = 0;
             uint32_t nin = 0;
-            auto stage_tile = [&](uint32_t t, bool from_regs) {
-                __syncthreads();
+            // number of the tile's cells at written positions (<= hi_rel; a prefix, cells ascend) and, for q=0 pileups,
+            // the presence-hash words of the cells (LDS) and their sum over the cells beyond hi_rel
+            auto scan_tile = [&](uint32_t tl) {
                 uint32_t cnt_in = 0;
                 uint64_t b1 = 0, b2 = 0;
+                uint32_t snps[SLAB_TILE / 64];
+#pragma unroll
+                for (int u = 0; u < SLAB_TILE / 64; ++u) snps[u] = c_snp[lane + 64 * u];       // (stale words beyond tl are masked below)
 #pragma unroll
                 for (int u = 0; u < SLAB_TILE / 64; ++u) {
                     const uint32_t c = lane + 64 * u;
-                    const uint32_t cc = t * SLAB_TILE + c;
-                    bool in = false;
-                    if (cc < L) {
-                        const uint32_t snp = from_regs ? pf_snp[u] : cd.cell_snp[cbeg + cc];
-                        const uint32_t aq = from_regs ? pf_aq[u] : (uint32_t)cd.cell_aw[cbeg + cc];
-                        const uint32_t pr = snp - pos0;
-                        const uint32_t al = aq >> 28;
-                        c_off[c] = pr * pos_bytes;
-                        c_aw[c] = (al << 28) | (aq & 0x0fffffffu);
-                        in = (int32_t)pr <= hi_rel;
-                        if (Q0) {
-                            const uint64_t r1 = g.Rp1[hash_idx(snp, al)], r2 = g.Rp2[hash_idx(snp, al)];
+                    const bool in = c < tl && (int32_t)(snps[u] - pos0) <= hi_rel;
+                    if (Q0) {
+                        if (c < tl) {
+                            const uint32_t hx = hash_idx(snps[u], c_aw[c] >> 28);
+                            const uint64_t r1 = g.Rp1[hx], r2 = g.Rp2[hx];
                             c_rp1[c] = r1; c_rp2[c] = r2;
                             if (!in) { b1 += r1; b2 += r2; }
                         }
@@ -219,11 +236,31 @@ void beam_slab_kernel(BeamArgs g) {
                 }
                 nin = uni(cnt_in);
                 if (Q0) { rpb1 = wave_sum_u64(b1); rpb2 = wave_sum_u64(b2); }
+            };
+            // multi-tile reads (L > SLAB_TILE) stage every tile from HBM inside the phases that walk the cells
+            auto stage_tile = [&](uint32_t t) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < SLAB_TILE / 64; ++u) {
+                    const uint32_t c = lane + 64 * u;
+                    const uint32_t cc = t * SLAB_TILE + c;
+                    if (cc < L) { c_snp[c] = cd.cell_snp[cbeg + cc]; c_aw[c] = cd.cell_aw[cbeg + cc]; }
+                }
+                __syncthreads();
+                scan_tile(min((uint32_t)SLAB_TILE, L - t * SLAB_TILE));
                 __syncthreads();
             };
-            if (ntiles == 1) stage_tile(0, true);
-            if (i + 1 < n) load_cells(m_next);           // the prefetch registers are free again: request the next read's cells now,
-                                                         // their latency hides behind this step's slab loads
+            if (ntiles == 1) { scan_tile(L); if (Q0) __syncthreads(); }
+            // issued ahead of phase A's slab loads (same in-order pipe, so no wait of its own): cells of read i+1 by LDS-DMA,
+            // record of read i+2, and every 64 steps the next 64 read ids
+            if (i + 1 < n) dma_cells((i + 1) & 1, cm_next);
+            if (i + 2 < n) {
+                if (((i + 2) & 63) == 0) {               // (the wait stays inside this branch: at the join hipcc would wait vmcnt(0) every step)
+                    const uint32_t nv = (i + 2 + lane < n) ? reads[i + 2 + lane] : 0;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(rid_vec) : "v"(nv));
+                }
+                rec_n2 = load_rec(rl32(rid_vec, (i + 2) & 63));
+            }
             BEAM_TICK(0);
 
             // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
@@ -281,15 +318,17 @@ void beam_slab_kernel(BeamArgs g) {
                     if (Q0) { const bool np = valid && !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
                 };
                 for (uint32_t t = 0; t < ntiles; ++t) {
-                    if (ntiles > 1) stage_tile(t, false);
+                    if (ntiles > 1) stage_tile(t);
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                    // SLAB_U independent 16-B loads in flight per lane; the loop is wave-uniform (invalid slots and idle lanes read
+                    // cell 0 of a slab with weight 0: no branches), and the next read is staged behind the first batch of loads
                     if (act) {
-                        for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_U * Gs) {       // SLAB_U independent loads in flight per lane
+                        for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_U * Gs) {
                             uint32_t offs[SLAB_U], aws[SLAB_U];
 #pragma unroll
-                            for (int u = 0; u < SLAB_U; ++u) {      // invalid slots read cell 0 of the slab with weight 0: no branches
+                            for (int u = 0; u < SLAB_U; ++u) {
                                 const uint32_t c = c0 + u * Gs; const bool v = c < nin; const uint32_t cx = v ? c : 0;
-                                offs[u] = c_off[cx]; aws[u] = v ? c_aw[cx] : 0;
+                                offs[u] = (c_snp[cx] - pos0) * pos_bytes; aws[u] = v ? c_aw[cx] : 0;
                             }
                             ulonglong2 vv[SLAB_U][A / 2];
 #pragma unroll
@@ -303,8 +342,8 @@ void beam_slab_kernel(BeamArgs g) {
                             for (int u = 0; u < SLAB_U; ++u) cell(vv[u], aws[u], c0 + u * Gs, c0 + u * Gs < nin);
                             qs += ps; qd += pd;
                         }
-                        if (sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }   // cells beyond hi_rel (:45-48)
                     }
+                    if (act && sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }   // cells beyond hi_rel (:45-48)
                 }
                 // segmented all-reduce over the Gs lanes of a slab (DPP, no LDS crossbar)
                 qs = seg_sum_u64(qs, Gs); qd = seg_sum_u64(qd, Gs); m = seg_sum_u32(m, Gs);
@@ -316,6 +355,11 @@ void beam_slab_kernel(BeamArgs g) {
                     if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of the next read has landed (hipcc does not track it)
+            // Pin the record's wait HERE, where nothing younger is in flight: consumed at the end of the step, hipcc would wait
+            // vmcnt(0) there and stall on the acknowledgements of the step's slab stores.
+            uint32_t rec_hold;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(rec_hold) : "v"(rec_n2));
             __syncthreads();
             BEAM_TICK(1);
 
@@ -346,7 +390,8 @@ void beam_slab_kernel(BeamArgs g) {
                     mx = (j == 0) ? o : (o > mx ? o : mx);
                 }
                 if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
-                for (uint32_t j = 0; j < p; ++j) sum += exp(shfl_f64(pv, seg0 + (int)j) - mx);
+                const double ex = exp(pv - mx);              // each lane evaluates its own term once; the sum runs in the reference's order j = 0..p-1
+                for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
                 const double lse = mx + log(sum);
                 bool pass = false;
                 uint64_t ch1 = 0, ch2 = 0, cq = 0, cs = 0;
@@ -382,7 +427,6 @@ void beam_slab_kernel(BeamArgs g) {
 
             // ---- M: survivors (lane j = heap slot j = next state j) and their slabs -----------------------------------
             const uint32_t nnext = H.len;
-            const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
             const bool surv = lane < nnext;
             const uint32_t eid = surv ? H.hp_id : 0;
             const uint64_t n_q = shfl_u64(ev_q, (int)eid), n_h1 = shfl_u64(ev_h1, (int)eid), n_h2 = shfl_u64(ev_h2, (int)eid);
@@ -482,27 +526,35 @@ void beam_slab_kernel(BeamArgs g) {
                 // leaders' target slabs, compacted into freelist[] (reused as scratch)
                 if (lead) freelist[__popcll(lmask & lane_lt)] = newid[u_old];
                 for (uint32_t t = 0; t < ntiles; ++t) {
-                    if (ntiles > 1) stage_tile(t, false); else __syncthreads();
+                    if (ntiles > 1) stage_tile(t); else __syncthreads();
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
                     const uint32_t items = nlead * tl;
                     auto addr_of = [&](uint32_t x, uint32_t& w) -> uint64_t* {
                         const uint32_t e = x / tl, c = x - e * tl;
                         const uint32_t aw = c_aw[c];
                         w = aw & 0x0fffffffu;
-                        return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + c_off[c] + (aw >> 28) * 8));
+                        return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + (c_snp[c] - pos0) * pos_bytes + (aw >> 28) * 8));
                     };
-                    for (uint32_t x = lane; x < items; x += 256) {          // 4 read-modify-writes in flight per lane; the tail
-                        uint32_t w[4]; uint64_t* ptr[4]; uint64_t v[4];     // slots load item 0 (harmless) and skip the store
+                    // 4 read-modify-writes in flight per lane, branch-free: the tail slots go to the lane's dummy word in the slot's
+                    // scratch.  (A load left unconsumed on some path makes hipcc wait vmcnt(0) at the top of the next step, i.e.
+                    // for the acknowledgement of these stores, before phase A can issue its loads.)
+                    for (uint32_t x0 = 0; x0 < items; x0 += 256) {
+                        uint32_t w[4]; uint64_t* ptr[4]; uint64_t v[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { const uint32_t xx = x + 64 * u; ptr[u] = addr_of(xx < items ? xx : 0, w[u]); }
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t xx = x0 + lane + 64 * u;
+                            uint64_t* pa = addr_of(xx < items ? xx : 0, w[u]);
+                            ptr[u] = xx < items ? pa : dummy + lane;
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) v[u] = *ptr[u];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (x + 64 * u < items) *ptr[u] = Q0 ? ((v[u] + w[u]) | PRESENT_BIT) : v[u] + w[u];
+                        for (int u = 0; u < 4; ++u) *ptr[u] = Q0 ? ((v[u] + w[u]) | PRESENT_BIT) : v[u] + w[u];
                     }
                 }
             }
-            m_cur = m_next; m_next = m_next2;
+            cm_cur = cm_next; sm_cur = sm_next;
+            if (i + 2 < n) { cm_next = rec_cm(rec_hold); sm_next = rec_sm(rec_hold); }
             __syncthreads();
             BEAM_TICK(5);
             cur ^= 1;
@@ -535,7 +587,8 @@ void beam_slab_kernel(BeamArgs g) {
         BEAM_TICK(6);
     }
 #ifdef FLORIA_PROF
-    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g.prof[16 + i], t_acc[i]);
+    if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g.prof[16 + i], t_acc[i]);
+                     atomicAdd(&g.prof[24], wall_clock64() - t_wall0); atomicAdd(&g.prof[25], clock64() - t_core0); atomicAdd(&g.prof[26], 1ull); }
 #endif
     min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 uint64_t ts1 = 0, ts2 = 0;
                 for (uint32_t j = 0; j < p; ++j) { const double o = shfl_f64(pv, seg0 + (int)j); mx = (j == 0) ? o : (o > mx ? o : mx); }
                 if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
-                for (uint32_t j = 0; j < p; ++j) sum += exp(shfl_f64(pv, seg0 + (int)j) - mx);
+                const double ex = exp(pv - mx);              // own term once; summed in the reference's order j = 0..p-1
+                for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
                 const double lse = mx + log(sum);
                 bool pass = false;
                 uint64_t ch1 = 0, ch2 = 0, cq = 0;

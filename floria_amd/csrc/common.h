@@ -26,6 +26,7 @@ struct ContigDev {
     const uint32_t* cell_snp;   // [n_cells] 1-based SNP index
     const uint32_t* cell_aw;    // [n_cells] allele << 28 | Q24 quality weight (w(q) <= 2^24), precomputed at upload
     const uint64_t* tw;         // [2*n_reads] per-read hash constants: sum over cells of Rq{1,2}[hash_idx(snp, allele)] * w
+    const uint32_t* meta;       // [8*n_reads] packed per-read record {cell offset, cell count, first, last, tw1 lo/hi, tw2 lo/hi}: one 32-B load per beam step
     uint32_t        n_reads;
     uint32_t        pad;
 };

@@ -113,7 +113,7 @@ struct floria_hip_contig {
     uint32_t n_alleles = 2;     // 2 or 4 (kernel template)
     bool has_q0 = false;        // some cell has qual 0 (weight 0): presence != (weight sum > 0)
     std::vector<uint32_t> h_first, h_last, h_read_off;
-    DevBuf d_read_off, d_first, d_last, d_snp, d_aq, d_tw;
+    DevBuf d_read_off, d_first, d_last, d_snp, d_aq, d_tw, d_meta;
     fl::ContigDev dev{};
 };
 
@@ -247,7 +247,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         } else {
             const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
             // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
-            const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));
+            const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 128 + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + 64 dummy u64 words (beam_slab_kernel's branch-free tails)
             const fl::SlabLds SL0 = fl::slab_lds_layout(LM, p, any_q0);
             const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL0.total + 256)));
             uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * FLORIA_FAST_WAVES, by_lds);
@@ -481,6 +481,7 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     c->h_read_off.assign(p->read_off, p->read_off + p->n_reads + (p->n_reads ? 1 : 0));
     std::vector<uint32_t> aq(nc);     // allele << 28 | Q24 weight of the cell (weights are < 2^24)
     std::vector<uint64_t> tw((size_t)p->n_reads * 2, 0);
+    std::vector<uint32_t> meta((size_t)p->n_reads * 8, 0);
     for (uint32_t r = 0; r < p->n_reads; ++r) {
         uint64_t t1 = 0, t2 = 0;
         for (uint64_t i = p->read_off[r]; i < p->read_off[r + 1]; ++i) {
@@ -491,9 +492,12 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
             t1 += ctx->h_rq1[idx] * w; t2 += ctx->h_rq2[idx] * w;
         }
         tw[2 * (size_t)r] = t1; tw[2 * (size_t)r + 1] = t2;
+        uint32_t* mr = &meta[8 * (size_t)r];
+        mr[0] = p->read_off[r]; mr[1] = p->read_off[r + 1] - p->read_off[r]; mr[2] = p->first[r]; mr[3] = p->last[r];
+        mr[4] = (uint32_t)t1; mr[5] = (uint32_t)(t1 >> 32); mr[6] = (uint32_t)t2; mr[7] = (uint32_t)(t2 >> 32);
     }
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
-        int r2 = b.ensure(std::max<size_t>(bytes, 16));
+        int r2 = b.ensure(bytes + 16);            // 16-B tail padding: the beam kernel's LDS-DMA moves cells in 16-B pieces
         if (r2) return r2;
         if (bytes) { hipError_t e = hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return fail(FLORIA_E_DEVICE, hipGetErrorString(e)); }
         return 0;
@@ -504,16 +508,17 @@ int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria
     if (!rc) rc = up(c->d_snp, p->snp, nc * 4);
     if (!rc) rc = up(c->d_aq, aq.data(), nc * 4);
     if (!rc) rc = up(c->d_tw, tw.data(), tw.size() * 8);
+    if (!rc) rc = up(c->d_meta, meta.data(), meta.size() * 4);
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(FLORIA_E_DEVICE, "upload sync failed");
     if (rc) { floria_hip_contig_free(c); return rc; }
     c->dev.read_off = c->d_read_off.as<uint32_t>(); c->dev.first = c->d_first.as<uint32_t>(); c->dev.last = c->d_last.as<uint32_t>();
-    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aw = c->d_aq.as<uint32_t>(); c->dev.tw = c->d_tw.as<uint64_t>(); c->dev.n_reads = p->n_reads;
+    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aw = c->d_aq.as<uint32_t>(); c->dev.tw = c->d_tw.as<uint64_t>(); c->dev.meta = c->d_meta.as<uint32_t>(); c->dev.n_reads = p->n_reads;
     *out = c;
     return 0;
 }
 void floria_hip_contig_free(floria_hip_contig* c) {
     if (!c) return;
-    for (DevBuf* b : {&c->d_read_off, &c->d_first, &c->d_last, &c->d_snp, &c->d_aq, &c->d_tw}) b->release();
+    for (DevBuf* b : {&c->d_read_off, &c->d_first, &c->d_last, &c->d_snp, &c->d_aq, &c->d_tw, &c->d_meta}) b->release();
     delete c;
 }
 
