@@ -53,7 +53,8 @@ class CTiming(C.Structure):
                 ("reassign_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("total_ms", C.c_double), ("beam_launches", C.c_uint32), ("optimize_launches", C.c_uint32),
                 ("algorithmic_bytes", C.c_uint64), ("beam_steps", C.c_uint64),
-                ("beam_launch_bytes", C.c_uint64), ("jobs", C.c_uint64)]
+                ("beam_launch_bytes", C.c_uint64), ("jobs", C.c_uint64),
+                ("streams", C.c_uint32), ("reserved", C.c_uint32), ("phase_ms", C.c_double)]
 
 
 def ptr(a, ctype):

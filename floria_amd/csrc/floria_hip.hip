@@ -81,8 +81,13 @@ uint64_t splitmix64(uint64_t& s) {
 struct floria_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint32_t user_slots = 0;
+    uint32_t user_slots = 0, user_groups = 0;
     int n_cu = 256;
+    // job groups: the (block, ploidy) launch triples of disjoint block groups run on their own streams, so one group's
+    // launch tail (persistent waves draining their last jobs) is filled by the other groups' kernels
+    static constexpr uint32_t MAX_GROUPS = 8;
+    hipStream_t gstream[MAX_GROUPS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
     // cached tables
     double binom_eps = -1.0;
     uint32_t binom_nmax = 0;
@@ -199,14 +204,16 @@ struct EventTimer {
     hipStream_t s;
     explicit EventTimer(hipStream_t st) : s(st) {}
     ~EventTimer() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
-    int begin(int k) {
+    std::vector<hipStream_t> on;
+    int begin(int k, hipStream_t st = nullptr) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
-        ev.push_back({a, b}); kind.push_back(k);
-        (void)hipEventRecord(a, s);
+        ev.push_back({a, b}); kind.push_back(k); on.push_back(st ? st : s);
+        (void)hipEventRecord(a, on.back());
         return (int)ev.size() - 1;
     }
-    void end(int i) { if (i >= 0) (void)hipEventRecord(ev[i].second, s); }
+    void end(int i) { if (i >= 0) (void)hipEventRecord(ev[i].second, on[i]); }
+    double elapsed(int i) { float ms = 0; if (i >= 0 && hipEventElapsedTime(&ms, ev[i].first, ev[i].second) == hipSuccess) return ms; return 0; }
     double sum(int k) {
         double t = 0;
         for (size_t i = 0; i < ev.size(); ++i) if (kind[i] == k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[i].first, ev[i].second) == hipSuccess) t += ms; }
@@ -219,149 +226,202 @@ struct EventTimer {
         return ms;
     }
 };
-enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5 };
+enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5, K_PHASE = 6 };
 
+void sync_all(floria_hip_ctx* ctx) {
+    for (uint32_t g = 0; g < floria_hip_ctx::MAX_GROUPS; ++g) if (ctx->gstream[g]) (void)hipStreamSynchronize(ctx->gstream[g]);
+    (void)hipStreamSynchronize(ctx->stream);
+}
+
+// One launch triple (beam -> optimise -> stop rule) per ploidy and JOB GROUP.  `jobs` holds the non-empty blocks, longest
+// first inside each group; group g owns jobs [group_off[g], group_off[g+1]) and runs on its own stream with its own scratch.
 template <int A>
-int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const uint32_t* d_jobs,
-              uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
+int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const std::vector<uint32_t>& group_off,
+              const uint32_t* d_jobs, uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
               uint8_t* d_beam_part, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
               uint32_t* d_tried, uint32_t* d_queue, unsigned long long* d_margin, uint32_t* d_diag,
               unsigned long long* d_steps, EventTimer& T, bool& p1_shortcut) {
     const uint32_t P = prm->max_ploidy, B = prm->beam;
     p1_shortcut = false;
     const uint32_t n_jobs = (uint32_t)jobs.size();
+    const uint32_t G = (uint32_t)group_off.size() - 1;
+    if (n_jobs == 0) return 0;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const double cutoff = std::log(PROB_CUTOFF);      // graph_processing.rs:146
+    // fork: every group stream starts after what the main stream has queued so far (uploads, memsets, block_reads_kernel)
+    hipStream_t gs[floria_hip_ctx::MAX_GROUPS];
+    gs[0] = ctx->stream;
+    if (G > 1) {
+        if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for (uint32_t g = 1; g < G; ++g) {                 // group 0 stays on the main stream (HIP maps streams onto few hardware queues)
+            if (!ctx->gstream[g]) HIPCHK(hipStreamCreateWithFlags(&ctx->gstream[g], hipStreamNonBlocking));
+            if (!ctx->ev_join[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[g], hipEventDisableTiming));
+            gs[g] = ctx->gstream[g];
+        }
+    }
+    const int t_phase = T.begin(K_PHASE);
+    bool forked = false;
+    auto fork = [&]() -> int {
+        if (G > 1 && !forked) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            for (uint32_t g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(gs[g], ctx->ev_fork, 0));
+            forked = true;
+        }
+        return 0;
+    };
     for (uint32_t p = 1; p <= P; ++p) {
-        (void)cutoff;
-        if (n_jobs == 0) break;
         const uint32_t LM = p * B;
         if (LM > 65000) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam too large");
         // ---- beam search ---------------------------------------------------------------------------------------
         // ploidy 1 has nothing to search: one state, one partition, every child passes (p_k - lse == 0 > ln 0.01), the
         // partition is "all reads in haplotype 0" (global_clustering.rs:74-134 with ploidy == 1) -> a memset.
-        if (p == 1 && !getenv("FLORIA_HIP_NO_P1_SHORTCUT")) {
+        const bool shortcut = p == 1 && !getenv("FLORIA_HIP_NO_P1_SHORTCUT");
+        if (shortcut) {
             HIPCHK(hipMemsetAsync(d_beam_part, 0, tot_reads, ctx->stream));
             p1_shortcut = true;
-        } else {
-            const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
-            // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
-            const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 128 + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + 64 dummy u64 words (beam_slab_kernel's branch-free tails)
-            const fl::SlabLds SL0 = fl::slab_lds_layout(LM, p, any_q0);
-            const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL0.total + 256)));
-            uint32_t slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * FLORIA_FAST_WAVES, by_lds);
-            slots = std::min(slots, n_jobs);
-            const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
-            while (slots > 1 && (state_bytes + hist_stride * 4) * slots > budget) slots /= 2;
-            int rc = ctx->state_pool.ensure(state_bytes * slots); if (rc) return rc;
-            rc = ctx->hist_pool.ensure(hist_stride * 4 * slots); if (rc) return rc;
-            fl::BeamArgs a{};
-            a.bs = bs; a.job_block = d_jobs; a.n_jobs = n_jobs; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
-            a.queue_head = d_queue; a.blk_done = d_done;
-            a.state_pool = ctx->state_pool.as<uint64_t>(); a.hist_pool = ctx->hist_pool.as<uint32_t>(); a.hist_stride = hist_stride;
-            a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
-            a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
-            const uint64_t* H = ctx->d_hash.as<uint64_t>();
-            a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
-            a.part_out = d_beam_part; a.min_margin_bits = d_margin; a.diag = d_diag; a.steps_done = d_steps;
-            a.prof = (unsigned long long*)(d_diag + 4);
-            const fl::BeamLds LY = fl::beam_lds_layout(LM);
+        }
+        if (int rc = fork()) return rc;
+        // sizes shared by the groups of this ploidy
+        const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
+        // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
+        const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 128 + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + 64 dummy u64 words (beam_slab_kernel's branch-free tails)
+        const fl::SlabLds SL = fl::slab_lds_layout(LM, p, any_q0);
+        const fl::WideLds WL = fl::wide_lds_layout(LM, p, any_q0);
+        const fl::BeamLds LY = fl::beam_lds_layout(LM);
+        const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL.total + 256)));
+        uint32_t beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * FLORIA_FAST_WAVES, by_lds);
+        beam_slots = std::min(beam_slots, n_jobs);
+        const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
+        while (beam_slots > 1 && (state_bytes + hist_stride * 4) * beam_slots * G > budget) beam_slots /= 2;
+        const char* force = getenv("FLORIA_HIP_BEAM");       // dev/test knob: generic | fast | slab | wide
+        const bool fits32 = (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull;
+        const bool small = LM <= 63 && fits32;
+        bool wide = !small && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && WL.total <= 150 * 1024;
+        if (force && !strcmp(force, "wide") && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && WL.total <= 150 * 1024) wide = true;
+        if (force && strcmp(force, "wide")) wide = false;
+        bool slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && SL.total <= 60 * 1024;
+        bool fast = small;
+        if (force && !strcmp(force, "generic")) { slab = false; fast = false; }
+        if (force && !strcmp(force, "fast")) slab = false;
+        if (!shortcut) {
+            int rc = ctx->state_pool.ensure(state_bytes * beam_slots * G); if (rc) return rc;
+            rc = ctx->hist_pool.ensure(hist_stride * 4 * beam_slots * G); if (rc) return rc;
             if (LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
-            if (LY.total > 48 * 1024)
+            if (!wide && !slab && !fast && LY.total > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void*)fl::beam_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY.total));
-            HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
-            const char* force = getenv("FLORIA_HIP_BEAM");       // dev/test knob: generic | fast | slab | wide
-            const bool fits32 = (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull;
-            const bool small = LM <= 63 && fits32;
-            const fl::WideLds WL = fl::wide_lds_layout(LM, p, any_q0);
-            bool wide = !small && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && WL.total <= 150 * 1024;
-            if (force && !strcmp(force, "wide") && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && WL.total <= 150 * 1024) wide = true;
-            if (force && strcmp(force, "wide")) wide = false;
-            const fl::SlabLds SL = fl::slab_lds_layout(LM, p, any_q0);
-            bool slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && SL.total <= 60 * 1024;
-            bool fast = small;
-            if (force && !strcmp(force, "generic")) { slab = false; fast = false; }
-            if (force && !strcmp(force, "fast")) slab = false;
-            int t = T.begin(K_BEAM);
-            if (wide) {
-                const uint32_t wslots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (WL.total + 512))));
-                if (WL.total > 48 * 1024) {
-                    if (any_q0) HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
-                    else HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
-                }
-                if (any_q0) hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(wslots), dim3(64), WL.total, ctx->stream, a);
-                else hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(wslots), dim3(64), WL.total, ctx->stream, a);
-            } else if (slab) {
-                if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), SL.total, ctx->stream, a);
-                else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), SL.total, ctx->stream, a);
-            } else if (fast) {
-                const fl::FastLds FL = fl::fast_lds_layout(LM, any_q0);
-                if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, ctx->stream, a);
-                else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, ctx->stream, a);
-            } else
-                hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), LY.total, ctx->stream, a);
-            T.end(t);
-            HIPCHK(hipGetLastError());
-            ctx->timing.beam_launches++;
+            if (wide && WL.total > 48 * 1024) {
+                if (any_q0) HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
+                else HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
+            }
         }
-        // ---- optimise + MEC stats ----------------------------------------------------------------------------------
+        // optimise: sizes
+        uint64_t cand_cap = 1;
+        while (cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) cand_cap <<= 1;
+        const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
+        const uint32_t threads = mean_n >= 384 ? 1024 : (mean_n >= 96 ? 512 : 128);
+        const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
+        const size_t hist_bytes = (size_t)span_max * p * A * 8;
+        const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
+        const bool hl = hist_bytes + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
+        const size_t lds = moved_bytes + meta_bytes + (hl ? hist_bytes : 0) + 16;
+        uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads));
+        per_cu = std::min<uint32_t>(per_cu, 8);
+        const uint32_t opt_slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, n_jobs);
         {
-            uint64_t cand_cap = 1;
-            while (cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) cand_cap <<= 1;
-            const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
-            const uint32_t threads = mean_n >= 384 ? 1024 : (mean_n >= 96 ? 512 : 128);
-            const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
-            const size_t hist_bytes = (size_t)span_max * p * A * 8;
-            const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
-            const bool hl = hist_bytes + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
-            const size_t lds = moved_bytes + meta_bytes + (hl ? hist_bytes : 0) + 16;
-            uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads));
-            per_cu = std::min<uint32_t>(per_cu, 8);
-            const uint32_t slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, n_jobs);
-            int rc = ctx->opt_hist.ensure((uint64_t)slots * span_max * p * A * 8); if (rc) return rc;
-            rc = ctx->opt_dist.ensure((uint64_t)slots * n_max * p * 8); if (rc) return rc;
-            rc = ctx->opt_gain.ensure((uint64_t)slots * cand_cap * 8); if (rc) return rc;
-            rc = ctx->opt_key.ensure((uint64_t)slots * cand_cap * 4); if (rc) return rc;
-            rc = ctx->opt_moves.ensure((uint64_t)slots * n_max * 4); if (rc) return rc;
-            fl::OptArgs a{};
-            a.bs = bs; a.job_block = d_jobs; a.n_jobs = n_jobs; a.ploidy = p; a.max_ploidy = P; a.span_max = span_max; a.n_max = n_max;
-            a.queue_head = d_queue; a.blk_done = d_done; a.eps = prm->epsilon;
-            a.part_in = d_beam_part; a.part_out = d_planes + (uint64_t)(p - 1) * tot_reads;
-            a.hist_pool = ctx->opt_hist.as<uint64_t>(); a.dist_pool = ctx->opt_dist.as<double>();
-            a.cand_gain_pool = ctx->opt_gain.as<uint64_t>(); a.cand_key_pool = ctx->opt_key.as<uint32_t>();
-            a.moves_pool = ctx->opt_moves.as<uint32_t>(); a.cand_cap = cand_cap;
-            a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
-            a.prof = (unsigned long long*)(d_diag + 4);
-            HIPCHK(hipMemsetAsync(d_queue, 0, 4, ctx->stream));
-            int t = T.begin(K_OPT);
-            auto launch = [&](auto kern) -> hipError_t {
-                if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
-                hipLaunchKernelGGL(kern, dim3(slots), dim3(threads), lds, ctx->stream, a);
-                return hipGetLastError();
-            };
-            hipError_t le;
-            if (hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
-            else    le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512>) : launch(fl::optimize_kernel<A, false, 128>);
-            T.end(t);
-            if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));
-            ctx->timing.optimize_launches++;
+            int rc = ctx->opt_hist.ensure((uint64_t)opt_slots * G * span_max * p * A * 8); if (rc) return rc;
+            rc = ctx->opt_dist.ensure((uint64_t)opt_slots * G * n_max * p * 8); if (rc) return rc;
+            rc = ctx->opt_gain.ensure((uint64_t)opt_slots * G * cand_cap * 8); if (rc) return rc;
+            rc = ctx->opt_key.ensure((uint64_t)opt_slots * G * cand_cap * 4); if (rc) return rc;
+            rc = ctx->opt_moves.ensure((uint64_t)opt_slots * G * n_max * 4); if (rc) return rc;
         }
-        // ---- stop rule --------------------------------------------------------------------------------------------------
-        {
-            fl::SelectArgs s{};
-            s.n_blocks = bs.n_blocks; s.ploidy = p; s.max_ploidy = P; s.stopping_heuristic = prm->stopping_heuristic; s.eps = prm->epsilon;
-            const double eps = prm->epsilon, pl = (double)p;    // graph_processing.rs:204-220
-            if (prm->ploidy_sensitivity == 1)      s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 0.50) + 1.00));
-            else if (prm->ploidy_sensitivity == 2) s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1. / 3.));
-            else                                   s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1.00));
-            s.blk_read_off = bs.blk_read_off; s.mec = d_mec; s.num_alleles = d_na; s.blk_done = d_done; s.best_ploidy = d_best; s.tried = d_tried;
-            int t = T.begin(K_SEL);
-            hipLaunchKernelGGL(fl::select_kernel, dim3((bs.n_blocks + 255) / 256), dim3(256), 0, ctx->stream, s);
-            T.end(t);
-            HIPCHK(hipGetLastError());
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t nj = group_off[g + 1] - group_off[g];
+            if (nj == 0) continue;
+            hipStream_t st = gs[g];
+            const uint32_t* gjobs = d_jobs + group_off[g];
+            uint32_t* gqueue = d_queue + 2 * g;              // [0] beam, [1] optimise
+            if (!shortcut) {
+                const uint32_t slots = std::min(beam_slots, nj);
+                fl::BeamArgs a{};
+                a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
+                a.queue_head = gqueue; a.blk_done = d_done;
+                a.state_pool = ctx->state_pool.as<uint64_t>() + (state_bytes / 8) * beam_slots * g;
+                a.hist_pool = ctx->hist_pool.as<uint32_t>() + hist_stride * beam_slots * g; a.hist_stride = hist_stride;
+                a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
+                a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
+                const uint64_t* H = ctx->d_hash.as<uint64_t>();
+                a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
+                a.part_out = d_beam_part; a.min_margin_bits = d_margin; a.diag = d_diag; a.steps_done = d_steps;
+                a.prof = (unsigned long long*)(d_diag + 4);
+                HIPCHK(hipMemsetAsync(gqueue, 0, 4, st));
+                int t = T.begin(K_BEAM, st);
+                if (wide) {
+                    const uint32_t wslots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (WL.total + 512))));
+                    if (any_q0) hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(wslots), dim3(64), WL.total, st, a);
+                    else hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(wslots), dim3(64), WL.total, st, a);
+                } else if (slab) {
+                    if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), SL.total, st, a);
+                    else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), SL.total, st, a);
+                } else if (fast) {
+                    const fl::FastLds FL = fl::fast_lds_layout(LM, any_q0);
+                    if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, st, a);
+                    else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, st, a);
+                } else
+                    hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), LY.total, st, a);
+                T.end(t);
+                HIPCHK(hipGetLastError());
+                ctx->timing.beam_launches++;
+            }
+            // ---- optimise + MEC stats ------------------------------------------------------------------------------
+            {
+                const uint32_t slots = std::min(opt_slots, nj);
+                const uint64_t so = (uint64_t)opt_slots * g;
+                fl::OptArgs a{};
+                a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.max_ploidy = P; a.span_max = span_max; a.n_max = n_max;
+                a.queue_head = gqueue + 1; a.blk_done = d_done; a.eps = prm->epsilon;
+                a.part_in = d_beam_part; a.part_out = d_planes + (uint64_t)(p - 1) * tot_reads;
+                a.hist_pool = ctx->opt_hist.as<uint64_t>() + so * span_max * p * A; a.dist_pool = ctx->opt_dist.as<double>() + so * n_max * p;
+                a.cand_gain_pool = ctx->opt_gain.as<uint64_t>() + so * cand_cap; a.cand_key_pool = ctx->opt_key.as<uint32_t>() + so * cand_cap;
+                a.moves_pool = ctx->opt_moves.as<uint32_t>() + so * n_max; a.cand_cap = cand_cap;
+                a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
+                a.prof = (unsigned long long*)(d_diag + 4);
+                HIPCHK(hipMemsetAsync(gqueue + 1, 0, 4, st));
+                int t = T.begin(K_OPT, st);
+                auto launch = [&](auto kern) -> hipError_t {
+                    if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
+                    hipLaunchKernelGGL(kern, dim3(slots), dim3(threads), lds, st, a);
+                    return hipGetLastError();
+                };
+                hipError_t le;
+                if (hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
+                else    le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512>) : launch(fl::optimize_kernel<A, false, 128>);
+                T.end(t);
+                if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));
+                ctx->timing.optimize_launches++;
+            }
+            // ---- stop rule ---------------------------------------------------------------------------------------------
+            {
+                fl::SelectArgs s{};
+                s.job_block = gjobs; s.n_jobs = nj; s.ploidy = p; s.max_ploidy = P; s.stopping_heuristic = prm->stopping_heuristic; s.eps = prm->epsilon;
+                const double eps = prm->epsilon, pl = (double)p;    // graph_processing.rs:204-220
+                if (prm->ploidy_sensitivity == 1)      s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 0.50) + 1.00));
+                else if (prm->ploidy_sensitivity == 2) s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1. / 3.));
+                else                                   s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1.00));
+                s.mec = d_mec; s.num_alleles = d_na; s.blk_done = d_done; s.best_ploidy = d_best; s.tried = d_tried;
+                int t = T.begin(K_SEL, st);
+                hipLaunchKernelGGL(fl::select_kernel, dim3((nj + 255) / 256), dim3(256), 0, st, s);
+                T.end(t);
+                HIPCHK(hipGetLastError());
+            }
         }
     }
+    // join: the main stream continues after every group
+    if (G > 1 && forked) {
+        for (uint32_t g = 1; g < G; ++g) { HIPCHK(hipEventRecord(ctx->ev_join[g], gs[g])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g], 0)); }
+    }
+    T.end(t_phase);
+    ctx->timing.streams = G;
     return 0;
 }
 
@@ -412,6 +472,11 @@ void floria_hip_destroy(floria_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0, &c->graph_buf, &c->graph_hist, &c->graph_sort}) b->release();
+    for (uint32_t g = 0; g < floria_hip_ctx::MAX_GROUPS; ++g) {
+        if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
+        if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -598,6 +663,16 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     std::vector<uint32_t> jobs;
     for (uint32_t b = 0; b < n_blocks; ++b) if (cnt[b]) jobs.push_back(b);
     std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return cnt[a] > cnt[b2]; });
+    // job groups (longest-first inside each group, dealt round-robin so every group sees the same size mix)
+    uint32_t G = ctx->user_groups ? ctx->user_groups : 2;
+    if (const char* ge = getenv("FLORIA_HIP_GROUPS")) G = (uint32_t)std::max(1, atoi(ge));
+    G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
+    std::vector<uint32_t> group_off(G + 1, 0);
+    if (G > 1) {
+        std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
+        for (uint32_t g = 0; g < G; ++g) { for (size_t j = g; j < jobs.size(); j += G) dealt.push_back(jobs[j]); group_off[g + 1] = (uint32_t)dealt.size(); }
+        jobs.swap(dealt);
+    } else group_off[1] = (uint32_t)jobs.size();
 
     rc = ensure_binom(ctx, prm->epsilon, len_max); if (rc) return rc;
     if (span_max > fl::HASH_M) return fail(FLORIA_E_UNSUPPORTED, "a block's reads span more than 65536 SNPs");
@@ -607,7 +682,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     cursor = 0;
     const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg(tot + 16),
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
-              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(16), s_margin = seg(16),
+              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(8 * floria_hip_ctx::MAX_GROUPS + 16), s_margin = seg(16),
               s_diag = seg(16 + 8 * 32), s_steps = seg(16);
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
     char* M = ctx->misc.as<char>();
@@ -642,11 +717,11 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
 
     bool p1_shortcut = false;
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
-    rc = run(ctx, any_q0, bs, jobs, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
+    rc = run(ctx, any_q0, bs, jobs, group_off, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
              (uint8_t*)(M + s_bpart.off), (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
              (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
-    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if (rc) { sync_all(ctx); return rc; }
     {
         int t = T.begin(K_SEL);
         if (n_blocks) hipLaunchKernelGGL(fl::gather_kernel, dim3(n_blocks), dim3(64), 0, ctx->stream, n_blocks, bs.blk_read_off,
@@ -692,7 +767,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     if (p1_shortcut && !jobs.empty()) margin = std::min(margin, std::fabs(0.0 - std::log(PROB_CUTOFF)));   // the ploidy-1 decisions: p_k - lse == 0
     R->min_prune_margin = margin;
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
-    ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span();
+    ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span(); ctx->timing.phase_ms = T.sum(K_PHASE);
     ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
     for (uint32_t b = 0; b < n_blocks; ++b) {          // a beam launch for ploidy p phases the blocks with tried >= p (ploidy 1 needs no launch)
         const uint32_t launches_b = R->ploidies_tried[b] - ((p1_shortcut && R->ploidies_tried[b]) ? 1 : 0);

@@ -358,10 +358,10 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
 
 // ---- ploidy stop rule (graph_processing.rs:196-251), one thread per block, after ploidy p finished ----------
 struct SelectArgs {
-    uint32_t n_blocks, ploidy, max_ploidy;
+    const uint32_t* job_block;       // the non-empty blocks this launch decides (empty blocks keep best_ploidy = tried = 0)
+    uint32_t n_jobs, ploidy, max_ploidy;
     int32_t  stopping_heuristic;
     double   eps, mec_threshold;     // threshold for THIS ploidy, computed on the host with libm pow (:204-220)
-    const uint64_t* blk_read_off;
     const double* mec;
     const double* num_alleles;
     uint8_t*  blk_done;
@@ -369,9 +369,10 @@ struct SelectArgs {
     uint32_t* tried;
 };
 __global__ void select_kernel(SelectArgs g) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= g.n_blocks || g.blk_done[b]) return;
-    if (g.blk_read_off[b + 1] == g.blk_read_off[b]) { g.blk_done[b] = 1; g.best_ploidy[b] = 0; g.tried[b] = 0; return; }
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.n_jobs) return;
+    const uint32_t b = g.job_block[j];
+    if (g.blk_done[b]) return;
     const uint32_t p = g.ploidy;
     const double mec_p = g.mec[(uint64_t)b * g.max_ploidy + p - 1];
     const double expected = g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] * g.eps;         // :196

@@ -131,6 +131,10 @@ typedef struct {
     uint64_t beam_steps;       /* reads consumed by beam search, summed over (block, ploidy) jobs */
     uint64_t beam_launch_bytes;/* sum over beam launches of bytes(block) of the blocks that launch phased */
     uint64_t jobs;             /* (block, ploidy) jobs actually run */
+    uint32_t streams;          /* job groups of the last S1 call: their launch triples overlap on separate streams, so the
+                                * per-kernel sums above can exceed phase_ms */
+    uint32_t reserved;
+    double   phase_ms;         /* wall time of the per-ploidy launch loop (fork of the first group -> join of the last) */
 } floria_timing;
 
 typedef struct floria_hip_ctx floria_hip_ctx;

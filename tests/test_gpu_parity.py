@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from floria_amd import synth
-from floria_amd.pileup import Pileup
+from floria_amd.pileup import Pileup, reads_in_interval
 from tests.helpers import assert_block_results_equal, random_pileup
 from tests.test_golden_oracle import GOLD, load_golden
 
@@ -343,3 +343,72 @@ def test_mixed_batch_alleles_and_q0(gpu_ctx, hip_lib, oracle_mod):
         assert np.array_equal(ro.mec.view(np.uint64), r.mec[2 * i:2 * i + 2].view(np.uint64))
     for x in res:
         x.free()
+
+
+def numpy_mec_no_phred(p, ids, part, ploidy, eps):
+    """get_mec_stats_epsilon_no_phred (local_clustering.rs:187-215) restated with numpy bincounts, independently of the oracle:
+    per partition and SNP the allele counts; errors += total - max, and += eps where the consensus count is <= 1."""
+    bad = 0.0
+    for k in range(ploidy):
+        rs = ids[part == k]
+        if len(rs) == 0:
+            continue
+        lo, hi = p.read_off[rs], p.read_off[rs + 1]
+        cells = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)])
+        snp, al = p.snp[cells].astype(np.int64), p.allele[cells].astype(np.int64)
+        base = snp.min()
+        cnt = np.zeros((snp.max() - base + 1, 4), np.int64)
+        np.add.at(cnt, (snp - base, al), 1)
+        tot, mx = cnt.sum(1), cnt.max(1)
+        have = tot > 0
+        bad += float((tot - mx)[have].sum()) + float(np.count_nonzero(mx[have] <= 1)) * eps
+    return bad
+
+
+def test_bench_scale_properties(gpu_ctx, hip_lib, oracle_mod, monkeypatch):
+    """Size-independent properties on a bench-shaped batch (BASELINE config 4 contigs at full contig size, enough blocks for the job
+    groups to run on two streams): group count never changes results, the reported MEC of every sampled block equals an independent
+    numpy recomputation from the returned partition, read lists equal the interval query, and a block sample equals the oracle."""
+    n_contigs = 300
+    contigs = [synth.make_config_contig(4, i) for i in range(n_contigs)]
+    res = [gpu_ctx.upload(c.pileup) for c in contigs]
+    par = hip_lib.make_params(EPS)
+    bc, bs, be = [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+        bc += [i] * len(s); bs += list(s); be += list(e)
+    assert len(bc) >= 2048                                           # two job groups by default
+    monkeypatch.setenv("FLORIA_HIP_GROUPS", "1")
+    one = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+    assert gpu_ctx.timing()["streams"] == 1
+    monkeypatch.delenv("FLORIA_HIP_GROUPS")
+    two = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+    assert gpu_ctx.timing()["streams"] == 2
+    monkeypatch.setenv("FLORIA_HIP_GROUPS", "3")
+    three = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+    monkeypatch.delenv("FLORIA_HIP_GROUPS")
+    assert_block_results_equal(one, two, "1 vs 2 job groups")
+    assert_block_results_equal(one, three, "1 vs 3 job groups")
+    assert one.min_prune_margin == two.min_prune_margin == three.min_prune_margin > 1e-9
+    assert np.all(two.ploidies_tried >= two.best_ploidy) and np.all(two.best_ploidy >= 1) and np.all(two.best_ploidy <= 5)
+    rng = np.random.default_rng(1577)
+    sample = rng.choice(two.n_blocks, size=96, replace=False)
+    for blk in sample:
+        ci = bc[blk]
+        p = contigs[ci].pileup
+        ids, part = two.block(int(blk))
+        assert np.array_equal(ids, reads_in_interval(p, bs[blk], be[blk]))
+        bp = int(two.best_ploidy[blk])
+        assert np.all(part < bp)
+        assert two.mec[blk, bp - 1] == numpy_mec_no_phred(p, ids.astype(np.int64), part, bp, EPS)
+    # 32 of the sampled blocks against the oracle, bit for bit
+    for blk in sample[:32]:
+        ci = bc[blk]
+        ro = oracle_mod.phase_blocks(contigs[ci].pileup, [bs[blk]], [be[blk]], oracle_mod.make_params(EPS))
+        ids, part = two.block(int(blk))
+        oid, opart = ro.block(0)
+        assert ro.best_ploidy[0] == two.best_ploidy[blk] and ro.ploidies_tried[0] == two.ploidies_tried[blk]
+        assert np.array_equal(oid, ids) and np.array_equal(opart, part)
+        assert np.array_equal(ro.mec[0].view(np.uint64), two.mec[blk].view(np.uint64))
+    for r in res:
+        r.free()
