@@ -43,7 +43,11 @@ __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
     if (Gs >= 16) v += dpp_mov<0x140>(v);
     return v;
 }
+// x / d for 0 <= x < 2^20 without an integer division (a u32 division costs ~30 VALU instructions): the exact quotient of x + 0.5 is
+// at least 0.5/d away from every integer, while the float error (1-ulp reciprocal, one product) is < 4e-7 * x/d < 0.42/d
+__device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return (uint32_t)(((float)x + 0.5f) * rcp_d); }
 constexpr int SLAB_NS_MAX = 512;
+constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
 #ifndef FLORIA_SLAB_U
 #define FLORIA_SLAB_U 4
 #endif
@@ -83,7 +87,11 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 #ifdef FLORIA_PROF
 #define BEAM_TICK(ph) do { const unsigned long long _t = clock64(); t_acc[ph] += _t - t_last; t_last = _t; } while (0)
 #else
+#ifdef FLORIA_MARK
+#define BEAM_TICK(ph) asm volatile("; ====PHASE_END " #ph)
+#else
 #define BEAM_TICK(ph) do {} while (0)
+#endif
 #endif
 
 template <int A, bool Q0>
@@ -120,6 +128,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint64_t lane_lt = (1ull << lane) - 1;
 
     const uint32_t S = 64 / p;
+    const float rcp_p = __builtin_amdgcn_rcpf((float)p);
     const uint32_t my_sl = lane / p, my_k = lane % p;
     const bool lane_pair = my_sl < S;
     const uint64_t rk1 = c_rk1[my_k], rk2 = c_rk2[my_k];
@@ -264,13 +273,13 @@ void beam_slab_kernel(BeamArgs g) {
             BEAM_TICK(0);
 
             // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
-            uint32_t Gs = 1;
-            while (Gs < 16 && nlive * (Gs * 2) <= 64) Gs *= 2;
+            uint32_t Gs = 1, lgGs = 0;
+            while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
             const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
             const bool trunc = tend >= (int32_t)start_rel;            // some written position leaves the hash window this step
-            const uint32_t per = 64 / Gs;                       // slabs per pass
+            const uint32_t per = 64u >> lgGs;                   // slabs per pass
             for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
-                const uint32_t li = l0 + lane / Gs, sub = lane % Gs;
+                const uint32_t li = l0 + (lane >> lgGs), sub = lane & (Gs - 1);
                 const bool act = li < nlive;
                 const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
                 uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
@@ -390,16 +399,30 @@ void beam_slab_kernel(BeamArgs g) {
                     mx = (j == 0) ? o : (o > mx ? o : mx);
                 }
                 if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
-                const double ex = exp(pv - mx);              // each lane evaluates its own term once; the sum runs in the reference's order j = 0..p-1
-                for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
-                const double lse = mx + log(sum);
-                bool pass = false;
+                // Pruning test (pv - lse) > ln 0.01 and its margin.  Screen with hardware f32 exp2/log2 (error of the screened
+                // value < 2e-5): a decision further than PRUNE_SCREEN from the threshold AND from the wave's running
+                // minimum margin has the same outcome and cannot lower the minimum, so the f64 exp/log (identical to the generic
+                // kernels and the oracle's formula) only run in the steps where some lane is close.
+                const double dx = pv - mx;
+                const float ef = __builtin_amdgcn_exp2f((float)dx * 1.44269504088896341f);
+                float sumf = 0.f;
+                for (uint32_t j = 0; j < p; ++j) sumf += __shfl(ef, seg0 + (int)j);
+                const double dscr = (dx - (double)(__builtin_amdgcn_logf(sumf) * 0.693147180559945309f)) - g.cutoff;
+                const double ascr = fabs(dscr);
+                const bool far_enough = ascr >= PRUNE_SCREEN && ascr - PRUNE_SCREEN >= min_margin;     // false for NaN
+                bool pass = dscr > 0.0;
+                if (__any(act && !far_enough)) {
+                    const double ex = exp(dx);               // own term once; the sum runs in the reference's order j = 0..p-1
+                    for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
+                    const double lse = mx + log(sum);
+                    const double am = fabs((pv - lse) - g.cutoff);
+                    if (act) min_margin = am < min_margin ? am : min_margin;
+                    pass = (pv - lse) > g.cutoff;
+                }
+                pass = pass && act;
                 uint64_t ch1 = 0, ch2 = 0, cq = 0, cs = 0;
                 uint32_t cm = 0;
                 if (act) {
-                    const double am = fabs((pv - lse) - g.cutoff);
-                    min_margin = am < min_margin ? am : min_margin;
-                    pass = (pv - lse) > g.cutoff;
                     cq = st_q[a] + qd;
                     cm = st_m[a] + m;
                     cs = (uint64_t)__double_as_longlong(qm_to_f64(cq, cm, g.eps));
@@ -418,7 +441,7 @@ void beam_slab_kernel(BeamArgs g) {
                     evalid |= 1ull << id;
                     wl64(ev_s, s_s, id); wl64(ev_h1, s_h1, id); wl64(ev_h2, s_h2, id);
                     wl64(ev_q, rl64(cq, src), id); wl32(ev_m, rl32(cm, src), id);
-                    wl32(ev_pk, (a0 + src / p) | ((src % p) << 16), id);
+                    wl32(ev_pk, (a0 + rl32(my_sl, src)) | (rl32(my_k, src) << 16), id);
                     H.push(s_s, id);
                     if (H.len > limit) evalid &= ~(1ull << H.pop());
                 }
@@ -439,7 +462,7 @@ void beam_slab_kernel(BeamArgs g) {
             __syncthreads();
             // inherited pointers (every partition but the modified one) and the modified slab's leader
             for (uint32_t x = lane; x < nnext * p; x += 64) {
-                const uint32_t j = x / p, k = x - j * p;
+                const uint32_t j = div_small(x, rcp_p), k = x - j * p;
                 const uint32_t pk = s_pk[j];
                 const uint32_t sid = st_sl[(pk & 0xffff) * p + k];
                 nx_sl[x] = (uint16_t)sid;
@@ -512,8 +535,9 @@ void beam_slab_kernel(BeamArgs g) {
             if (new_hi > hi_rel) {
                 const uint32_t cntz = (uint32_t)(new_hi - hi_rel) * A;
                 const uint32_t items = nl * cntz;
+                const float rcp_cntz = __builtin_amdgcn_rcpf((float)cntz);
                 for (uint32_t x = lane; x < items; x += 64) {
-                    const uint32_t e = x / cntz, o = x - e * cntz;
+                    const uint32_t e = items < (1u << 20) ? div_small(x, rcp_cntz) : x / cntz, o = x - e * cntz;
                     *(uint64_t*)(pool + ((uint32_t)live_id[e] * slab_bytes + (uint32_t)(hi_rel + 1) * pos_bytes + o * 8)) = 0;
                 }
             }
@@ -529,8 +553,9 @@ void beam_slab_kernel(BeamArgs g) {
                     if (ntiles > 1) stage_tile(t); else __syncthreads();
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
                     const uint32_t items = nlead * tl;
+                    const float rcp_tl = __builtin_amdgcn_rcpf((float)tl);
                     auto addr_of = [&](uint32_t x, uint32_t& w) -> uint64_t* {
-                        const uint32_t e = x / tl, c = x - e * tl;
+                        const uint32_t e = div_small(x, rcp_tl), c = x - e * tl;
                         const uint32_t aw = c_aw[c];
                         w = aw & 0x0fffffffu;
                         return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + (c_snp[c] - pos0) * pos_bytes + (aw >> 28) * 8));
@@ -588,7 +613,8 @@ void beam_slab_kernel(BeamArgs g) {
     }
 #ifdef FLORIA_PROF
     if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g.prof[16 + i], t_acc[i]);
-                     atomicAdd(&g.prof[24], wall_clock64() - t_wall0); atomicAdd(&g.prof[25], clock64() - t_core0); atomicAdd(&g.prof[26], 1ull); }
+                     atomicAdd(&g.prof[24], wall_clock64() - t_wall0); atomicAdd(&g.prof[25], clock64() - t_core0); atomicAdd(&g.prof[26], 1ull);
+                     atomicAdd(&g.prof[26 + g.ploidy], wall_clock64() - t_wall0); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);

@@ -1,6 +1,6 @@
-#!/bin/bash
 for v in "$@"; do
   make -C floria_amd/csrc -B EXTRA="$v" libfloria_hip.so > /dev/null 2>&1 || { echo "BUILD FAILED: $v"; continue; }
   echo "== $v"
-  python bench.py --steps 2 --warmup 1 --cpu-sample 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"
+  for G in 1 2; do FLORIA_HIP_GROUPS=$G python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>&1 | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"; done
 done
+make -C floria_amd/csrc -B libfloria_hip.so > /dev/null 2>&1
