@@ -138,6 +138,7 @@ void beam_slab_kernel(BeamArgs g) {
 #ifdef FLORIA_PROF
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
+    uint32_t c_pass = 0, c_push = 0, c_pop = 0;
 #endif
 
     for (;;) {
@@ -431,6 +432,9 @@ void beam_slab_kernel(BeamArgs g) {
                 }
                 uint64_t passmask = __ballot(pass);
                 BEAM_TICK(7);
+#ifdef FLORIA_PROF
+                c_pass += (uint32_t)__popcll(passmask);
+#endif
                 while (passmask) {
                     const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
                     passmask &= passmask - 1;
@@ -443,6 +447,9 @@ void beam_slab_kernel(BeamArgs g) {
                     wl64(ev_q, rl64(cq, src), id); wl32(ev_m, rl32(cm, src), id);
                     wl32(ev_pk, (a0 + rl32(my_sl, src)) | (rl32(my_k, src) << 16), id);
                     H.push(s_s, id);
+#ifdef FLORIA_PROF
+                    c_push++; if (H.len > limit) c_pop++;
+#endif
                     if (H.len > limit) evalid &= ~(1ull << H.pop());
                 }
                 BEAM_TICK(2);
@@ -614,7 +621,8 @@ void beam_slab_kernel(BeamArgs g) {
 #ifdef FLORIA_PROF
     if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g.prof[16 + i], t_acc[i]);
                      atomicAdd(&g.prof[24], wall_clock64() - t_wall0); atomicAdd(&g.prof[25], clock64() - t_core0); atomicAdd(&g.prof[26], 1ull);
-                     atomicAdd(&g.prof[26 + g.ploidy], wall_clock64() - t_wall0); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
+                     atomicAdd(&g.prof[26 + g.ploidy], wall_clock64() - t_wall0);
+                     atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);

@@ -21,6 +21,7 @@
 #include <numeric>
 #include <string>
 #include <utility>
+#include <mutex>
 #include <vector>
 
 #include "../../include/floria_hip.h"
@@ -78,6 +79,34 @@ uint64_t splitmix64(uint64_t& s) {
 
 }  // namespace
 
+// Large result arrays (read ids, partitions: tens of MB per S1 call) come from a small process-wide cache: a fresh malloc of
+// that size is an mmap whose pages fault one by one under the device->host copy.  Header = capacity, 64 B before the payload.
+namespace {
+struct BigCache {
+    std::mutex m;
+    std::vector<std::pair<void*, size_t>> v;      // (base, capacity)
+    void* get(size_t n) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].second >= n && v[i].second <= 2 * n + 4096) { void* b = v[i].first; v.erase(v.begin() + i); return (char*)b + 64; }
+        }
+        void* b = malloc(n + 64);
+        if (!b) return nullptr;
+        *(size_t*)b = n;
+        return (char*)b + 64;
+    }
+    void put(void* payload) {
+        if (!payload) return;
+        void* b = (char*)payload - 64;
+        const size_t cap = *(size_t*)b;
+        std::lock_guard<std::mutex> l(m);
+        if (cap >= (1u << 20) && v.size() < 8) v.push_back({b, cap}); else free(b);
+    }
+};
+BigCache g_big;
+}  // namespace
+
 struct floria_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -88,6 +117,8 @@ struct floria_hip_ctx {
     static constexpr uint32_t MAX_GROUPS = 8;
     hipStream_t gstream[MAX_GROUPS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
+    hipEvent_t ev_rids = nullptr;
     // cached tables
     double binom_eps = -1.0;
     uint32_t binom_nmax = 0;
@@ -230,6 +261,7 @@ enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5, K
 
 void sync_all(floria_hip_ctx* ctx) {
     for (uint32_t g = 0; g < floria_hip_ctx::MAX_GROUPS; ++g) if (ctx->gstream[g]) (void)hipStreamSynchronize(ctx->gstream[g]);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(ctx->stream);
 }
 
@@ -477,6 +509,8 @@ void floria_hip_destroy(floria_hip_ctx* c) {
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_rids) (void)hipEventDestroy(c->ev_rids);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -707,6 +741,9 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
         hipLaunchKernelGGL(fl::block_reads_kernel<true>, dim3(n_blocks), dim3(64), 0, ctx->stream, sa);
         T.end(tk);
         HIPCHK(hipGetLastError());
+        if (!ctx->ev_rids) HIPCHK(hipEventCreateWithFlags(&ctx->ev_rids, hipEventDisableTiming));
+        if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventRecord(ctx->ev_rids, ctx->stream));
     }
 
     fl::BlockSet bs{};
@@ -715,6 +752,18 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     bs.blk_pos0 = (const uint32_t*)(M0 + s_p0.off); bs.blk_span = (const uint32_t*)(M0 + s_sp.off);
     bs.blk_read_off = (const uint64_t*)(M0 + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
 
+    // ---- result buffers (allocated first: the read-id lists are copied back while the launch loop runs) -----------------
+    floria_block_result* R = (floria_block_result*)calloc(1, sizeof(floria_block_result));
+    if (!R) return fail(FLORIA_E_NOMEM, "calloc");
+    R->n_blocks = n_blocks; R->max_ploidy = P;
+    R->best_ploidy = (uint32_t*)calloc(n_blocks + 1, 4);
+    R->ploidies_tried = (uint32_t*)calloc(n_blocks + 1, 4);
+    R->read_off = (uint64_t*)calloc(n_blocks + 1, 8);
+    R->read_id = (uint32_t*)g_big.get(4 * (tot + 1));
+    R->part = (uint8_t*)g_big.get(tot + 1);
+    R->mec = (double*)calloc((size_t)n_blocks * P + 1, 8);
+    struct ResultGuard { floria_hip_ctx* c; floria_block_result* r; ~ResultGuard() { if (r) { sync_all(c); floria_hip_block_result_free(r); } } } guard{ctx, R};   // every early return below
+    if (!R->best_ploidy || !R->ploidies_tried || !R->read_off || !R->read_id || !R->part || !R->mec) { return fail(FLORIA_E_NOMEM, "malloc"); }
     bool p1_shortcut = false;
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
     rc = run(ctx, any_q0, bs, jobs, group_off, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
@@ -722,6 +771,14 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
              (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
     if (rc) { sync_all(ctx); return rc; }
+    int t_rids = -1;
+    if (n_blocks && tot) {              // everything is queued: the copy (pageable destination, the host may block here) overlaps the kernels
+        HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rids, 0));
+        t_rids = T.begin(K_D2H, ctx->copy_stream);
+        hipError_t ce = hipMemcpyAsync(R->read_id, M + s_rids.off, 4ull * tot, hipMemcpyDeviceToHost, ctx->copy_stream);
+        T.end(t_rids);
+        if (ce != hipSuccess) { sync_all(ctx); return fail(FLORIA_E_DEVICE, hipGetErrorString(ce)); }
+    }
     {
         int t = T.begin(K_SEL);
         if (n_blocks) hipLaunchKernelGGL(fl::gather_kernel, dim3(n_blocks), dim3(64), 0, ctx->stream, n_blocks, bs.blk_read_off,
@@ -730,17 +787,6 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
         HIPCHK(hipGetLastError());
     }
 
-    // ---- results ------------------------------------------------------------------------------------------------
-    floria_block_result* R = (floria_block_result*)calloc(1, sizeof(floria_block_result));
-    if (!R) return fail(FLORIA_E_NOMEM, "calloc");
-    R->n_blocks = n_blocks; R->max_ploidy = P;
-    R->best_ploidy = (uint32_t*)calloc(n_blocks + 1, 4);
-    R->ploidies_tried = (uint32_t*)calloc(n_blocks + 1, 4);
-    R->read_off = (uint64_t*)calloc(n_blocks + 1, 8);
-    R->read_id = (uint32_t*)malloc(4 * (tot + 1));
-    R->part = (uint8_t*)malloc(tot + 1);
-    R->mec = (double*)calloc((size_t)n_blocks * P + 1, 8);
-    if (!R->best_ploidy || !R->ploidies_tried || !R->read_off || !R->read_id || !R->part || !R->mec) { floria_hip_block_result_free(R); return fail(FLORIA_E_NOMEM, "malloc"); }
     int td = T.begin(K_D2H);
     hipError_t e = hipSuccess;
     uint32_t diag[4] = {0, 0, 0, 0};
@@ -751,15 +797,15 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
         if (e == hipSuccess) e = hipMemcpyAsync(R->ploidies_tried, M + s_tried.off, 4ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(R->mec, M + s_mec.off, 8ull * n_blocks * P, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && tot) e = hipMemcpyAsync(R->part, M + s_out.off, tot, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && tot) e = hipMemcpyAsync(R->read_id, M + s_rids.off, 4ull * tot, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(diag, M + s_diag.off, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&steps, M + s_steps.off, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&margin, M + s_margin.off, 8, hipMemcpyDeviceToHost, ctx->stream);
     T.end(td);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, std::string("phase_blocks: ") + hipGetErrorString(e)); }
-    if (diag[1]) { floria_hip_block_result_free(R); return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
+    if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
+    if (e != hipSuccess) { sync_all(ctx); return fail(FLORIA_E_DEVICE, std::string("phase_blocks: ") + hipGetErrorString(e)); }
+    if (diag[1]) { return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
 #ifdef FLORIA_PROF
     { unsigned long long prof[32]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
 #endif
@@ -776,6 +822,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     ctx->batch_token = R->batch_token = ++ctx->token_counter;
     ctx->last_bs = bs; ctx->last_part = (const uint8_t*)(M + s_out.off); ctx->last_best = (const uint32_t*)(M + s_best.off); ctx->last_nall = nall;
     ctx->last_bc = bc; ctx->last_start.assign(blk_start, blk_start + n_blocks); ctx->last_end.assign(blk_end, blk_end + n_blocks);
+    guard.r = nullptr;
     *out = R;
     return 0;
 }
@@ -800,7 +847,7 @@ int floria_hip_phase_blocks(floria_hip_ctx* ctx, const floria_pileup* pileup, co
 
 void floria_hip_block_result_free(floria_block_result* r) {
     if (!r) return;
-    free(r->best_ploidy); free(r->ploidies_tried); free(r->read_off); free(r->read_id); free(r->part); free(r->mec); free(r);
+    free(r->best_ploidy); free(r->ploidies_tried); free(r->read_off); g_big.put(r->read_id); g_big.put(r->part); free(r->mec); free(r);
 }
 
 // ---- hap-graph nodes + edges on the resident batch ------------------------------------------------
