@@ -33,4 +33,47 @@ json.dump(out, open(O+"/pmc_summary.json","w"), indent=1)
 print(json.dumps(out)[:600])
 PY
 cp $O/stats/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
-tail -1 $O/bench_stats.log > $O/bench.json
+grep '^{' $O/bench_stats.log | tail -1 > $O/bench.json
+# ---- SQ counters (two more passes): VALU / SALU / LDS / VMEM instruction counts, busy and wait cycles per kernel --------------------
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq1 -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/bench_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU --output-format csv -d $O/pmc_sq2 -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/bench_sq2.log 2>&1
+cd $R
+python - <<PY
+import csv, json, collections, glob
+O="$O"
+raw=collections.defaultdict(lambda: collections.defaultdict(float)); dur=collections.defaultdict(float); nl=collections.defaultdict(set)
+for d in ("pmc_sq1","pmc_sq2"):
+    fs=glob.glob(O+"/"+d+"/**/*counter_collection.csv", recursive=True)
+    if not fs: continue
+    for r in csv.DictReader(open(fs[0])):
+        k=r["Kernel_Name"].split("(")[0]
+        if "beam" in k or "optimize" in k:
+            raw[k][r["Counter_Name"]]+=float(r["Counter_Value"])
+# kernel durations of the un-instrumented stats run (sum over launches of one bench step = total / 3 timed+warm steps is not needed: use per-launch avg * launches of one step)
+st=glob.glob(O+"/stats/**/*kernel_stats.csv", recursive=True)
+avg={}; calls={}
+if st:
+    for r in csv.DictReader(open(st[0])):
+        k=r["Name"].split("(")[0]; avg[k]=float(r["AverageNs"])/1e6; calls[k]=int(r["Calls"])
+out={"note":"rocprofv3 --pmc SQ_* (two passes, bench.py --steps 1 --warmup 0, config 4 full; kernels are serialised by the counter collection); SQ_*_CYCLES are quad-cycles per SIMD-wave accounting as in MI355X_MICROARCH.md; valu_busy_frac = SQ_ACTIVE_INST_VALU*4 / SQ_BUSY_CYCLES-normalised SIMD cycles (SQ_BUSY_CYCLES counts per SE: reported raw)","kernels":{},"raw":{k:dict(v) for k,v in raw.items()}}
+for k,v in raw.items():
+    if "SQ_WAVE_CYCLES" in v and v["SQ_WAVE_CYCLES"]>0:
+        out["kernels"][k]={"avg_launch_ms_stats_run":avg.get(k),"launches_stats_run":calls.get(k),
+            "insts_valu":v.get("SQ_INSTS_VALU"),"insts_salu":v.get("SQ_INSTS_SALU"),"insts_lds":v.get("SQ_INSTS_LDS"),
+            "insts_vmem_rd":v.get("SQ_INSTS_VMEM_RD"),"insts_vmem_wr":v.get("SQ_INSTS_VMEM_WR"),
+            "wave_cycles_waiting_frac": round(v.get("SQ_WAIT_ANY",0)/v["SQ_WAVE_CYCLES"],3),
+            "valu_active_over_wave_cycles": round(v.get("SQ_ACTIVE_INST_VALU",0)/v["SQ_WAVE_CYCLES"],4)}
+kt=glob.glob(O+"/pmc_sq2/**/*kernel_trace.csv", recursive=True)
+if kt:
+    dur=collections.defaultdict(float)
+    for r in csv.DictReader(open(kt[0])):
+        dur[r["Kernel_Name"].split("(")[0]]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))*1e-9
+    for k in out["kernels"]:
+        a=raw[k].get("SQ_ACTIVE_INST_VALU")
+        if a and dur.get(k):
+            out["kernels"][k]["kernel_seconds_in_counter_pass"]=round(dur[k],5)
+            out["kernels"][k]["valu_busy_frac"]=round(a*4/(dur[k]*2.37e9*1024),3)      # 4 cycles per wave instruction, 1024 SIMDs, 2.37 GHz measured core clock
+json.dump(out, open(O+"/sq_counters.json","w"), indent=1)
+print(json.dumps(out["kernels"])[:900])
+PY
