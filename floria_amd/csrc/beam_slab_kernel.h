@@ -94,12 +94,14 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 #endif
 #endif
 
-template <int A, bool Q0>
+// TP / TB: ploidy and beam width as compile-time constants (0 = read them from the arguments): LDS offsets become immediates, the
+// per-partition loops unroll and divisions by p turn into multiplications; the host picks TP = p, TB = 10 for the CLI's default beam.
+template <int A, bool Q0, int TP = 0, int TB = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_WAVES, FLORIA_FAST_WAVES)))
 void beam_slab_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t p = g.ploidy, B = g.beam, LM = p * B, NS = LM * p;
+    const uint32_t p = TP ? (uint32_t)TP : g.ploidy, B = TB ? (uint32_t)TB : g.beam, LM = p * B, NS = LM * p;
     const SlabLds LY = slab_lds_layout(LM, p, Q0);
     uint32_t* const c_snp_base = (uint32_t*)(smem + LY.off_coff);
     uint32_t* const c_aw_base  = (uint32_t*)(smem + LY.off_caw);

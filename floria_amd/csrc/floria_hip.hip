@@ -393,7 +393,12 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     if (any_q0) hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(wslots), dim3(64), WL.total, st, a);
                     else hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(wslots), dim3(64), WL.total, st, a);
                 } else if (slab) {
+                    const bool spec = A == 2 && !any_q0 && B == 10 && p >= 2 && p <= 5 && !getenv("FLORIA_HIP_NO_SPECIALIZED");
                     if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), SL.total, st, a);
+                    else if (spec && p == 2) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), SL.total, st, a);
+                    else if (spec && p == 3) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), SL.total, st, a);
+                    else if (spec && p == 4) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), SL.total, st, a);
+                    else if (spec && p == 5) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), SL.total, st, a);
                     else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), SL.total, st, a);
                 } else if (fast) {
                     const fl::FastLds FL = fl::fast_lds_layout(LM, any_q0);

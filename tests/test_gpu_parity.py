@@ -412,3 +412,18 @@ def test_bench_scale_properties(gpu_ctx, hip_lib, oracle_mod, monkeypatch):
         assert np.array_equal(ro.mec[0].view(np.uint64), two.mec[blk].view(np.uint64))
     for r in res:
         r.free()
+
+
+def test_specialised_and_generic_slab_kernels_agree(gpu_ctx, hip_lib, oracle_mod, monkeypatch):
+    # beam width 10 + biallelic + no q=0 cells runs beam_slab_kernel<2,false,P,10> (ploidy and beam as compile-time constants);
+    # FLORIA_HIP_NO_SPECIALIZED=1 forces the runtime-parameter instance.  Both must equal the oracle.
+    c = synth.make_config_contig(4, 11, 0.6)
+    s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+    ro = oracle_mod.phase_blocks(c.pileup, s, e, oracle_mod.make_params(EPS), threads=8)
+    spec = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
+    monkeypatch.setenv("FLORIA_HIP_NO_SPECIALIZED", "1")
+    gen = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
+    monkeypatch.delenv("FLORIA_HIP_NO_SPECIALIZED")
+    assert_block_results_equal(ro, spec, "specialised")
+    assert_block_results_equal(ro, gen, "generic")
+    assert spec.min_prune_margin == gen.min_prune_margin == ro.min_prune_margin
