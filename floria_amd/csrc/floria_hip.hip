@@ -351,12 +351,15 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         uint64_t cand_cap = 1;
         while (cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) cand_cap <<= 1;
         const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
-        const uint32_t threads = mean_n >= 384 ? 1024 : (mean_n >= 96 ? 512 : 128);
+        uint32_t threads = mean_n >= 384 ? 1024 : (mean_n >= 96 ? 512 : 128);
+        if (const char* te = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(te); if (tv == 1024 || tv == 512 || tv == 128) threads = (uint32_t)tv; }   // dev knob
         const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
         const size_t hist_bytes = (size_t)span_max * p * A * 8;
         const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
         const bool hl = hist_bytes + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
         const size_t lds = moved_bytes + meta_bytes + (hl ? hist_bytes : 0) + 16;
+        // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
+        if (A == 2 && hl && p <= 5 && threads == 1024 && !getenv("FLORIA_HIP_OPT_THREADS") && !getenv("FLORIA_HIP_NO_SPECIALIZED")) threads = 512;
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads));
         per_cu = std::min<uint32_t>(per_cu, 8);
         const uint32_t opt_slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, n_jobs);
@@ -431,7 +434,14 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     return hipGetLastError();
                 };
                 hipError_t le;
-                if (hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
+                const bool ospec = A == 2 && hl && threads >= 512 && p <= 5 && !getenv("FLORIA_HIP_NO_SPECIALIZED");
+                if (ospec && threads == 1024)
+                    le = p == 1 ? launch(fl::optimize_kernel<2, true, 1024, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 1024, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 1024, 3>)
+                       : p == 4 ? launch(fl::optimize_kernel<2, true, 1024, 4>) : launch(fl::optimize_kernel<2, true, 1024, 5>);
+                else if (ospec)
+                    le = p == 1 ? launch(fl::optimize_kernel<2, true, 512, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 512, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 512, 3>)
+                       : p == 4 ? launch(fl::optimize_kernel<2, true, 512, 4>) : launch(fl::optimize_kernel<2, true, 512, 5>);
+                else if (hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
                 else    le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512>) : launch(fl::optimize_kernel<A, false, 128>);
                 T.end(t);
                 if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));

@@ -89,7 +89,9 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 
 // HL = the job's histogram slab lives in LDS (span_max*ploidy*A*8 bytes fit): distance loads, the build/move atomics and the
 // MEC reductions then never leave the CU; only the reads' cells stream from HBM/L2.
-template <int A, bool HL, int OPT_THREADS>
+// TP: ploidy as a compile-time constant (0 = read it from the arguments): the per-partition loops of the distance pass are exact
+// instead of MAX_PLOIDY predicated iterations.
+template <int A, bool HL, int OPT_THREADS, int TP = 0>
 __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
     __shared__ uint64_t s_gain[OPT_SORT_LDS];
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     uint32_t* s_moved = (uint32_t*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t p = g.ploidy, PA = p * A;
+    const uint32_t p = TP ? (uint32_t)TP : g.ploidy, PA = p * A;
+    constexpr int KMAX = TP ? TP : MAX_PLOIDY;
     const uint32_t moved_bytes = (((g.n_max + 31) / 32) * 4 + 15) & ~15u;
     const uint32_t meta_n = g.n_max <= (uint32_t)OPT_META_MAX ? g.n_max : 0;            // 0 = read the metadata from HBM every time
     const uint32_t meta_bytes = (meta_n * 8 + 15) & ~15u;
@@ -220,9 +223,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                     uint32_t cb = 0, len = 0, kk = 0;
                     if (i < n) read_meta(i, cb, len, kk);
-                    uint64_t acc[MAX_PLOIDY];
+                    uint64_t acc[KMAX];
 #pragma unroll
-                    for (int k = 0; k < MAX_PLOIDY; ++k) acc[k] = 0;
+                    for (int k = 0; k < KMAX; ++k) acc[k] = 0;
                     for (uint32_t c0 = sub; c0 < len; c0 += 16 * 4) {
                         uint32_t sn[4], aqs[4];
 #pragma unroll
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                                 const uint64_t w = (aqs[u] & 0x0fffffffu);
                                 const uint64_t* row = hist + (uint64_t)(sn[u] - pos0) * PA;
 #pragma unroll
-                                for (int k = 0; k < MAX_PLOIDY; ++k) {
+                                for (int k = 0; k < KMAX; ++k) {
                                     if ((uint32_t)k < p) {
                                         uint64_t mx = 0, va = 0;
 #pragma unroll
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < MAX_PLOIDY; ++k) {
+                    for (int k = 0; k < KMAX; ++k) {
                         if ((uint32_t)k < p) {
                             const uint64_t t = row16_sum_u64(acc[k]);
                             if (sub == (uint32_t)k && i < n) dist[i * p + k] = qm_to_f64(t >> 16, t & 0xffff, g.eps);
