@@ -186,9 +186,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t r = uni(r_next);
             if (i + 1 < n) r_next = reads[i + 1];
-            const uint32_t cbeg = uni(cd.read_off[r]), L = uni(cd.read_off[r + 1]) - cbeg;
-            const uint32_t first_rel = uni(cd.first[r]) - pos0;
-            const int32_t  last_rel = (int32_t)(uni(cd.last[r]) - pos0);
+            const uint32_t cbeg = uni(G(cd.read_off)[r]), L = uni(G(cd.read_off)[r + 1]) - cbeg;
+            const uint32_t first_rel = uni(G(cd.first)[r]) - pos0;
+            const int32_t  last_rel = (int32_t)(uni(G(cd.last)[r]) - pos0);
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
             const uint32_t ntiles = (L + FAST_TILE - 1) / FAST_TILE;
 
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
                     const uint32_t cc = t * FAST_TILE + c;
                     bool in = false;
                     if (cc < L) {
-                        const uint32_t pr = cd.cell_snp[cbeg + cc] - pos0;
-                        const uint32_t aq = cd.cell_aw[cbeg + cc];
+                        const uint32_t pr = G(cd.cell_snp)[cbeg + cc] - pos0;
+                        const uint32_t aq = G(cd.cell_aw)[cbeg + cc];
                         const uint32_t al = aq >> 28;
                         const uint32_t w = (aq & 0x0fffffffu);
                         const uint32_t idx = pr * A + al;
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_
             };
             if (ntiles > 1) {                           // rare: reads with > 256 SNPs; hash constant in its own pass
                 for (uint32_t c = lane; c < L; c += 64) {
-                    const uint32_t pr = cd.cell_snp[cbeg + c] - pos0;
-                    const uint32_t aq = cd.cell_aw[cbeg + c];
+                    const uint32_t pr = G(cd.cell_snp)[cbeg + c] - pos0;
+                    const uint32_t aq = G(cd.cell_aw)[cbeg + c];
                     const uint32_t idx = pr * A + (aq >> 28);
                     const uint64_t w = (aq & 0x0fffffffu);
                     tw1 += g.Rq1[idx] * w; tw2 += g.Rq2[idx] * w;

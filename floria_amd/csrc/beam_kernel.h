@@ -204,17 +204,17 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
 
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t r = reads[i];
-            const uint32_t cbeg = cd.read_off[r], L = cd.read_off[r + 1] - cbeg;
-            const uint32_t first_rel = cd.first[r] - pos0;
-            const int32_t  last_rel = (int32_t)(cd.last[r] - pos0);
+            const uint32_t cbeg = G(cd.read_off)[r], L = G(cd.read_off)[r + 1] - cbeg;
+            const uint32_t first_rel = G(cd.first)[r] - pos0;
+            const int32_t  last_rel = (int32_t)(G(cd.last)[r] - pos0);
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;                 // :50-53
             const uint32_t ntiles = (L + BEAM_TILE - 1) / BEAM_TILE;
 
             // ---- per-read hash constant Tw = sum_cells Rq[pos,allele] * w (wave-uniform) ----------------
             uint64_t tw1 = 0, tw2 = 0;
             for (uint32_t c = lane; c < L; c += 64) {
-                uint32_t pr = cd.cell_snp[cbeg + c] - pos0;
-                uint32_t aq = cd.cell_aw[cbeg + c];
+                uint32_t pr = G(cd.cell_snp)[cbeg + c] - pos0;
+                uint32_t aq = G(cd.cell_aw)[cbeg + c];
                 uint64_t w = (aq & 0x0fffffffu);
                 uint32_t idx = pr * A + (aq >> 28);
                 tw1 += g.Rq1[idx] * w;
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                 for (uint32_t c = lane; c < BEAM_TILE; c += 64) {
                     uint32_t cc = t * BEAM_TILE + c;
                     if (cc < L) {
-                        uint32_t pr = cd.cell_snp[cbeg + cc] - pos0;
-                        uint32_t aq = cd.cell_aw[cbeg + cc];
+                        uint32_t pr = G(cd.cell_snp)[cbeg + cc] - pos0;
+                        uint32_t aq = G(cd.cell_aw)[cbeg + cc];
                         uint32_t al = aq >> 28;
                         c_pos[c] = pr;
                         c_aw[c] = (al << 28) | (aq & 0x0fffffffu);

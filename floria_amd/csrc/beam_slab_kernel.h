@@ -182,7 +182,7 @@ void beam_slab_kernel(BeamArgs g) {
         // read ids come 64 at a time (lane j = reads[base + j]).
         struct CellMeta { uint32_t cbeg, L; };
         struct StepMeta { uint32_t first, last; uint64_t tw1, tw2; };
-        auto load_rec = [&](uint32_t r) -> uint32_t { return lane < 8 ? cd.meta[8 * (uint64_t)r + lane] : 0u; };
+        auto load_rec = [&](uint32_t r) -> uint32_t { return lane < 8 ? G(cd.meta)[8 * (uint64_t)r + lane] : 0u; };
         auto rec_cm = [&](uint32_t v) { CellMeta m; m.cbeg = rl32(v, 0); m.L = rl32(v, 1); return m; };
         auto rec_sm = [&](uint32_t v) { StepMeta m; m.first = rl32(v, 2); m.last = rl32(v, 3);
                                         m.tw1 = ((uint64_t)rl32(v, 5) << 32) | rl32(v, 4); m.tw2 = ((uint64_t)rl32(v, 7) << 32) | rl32(v, 6); return m; };
@@ -190,8 +190,8 @@ void beam_slab_kernel(BeamArgs g) {
         // 3 cells past the read (the next read's cells or the arrays' 16-B tail padding, see floria_hip_contig_upload); never used.
         auto dma_cells = [&](uint32_t w, const CellMeta& m) {
             if (m.L <= (uint32_t)SLAB_TILE && 4 * lane < m.L) {
-                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(cd.cell_snp + m.cbeg + 4 * lane), (lds_void*)(c_snp_base + w * SLAB_TILE), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(cd.cell_aw + m.cbeg + 4 * lane), (lds_void*)(c_aw_base + w * SLAB_TILE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_snp) + m.cbeg + 4 * lane), (lds_void*)(c_snp_base + w * SLAB_TILE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_aw) + m.cbeg + 4 * lane), (lds_void*)(c_aw_base + w * SLAB_TILE), 16, 0, 0);
             }
         };
         uint64_t rpb1 = 0, rpb2 = 0;
@@ -256,7 +256,7 @@ void beam_slab_kernel(BeamArgs g) {
                 for (int u = 0; u < SLAB_TILE / 64; ++u) {
                     const uint32_t c = lane + 64 * u;
                     const uint32_t cc = t * SLAB_TILE + c;
-                    if (cc < L) { c_snp[c] = cd.cell_snp[cbeg + cc]; c_aw[c] = cd.cell_aw[cbeg + cc]; }
+                    if (cc < L) { c_snp[c] = G(cd.cell_snp)[cbeg + cc]; c_aw[c] = G(cd.cell_aw)[cbeg + cc]; }
                 }
                 __syncthreads();
                 scan_tile(min((uint32_t)SLAB_TILE, L - t * SLAB_TILE));

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                     const uint32_t cc = t * SLAB_TILE + c;
                     bool in = false;
                     if (cc < L) {
-                        const uint32_t snp = cd.cell_snp[cbeg + cc];
-                        const uint32_t aq = cd.cell_aw[cbeg + cc];
+                        const uint32_t snp = G(cd.cell_snp)[cbeg + cc];
+                        const uint32_t aq = G(cd.cell_aw)[cbeg + cc];
                         const uint32_t pr = snp - pos0, al = aq >> 28;
                         c_off[c] = pr * pos_bytes;
                         c_aw[c] = (al << 28) | (aq & 0x0fffffffu);

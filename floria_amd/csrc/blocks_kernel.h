@@ -47,11 +47,11 @@ __global__ __launch_bounds__(64) void block_reads_kernel(ScanArgs g) {
         const uint32_t r = r0 + lane;
         bool pass = false;
         if (r < hi) {
-            const uint32_t F = cd.first[r], La = cd.last[r];
+            const uint32_t F = G(cd.first)[r], La = G(cd.last)[r];
             pass = La >= start && La - F <= 10000;                 // :36-38, :44-46  (first <= end by construction, :39-41)
             if (pass && !FILL) {
                 cnt++; mn = F < mn ? F : mn; mx = La > mx ? La : mx;
-                const uint64_t L = cd.read_off[r + 1] - cd.read_off[r];
+                const uint64_t L = G(cd.read_off)[r + 1] - G(cd.read_off)[r];
                 bytes += 8 + (L + 3) / 4 + (L + 7) / 8 + L;
             }
         }

@@ -31,6 +31,12 @@ struct ContigDev {
     uint32_t        pad;
 };
 
+// A ContigDev is loaded from memory, so hipcc cannot tell that its pointers are global: loads through them would be FLAT loads, which
+// count in lgkmcnt as well as vmcnt (every LDS wait then also waits for them) and take the slower flat path.  G(p) asserts "global".
+template <class T> __device__ __forceinline__ const __attribute__((address_space(1))) T* G(const T* p) {
+    return (const __attribute__((address_space(1))) T*)p;
+}
+
 // Index of (absolute SNP position, allele) in the linear-hash multiplier tables.  Any window of <= HASH_M consecutive
 // positions maps injectively, and the index does not depend on the block, so a read's hash constant is precomputed once.
 constexpr uint32_t HASH_M = 65536;

@@ -63,9 +63,9 @@ __global__ __launch_bounds__(GRAPH_THREADS) void graph_kernel(GraphArgs g) {
     for (uint32_t i = grp; i < n16; i += GRAPH_THREADS / 16) {
         if (i < n) {
             const uint32_t r = reads[i], k = part[i];
-            const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+            const uint32_t cb = G(cd.read_off)[r], ce = G(cd.read_off)[r + 1];
             for (uint32_t c = cb + sub; c < ce; c += 16) {
-                const uint32_t sn = cd.cell_snp[c], aq = cd.cell_aw[c];
+                const uint32_t sn = G(cd.cell_snp)[c], aq = G(cd.cell_aw)[c];
                 if (sn >= lo && sn <= hi)
                     atomicAdd((unsigned long long*)&hist[(uint64_t)(sn - lo) * PA + k * A + (aq >> 28)], (unsigned long long)((1ull << CNT_SHIFT) | (aq & 0x0fffffffu)));
             }
@@ -130,14 +130,14 @@ __global__ __launch_bounds__(GRAPH_THREADS) void graph_kernel(GraphArgs g) {
             r = reads1[i]; k1 = part1[i];
             uint32_t l = 0, h = n;                                  // read lists ascend: binary search r in b'
             while (l < h) { const uint32_t mid = (l + h) >> 1; if (reads[mid] < r) l = mid + 1; else h = mid; }
-            if (l < n && reads[l] == r) { common = true; k2 = part[l]; cb = cd.read_off[r]; ce = cd.read_off[r + 1]; }
+            if (l < n && reads[l] == r) { common = true; k2 = part[l]; cb = G(cd.read_off)[r]; ce = G(cd.read_off)[r + 1]; }
         }
         uint64_t acc[MAX_PLOIDY];
 #pragma unroll
         for (int l = 0; l < MAX_PLOIDY; ++l) acc[l] = 0;
         if (common) {
             for (uint32_t c = cb + sub; c < ce; c += 16) {
-                const uint32_t sn = cd.cell_snp[c], aq = cd.cell_aw[c], al = aq >> 28;
+                const uint32_t sn = G(cd.cell_snp)[c], aq = G(cd.cell_aw)[c], al = aq >> 28;
                 if (sn < lo || sn > hi) continue;                    // outside the block: not a key of any node's hap_map
                 const uint64_t w = (aq & 0x0fffffffu);
                 const uint64_t* row = hist + (uint64_t)(sn - lo) * PA;

@@ -147,12 +147,12 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             const uint32_t r = reads[i], k = pin[i];
             part[i] = (uint8_t)k;
             atomicAdd(&s_size[k], 1u);
-            if (meta) { const uint32_t cb = cd.read_off[r]; m_cb[i] = cb; m_lk[i] = (cd.read_off[r + 1] - cb) | (k << 24); }
+            if (meta) { const uint32_t cb = G(cd.read_off)[r]; m_cb[i] = cb; m_lk[i] = (G(cd.read_off)[r + 1] - cb) | (k << 24); }
         }
         __syncthreads();
         auto read_meta = [&](uint32_t i, uint32_t& cb, uint32_t& len, uint32_t& k) {
             if (meta) { cb = m_cb[i]; const uint32_t lk = m_lk[i]; len = lk & 0xffffffu; k = lk >> 24; }
-            else { const uint32_t r = reads[i]; cb = cd.read_off[r]; len = cd.read_off[r + 1] - cb; k = part[i]; }
+            else { const uint32_t r = reads[i]; cb = G(cd.read_off)[r]; len = G(cd.read_off)[r + 1] - cb; k = part[i]; }
         };
         // 16 lanes per read (4 reads per wavefront, 16 per workgroup pass): 64-B coalesced cell segments, up to 8 cells
         // per lane loaded before the first atomic
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {
                 uint32_t sn[8], aqs[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aw[cb + c] : 0xffffffffu; }
+                for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? G(cd.cell_snp)[cb + c] : 0; aqs[u] = v ? G(cd.cell_aw)[cb + c] : 0xffffffffu; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (aqs[u] != 0xffffffffu)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     for (uint32_t c0 = sub; c0 < len; c0 += 16 * 4) {
                         uint32_t sn[4], aqs[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? cd.cell_snp[cb + c] : 0; aqs[u] = v ? cd.cell_aw[cb + c] : 0xffffffffu; }
+                        for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + 16 * u; const bool v = c < len; sn[u] = v ? G(cd.cell_snp)[cb + c] : 0; aqs[u] = v ? G(cd.cell_aw)[cb + c] : 0xffffffffu; }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (aqs[u] != 0xffffffffu) {
@@ -315,11 +315,11 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         uint32_t from = (mvv >> 4) & 15, to = mvv & 15;
                         if (undo) { uint32_t t = from; from = to; to = t; }
                         const uint32_t r = reads[rl];
-                        const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+                        const uint32_t cb = G(cd.read_off)[r], ce = G(cd.read_off)[r + 1];
                         for (uint32_t c = cb + lane; c < ce; c += 64) {
-                            const uint32_t aq = cd.cell_aw[c];
+                            const uint32_t aq = G(cd.cell_aw)[c];
                             const unsigned long long d = (1ull << CNT_SHIFT) | (aq & 0x0fffffffu);
-                            uint64_t* cp = hist + (uint64_t)(cd.cell_snp[c] - pos0) * PA + (aq >> 28);
+                            uint64_t* cp = hist + (uint64_t)(G(cd.cell_snp)[c] - pos0) * PA + (aq >> 28);
                             atomicAdd((unsigned long long*)(cp + from * A), 0ull - d);
                             atomicAdd((unsigned long long*)(cp + to * A), d);
                         }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
             const uint32_t r = ord ? ord[v] : v;
             const uint64_t c0 = roff[r], c1 = roff[r + 1];
             if (c0 == c1) continue;                              // assign[] was preset to -1
-            const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+            const uint32_t cb = G(cd.read_off)[r], ce = G(cd.read_off)[r + 1];
             uint32_t best = r2g[c0];
             if (c1 - c0 > 1) {
                 double bd = 0.0, bsame = 0.0;
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
                     const uint32_t p0 = g.grp_pos0[gb + gid];
                     uint64_t qs = 0, qd = 0; uint32_t m = 0;
                     for (uint32_t c = cb + lane; c < ce; c += 64) {          // utils_frags.rs:32-75
-                        const uint32_t aq = cd.cell_aw[c], al = aq >> 28;
-                        const uint64_t* cp = h + (uint64_t)(cd.cell_snp[c] - p0) * A;
+                        const uint32_t aq = G(cd.cell_aw)[c], al = aq >> 28;
+                        const uint64_t* cp = h + (uint64_t)(G(cd.cell_snp)[c] - p0) * A;
                         uint64_t mx = 0, va = 0;
 #pragma unroll
                         for (int a = 0; a < A; ++a) { const uint64_t q = cp[a]; mx = q > mx ? q : mx; va = (a == (int)al) ? q : va; }
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(64) void reassign_kernel(ReassignArgs g) {
                 uint64_t* h = g.hist + g.grp_hist_off[gb + best];
                 const uint32_t p0 = g.grp_pos0[gb + best];
                 for (uint32_t c = cb + lane; c < ce; c += 64) {
-                    const uint32_t aq = cd.cell_aw[c];
-                    h[(uint64_t)(cd.cell_snp[c] - p0) * A + (aq >> 28)] += (aq & 0x0fffffffu);
+                    const uint32_t aq = G(cd.cell_aw)[c];
+                    h[(uint64_t)(G(cd.cell_snp)[c] - p0) * A + (aq >> 28)] += (aq & 0x0fffffffu);
                 }
             }
             if (lane == 0) assign[r] = (int32_t)best;

@@ -37,10 +37,10 @@ __global__ __launch_bounds__(256) void stats_kernel(StatsArgs g) {
         const uint64_t r0 = g.grp_off[gi], r1 = g.grp_off[gi + 1];
         for (uint64_t i = r0 + grp; i < r1; i += 16) {                    // 16 lanes per read
             const uint32_t r = g.grp_read[i];
-            const uint32_t cb = cd.read_off[r], ce = cd.read_off[r + 1];
+            const uint32_t cb = G(cd.read_off)[r], ce = G(cd.read_off)[r + 1];
             for (uint32_t c = cb + sub; c < ce; c += 16) {
-                const uint32_t sn = cd.cell_snp[c];
-                if (sn >= lo && sn <= hi) atomicAdd(&hist[(uint64_t)(sn - lo) * A + (cd.cell_aw[c] >> 28)], 1u);
+                const uint32_t sn = G(cd.cell_snp)[c];
+                if (sn >= lo && sn <= hi) atomicAdd(&hist[(uint64_t)(sn - lo) * A + (G(cd.cell_aw)[c] >> 28)], 1u);
             }
         }
         __syncthreads();
