@@ -378,6 +378,9 @@ void beam_slab_kernel(BeamArgs g) {
             // ---- B: per (state, partition) pair: p-value, log-sum-exp, pruning, child (:74-134) -----------------------
             uint64_t evalid = 0;
             H.len = 0;
+            bool bulk = false;                       // this step took the no-duplicate / no-eviction path
+            uint64_t b_q = 0, b_h1 = 0, b_h2 = 0;    // its children (lane = (state, partition) pair)
+            uint32_t b_m = 0, src_map = 0;           // lane r = child lane of entry r
             for (uint32_t a0 = 0; a0 < nstates; a0 += S) {
                 const uint32_t a = a0 + my_sl;
                 const bool act = lane_pair && a < nstates;
@@ -437,6 +440,37 @@ void beam_slab_kernel(BeamArgs g) {
 #ifdef FLORIA_PROF
                 c_pass += (uint32_t)__popcll(passmask);
 #endif
+                // Common case (measured: 4.2 children pass per step, 0.06 % are duplicates, 1 % of the pushes overflow the heap): one batch,
+                // no more children than the heap holds, and pairwise distinct state hashes (tested with a 256-slot LDS table: a slot
+                // collision only sends the step down the general path).  Then every child is inserted, nothing is evicted, entry id =
+                // rank among the passing lanes: the entry table is skipped (the survivors gather straight from the child lanes in M)
+                // and only the std::BinaryHeap pushes remain.
+                if (a0 == 0 && nstates <= S) {
+                    const uint32_t npass = (uint32_t)__popcll(passmask);
+                    if (npass != 0 && npass <= limit) {
+                        volatile uint8_t* tab = (volatile uint8_t*)s_pk;     // 256 B, free until phase M; volatile: other LANES write the slot too,
+                                                                             // the compiler must not forward this lane's store to its load
+                        s_pk[lane] = 0xffffffffu;
+                        const uint32_t slot = (uint32_t)(ch1 ^ (ch1 >> 31) ^ (ch2 >> 17)) & 255u;
+                        if (pass) tab[slot] = (uint8_t)lane;
+                        const bool coll = pass && tab[slot] != (uint8_t)lane;
+                        if (!__any(coll)) {
+                            bulk = true;
+                            b_q = cq; b_h1 = ch1; b_h2 = ch2; b_m = cm;
+                            uint32_t r = 0;
+                            while (passmask) {
+                                const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
+                                passmask &= passmask - 1;
+                                wl32(src_map, src, r);
+                                H.push(rl64(cs, src), r);
+                                ++r;
+                            }
+#ifdef FLORIA_PROF
+                            c_push += npass;
+#endif
+                        }
+                    }
+                }
                 while (passmask) {
                     const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
                     passmask &= passmask - 1;
@@ -461,8 +495,16 @@ void beam_slab_kernel(BeamArgs g) {
             const uint32_t nnext = H.len;
             const bool surv = lane < nnext;
             const uint32_t eid = surv ? H.hp_id : 0;
-            const uint64_t n_q = shfl_u64(ev_q, (int)eid), n_h1 = shfl_u64(ev_h1, (int)eid), n_h2 = shfl_u64(ev_h2, (int)eid);
-            const uint32_t n_m = __shfl(ev_m, (int)eid), n_pk = __shfl(ev_pk, (int)eid);
+            uint64_t n_q, n_h1, n_h2;
+            uint32_t n_m, n_pk;
+            if (bulk) {
+                const int esrc = (int)__shfl(src_map, (int)eid);
+                n_q = shfl_u64(b_q, esrc); n_h1 = shfl_u64(b_h1, esrc); n_h2 = shfl_u64(b_h2, esrc);
+                n_m = __shfl(b_m, esrc); n_pk = __shfl(my_sl | (my_k << 16), esrc);
+            } else {
+                n_q = shfl_u64(ev_q, (int)eid); n_h1 = shfl_u64(ev_h1, (int)eid); n_h2 = shfl_u64(ev_h2, (int)eid);
+                n_m = __shfl(ev_m, (int)eid); n_pk = __shfl(ev_pk, (int)eid);
+            }
             const uint32_t pj = n_pk & 0xffff, kj = n_pk >> 16;
             uint64_t* nx_q = ST_q(cur ^ 1); uint64_t* nx_h1 = ST_h1(cur ^ 1); uint64_t* nx_h2 = ST_h2(cur ^ 1);
             uint32_t* nx_m = ST_m(cur ^ 1); uint16_t* nx_sl = ST_sl(cur ^ 1);
