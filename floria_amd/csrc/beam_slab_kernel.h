@@ -394,7 +394,8 @@ void beam_slab_kernel(BeamArgs g) {
                     if (trunc) { t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2; }
                     if (Q0) { np1 = r_np1[li]; np2 = r_np2[li]; }
                     const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
-                    const uint64_t nn = (uint64_t)(same_f + diff_f), kk = (uint64_t)diff_f;
+                    // `as usize` of the two sums: both are < 2^32 (a read has < 2^32 cells of weight <= 1), so the 1-instruction u32 conversion is exact
+                    const uint32_t nn = (uint32_t)(same_f + diff_f), kk = (uint32_t)diff_f;
                     if (nn <= g.binom_nmax) pv = g.binom_tab[nn * (nn + 1) / 2 + kk];
                     else { pv = binom_device(nn, kk, g.eps, g.div_factor); n_fallback++; }
                 }

@@ -95,6 +95,11 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 __device__ __forceinline__ double qm_to_f64(uint64_t q, uint64_t m, double eps) {
     return (double)q * 0x1p-24 + (double)m * eps;
 }
+// same value for a 32-bit count (one v_cvt_f64_u32 instead of the u64 -> f64 sequence)
+__device__ __forceinline__ double qm_to_f64(uint64_t q, uint32_t m, double eps) {
+    return (double)q * 0x1p-24 + (double)m * eps;
+}
+__device__ __forceinline__ double qm_to_f64(uint64_t q, int m, double eps) { return qm_to_f64(q, (uint32_t)m, eps); }
 
 // stable_binom_cdf_p_rev (utils_frags.rs:211-248) with device libm — only used beyond the host-built
 // table (n > binom_nmax); see beam kernel.
