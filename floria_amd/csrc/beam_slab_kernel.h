@@ -27,6 +27,16 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 // segmented all-reduce (sum) over aligned groups of Gs = 2,4,8,16 lanes with DPP row operations
+// log(sum_j exp(dx_j)) over the p lanes of a state, own term evaluated once, summed in the reference's order j = 0..p-1.  Runs in the few
+// steps that the f32 screen cannot decide; kept out of line so that its f64 exp/log temporaries do not count against the kernel's
+// steady-state register budget.
+__device__ __attribute__((noinline)) double log_sum_exp_terms(double dx, int seg0, uint32_t p) {
+    const double ex = exp(dx);
+    double sum = 0.0;
+    for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
+    return log(sum);
+}
+
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
 template <int CTRL> __device__ __forceinline__ uint64_t dpp_mov64(uint64_t v) { return ((uint64_t)dpp_mov<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_mov<CTRL>((uint32_t)v); }
 __device__ __forceinline__ uint64_t seg_sum_u64(uint64_t v, uint32_t Gs) {
@@ -97,7 +107,10 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 // TP / TB: ploidy and beam width as compile-time constants (0 = read them from the arguments): LDS offsets become immediates, the
 // per-partition loops unroll and divisions by p turn into multiplications; the host picks TP = p, TB = 10 for the CLI's default beam.
 template <int A, bool Q0, int TP = 0, int TB = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLORIA_FAST_WAVES, FLORIA_FAST_WAVES)))
+#ifndef FLORIA_SLAB_WAVES_LOW_P
+#define FLORIA_SLAB_WAVES_LOW_P 4      // ploidy 2 and 3 instances: 126-128 VGPRs and < 10 KB of LDS per wave -> 4 waves per SIMD
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TP == 2 || TP == 3) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES, (TP == 2 || TP == 3) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES)))
 void beam_slab_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
@@ -312,8 +325,11 @@ void beam_slab_kernel(BeamArgs g) {
                     if (A == 2) {
                         const uint64_t v0 = Q0 ? (vv[0].x & QMASK63) : vv[0].x, v1 = Q0 ? (vv[0].y & QMASK63) : vv[0].y;
                         nonempty = (v0 | v1) != 0;
-                        same = al ? (v1 >= v0) : (v0 >= v1);
-                        va = al ? vv[0].y : vv[0].x;
+                        // same <=> the read's allele holds the larger-or-equal sum <=> equal sums, or (allele == 1) != (v1 < v0); integer form
+                        // (sums are < 2^63, so the sign of the difference is the comparison) - hipcc turns the select form into 0/1 VGPR traffic
+                        const uint64_t d = v1 - v0;
+                        same = d == 0 || ((al ^ (uint32_t)(d >> 63)) & 1u) != 0;
+                        va = Q0 ? (al ? vv[0].y : vv[0].x) : 0;
                     } else {
                         uint64_t v[A];
 #pragma unroll
@@ -419,9 +435,7 @@ void beam_slab_kernel(BeamArgs g) {
                 const bool far_enough = ascr >= PRUNE_SCREEN && ascr - PRUNE_SCREEN >= min_margin;     // false for NaN
                 bool pass = dscr > 0.0;
                 if (__any(act && !far_enough)) {
-                    const double ex = exp(dx);               // own term once; the sum runs in the reference's order j = 0..p-1
-                    for (uint32_t j = 0; j < p; ++j) sum += shfl_f64(ex, seg0 + (int)j);
-                    const double lse = mx + log(sum);
+                    const double lse = mx + log_sum_exp_terms(dx, seg0, p);
                     const double am = fabs((pv - lse) - g.cutoff);
                     if (act) min_margin = am < min_margin ? am : min_margin;
                     pass = (pv - lse) > g.cutoff;
