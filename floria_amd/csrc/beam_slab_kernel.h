@@ -107,10 +107,13 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 // TP / TB: ploidy and beam width as compile-time constants (0 = read them from the arguments): LDS offsets become immediates, the
 // per-partition loops unroll and divisions by p turn into multiplications; the host picks TP = p, TB = 10 for the CLI's default beam.
 template <int A, bool Q0, int TP = 0, int TB = 0>
+#ifndef FLORIA_SLAB_LOW_P_MAX
+#define FLORIA_SLAB_LOW_P_MAX 3
+#endif
 #ifndef FLORIA_SLAB_WAVES_LOW_P
 #define FLORIA_SLAB_WAVES_LOW_P 4      // ploidy 2 and 3 instances: 126-128 VGPRs and < 10 KB of LDS per wave -> 4 waves per SIMD
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TP == 2 || TP == 3) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES, (TP == 2 || TP == 3) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TP >= 2 && TP <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES, (TP >= 2 && TP <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES)))
 void beam_slab_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
@@ -415,7 +418,7 @@ void beam_slab_kernel(BeamArgs g) {
                     if (nn <= g.binom_nmax) pv = g.binom_tab[nn * (nn + 1) / 2 + kk];
                     else { pv = binom_device(nn, kk, g.eps, g.div_factor); n_fallback++; }
                 }
-                double mx = 0.0, sum = 0.0;
+                double mx = 0.0;
                 uint64_t ts1 = 0, ts2 = 0;
                 for (uint32_t j = 0; j < p; ++j) {
                     const double o = shfl_f64(pv, seg0 + (int)j);

@@ -103,7 +103,8 @@ __device__ __forceinline__ double qm_to_f64(uint64_t q, int m, double eps) { ret
 
 // stable_binom_cdf_p_rev (utils_frags.rs:211-248) with device libm — only used beyond the host-built
 // table (n > binom_nmax); see beam kernel.
-__device__ inline double binom_device(uint64_t n, uint64_t k, double p, double div_factor) {
+// (out of line: only reached for n beyond the host-built table, and its libm temporaries would otherwise set the callers' register peak)
+__device__ __attribute__((noinline)) double binom_device(uint64_t n, uint64_t k, double p, double div_factor) {
     if (n == 0) return 0.0;
     double n64 = (double)n, k64 = (double)k;
     double a = k64 / n64;

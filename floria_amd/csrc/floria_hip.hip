@@ -322,7 +322,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         const fl::WideLds WL = fl::wide_lds_layout(LM, p, any_q0);
         const fl::BeamLds LY = fl::beam_lds_layout(LM);
         const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL.total + 256)));
-        const uint32_t waves_per_simd = (A == 2 && !any_q0 && B == 10 && (p == 2 || p == 3) && !getenv("FLORIA_HIP_NO_SPECIALIZED")) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES;
+        const uint32_t waves_per_simd = (A == 2 && !any_q0 && B == 10 && p >= 2 && p <= FLORIA_SLAB_LOW_P_MAX && !getenv("FLORIA_HIP_NO_SPECIALIZED")) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES;
         uint32_t beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * waves_per_simd, by_lds);
         beam_slots = std::min(beam_slots, n_jobs);
         const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
