@@ -28,11 +28,24 @@ for k in f:
         fk,nl=f[k]; wk,_=w.get(k,(0,nl))
         out["kernels"][k]={"launches":nl,"fetch_kib":fk,"write_kib":wk,"hbm_bytes_per_launch_raw":(fk+wk)*1024/nl,"hbm_bytes_per_launch_corrected":(2*fk+wk)*1024/nl}
 bk=[k for k in out["kernels"] if "beam_slab" in k]
-if bk: out["hbm_bytes_per_launch"]=out["kernels"][bk[0]]["hbm_bytes_per_launch_corrected"]
+if bk:      # calls-weighted mean over the kernel's ploidy-specialised instances (bench.py's roofline.traffic)
+    out["hbm_bytes_per_launch"]=sum(out["kernels"][k]["hbm_bytes_per_launch_corrected"]*out["kernels"][k]["launches"] for k in bk)/sum(out["kernels"][k]["launches"] for k in bk)
 json.dump(out, open(O+"/pmc_summary.json","w"), indent=1)
 print(json.dumps(out)[:600])
 PY
 cp $O/stats/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+python - <<PY
+import csv, json
+rows=list(csv.DictReader(open("$O/kernel_stats.csv")))
+fam={}
+for key in ("beam_slab_kernel","optimize_kernel"):
+    rs=[r for r in rows if key in r["Name"]]
+    calls=sum(int(r["Calls"]) for r in rs); tot=sum(float(r["TotalDurationNs"]) for r in rs)
+    fam[key]={"instances":[{"name":r["Name"].split("(")[0],"calls":int(r["Calls"]),"avg_ms":float(r["AverageNs"])/1e6} for r in rs],
+              "calls":calls,"avg_launch_ms":tot/calls/1e6 if calls else None,"total_ms":tot/1e6}
+json.dump({"note":"per-family aggregate of rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1): the ploidy-specialised instances of one kernel are separate rows in kernel_stats.csv; bench.py's roofline.avg_launch_ms is the calls-weighted mean over the beam_slab_kernel family","families":fam}, open("$O/kernel_family_stats.json","w"), indent=1)
+print(json.dumps({k:(v["calls"],round(v["avg_launch_ms"],3)) for k,v in fam.items()}))
+PY
 grep '^{' $O/bench_stats.log | tail -1 > $O/bench.json
 # ---- SQ counters (two more passes): VALU / SALU / LDS / VMEM instruction counts, busy and wait cycles per kernel --------------------
 cd /tmp
