@@ -70,3 +70,31 @@ def test_lpt_assignment_is_balanced_and_deterministic():
     loads = [costs[my_items(o, r)].sum() for r in range(4)]
     assert max(loads) - min(loads) <= costs.max()
     assert sorted(np.concatenate([my_items(o, r) for r in range(4)])) == list(range(101))
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """sizeof / offsetof of every struct in include/floria_hip.h, measured by gcc, equal the ctypes mirrors in floria_amd/_capi.py
+    (a drifted mirror would read garbage through the C ABI without any error)."""
+    import ctypes as C
+    import subprocess
+    from floria_amd import _capi as capi
+    pairs = {"floria_pileup": capi.CPileup, "floria_params": capi.CParams, "floria_block_result": capi.CBlockResult,
+             "floria_groups": capi.CGroups, "floria_ranges": capi.CRanges, "floria_timing": capi.CTiming, "floria_hap_graph": capi.CHapGraph}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "floria_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for line in out:
+        name, size, *offs = line.split()
+        cls = pairs[name]
+        assert int(size) == C.sizeof(cls), f"{name}: header {size} B, ctypes {C.sizeof(cls)} B"
+        assert [int(o) for o in offs] == [getattr(cls, f).offset for f, _ in cls._fields_], name
