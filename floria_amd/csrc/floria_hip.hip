@@ -31,6 +31,7 @@
 #include "beam_wide_kernel.h"
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
+#include "hapq_kernel.h"
 #include "blocks_kernel.h"
 #include "graph_kernel.h"
 #include "stats_kernel.h"
@@ -989,6 +990,114 @@ int floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* cons
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out4, M + s_out.off, 32ull * n_groups, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- get_hapq (part_block_manip.rs:517-616) for the haplosets of one contig --------------------------------------------------
+int floria_hip_hapq(floria_hip_ctx* ctx, const floria_hip_contig* contig, const uint64_t* grp_off, const uint32_t* grp_read,
+                    const uint32_t* grp_range, uint32_t n_groups, const uint64_t* snp_to_genome_pos, uint32_t n_snps,
+                    uint64_t block_length, uint8_t* hapq, double* rel_err, double* avg_err) {
+    if (!ctx || !contig || !avg_err || (n_groups && (!grp_off || !grp_range || !hapq || !rel_err))) return fail(FLORIA_E_INVALID, "null argument");
+    if (contig->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
+    if (block_length == 0) return fail(FLORIA_E_INVALID, "block_length must be positive");
+    if (n_groups == 0) { *avg_err = std::numeric_limits<double>::quiet_NaN(); return 0; }      // 0. / 0. (:540)
+    // (1) get_errors_cov_from_frags per haploset (:529-539)
+    std::vector<double> st(4ull * n_groups);
+    const floria_hip_contig* one[1] = {contig};
+    int rc = floria_hip_haploset_stats(ctx, one, 1, nullptr, grp_off, grp_read, grp_range, n_groups, st.data());
+    if (rc) return rc;
+    double weight = 0., error = 0.;
+    for (uint32_t g = 0; g < n_groups; ++g) { weight += st[4ull * g + 3]; error += st[4ull * g + 2]; }
+    const double avgerr = error / weight;
+    // spans of the haplosets' reads (the consensus haplotype has a key wherever a read has a cell) and base ranges (:584-600)
+    const uint32_t A = contig->n_alleles;
+    std::vector<uint32_t> lo(n_groups, 0), len(n_groups, 0);
+    std::vector<uint64_t> coff(n_groups + 1, 0), base_range(n_groups, 0);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        uint32_t r0 = 0xffffffffu, r1 = 0;
+        for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
+            const uint32_t r = grp_read[i];                                 // (validated by floria_hip_haploset_stats)
+            r0 = std::min(r0, contig->h_first[r]); r1 = std::max(r1, contig->h_last[r]);
+        }
+        if (!(r0 > r1)) {
+            lo[g] = r0; len[g] = r1 - r0 + 1;
+            const uint32_t x1 = grp_range[2 * g], x2 = grp_range[2 * g + 1];
+            if (!snp_to_genome_pos || x1 == 0 || x2 == 0 || x1 > n_snps || x2 > n_snps) return fail(FLORIA_E_INVALID, "haploset range outside snp_to_genome_pos");
+            base_range[g] = snp_to_genome_pos[x2 - 1] - snp_to_genome_pos[x1 - 1];
+        }
+        coff[g + 1] = coff[g] + len[g];
+    }
+    // (2) find_overlapping_blocks (:453-513): rust-lapper's half-open overlap, overlap_percent (:13-24) > 0.05
+    std::vector<uint32_t> pi, pj;
+    std::vector<double> pol;
+    std::vector<uint64_t> pair_off(n_groups + 1, 0);
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        const uint32_t x1 = grp_range[2 * i], x2 = grp_range[2 * i + 1];
+        for (uint32_t j = 0; j < n_groups; ++j) {
+            if (j == i) continue;
+            const uint32_t y1 = grp_range[2 * j], y2 = grp_range[2 * j + 1];
+            if (!(y1 < x2 && y2 > x1)) continue;
+            const uint32_t a = x2 - y1 + 1, b = y2 - x1 + 1;
+            double ol = (double)std::min(a, b) / (double)(x2 - x1 + 1);
+            if (ol > 1.) ol = 1.;
+            if (!(ol > 0.05)) continue;
+            pi.push_back(i); pj.push_back(j); pol.push_back(ol);
+        }
+        pair_off[i + 1] = pi.size();
+    }
+    const uint32_t n_pairs = (uint32_t)pi.size();
+    std::vector<uint32_t> sd(2ull * n_pairs + 2, 0);
+    if (n_pairs) {
+        HIPCHK(hipSetDevice(ctx->device));
+        ctx->batch_token = 0;
+        const uint64_t n_reads_tot = grp_off[n_groups];
+        struct Seg { size_t off, bytes; };
+        size_t cursor = 0;
+        auto seg = [&](size_t bytes) { Seg sg{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return sg; };
+        const Seg s_cd = seg(sizeof(fl::ContigDev)), s_go = seg(8ull * (n_groups + 1)), s_gr = seg(4ull * n_reads_tot + 4), s_lo = seg(4ull * n_groups),
+                  s_len = seg(4ull * n_groups), s_co = seg(8ull * (n_groups + 1)), s_h = seg(8ull * coff[n_groups] * A + 8), s_c = seg(coff[n_groups] + 8),
+                  s_pi = seg(4ull * n_pairs), s_pj = seg(4ull * n_pairs), s_sd = seg(8ull * n_pairs);
+        rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
+        char* M = ctx->misc.as<char>();
+        auto h2d = [&](Seg sg, const void* src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(M + sg.off, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; };
+        HIPCHK(h2d(s_cd, &contig->dev, sizeof(fl::ContigDev))); HIPCHK(h2d(s_go, grp_off, 8ull * (n_groups + 1))); HIPCHK(h2d(s_gr, grp_read, 4ull * n_reads_tot));
+        HIPCHK(h2d(s_lo, lo.data(), 4ull * n_groups)); HIPCHK(h2d(s_len, len.data(), 4ull * n_groups)); HIPCHK(h2d(s_co, coff.data(), 8ull * (n_groups + 1)));
+        HIPCHK(h2d(s_pi, pi.data(), 4ull * n_pairs)); HIPCHK(h2d(s_pj, pj.data(), 4ull * n_pairs));
+        HIPCHK(hipMemsetAsync(M + s_h.off, 0, s_h.bytes, ctx->stream));
+        fl::ConsensusArgs ca{};
+        ca.contig = (const fl::ContigDev*)(M + s_cd.off); ca.grp_off = (const uint64_t*)(M + s_go.off); ca.grp_read = (const uint32_t*)(M + s_gr.off);
+        ca.span_lo = (const uint32_t*)(M + s_lo.off); ca.span_len = (const uint32_t*)(M + s_len.off); ca.cons_off = (const uint64_t*)(M + s_co.off);
+        ca.hist = (unsigned long long*)(M + s_h.off); ca.cons = (uint8_t*)(M + s_c.off); ca.n_groups = n_groups;
+        if (A == 2) hipLaunchKernelGGL(fl::consensus_kernel<2>, dim3(n_groups), dim3(256), 0, ctx->stream, ca);
+        else hipLaunchKernelGGL(fl::consensus_kernel<4>, dim3(n_groups), dim3(256), 0, ctx->stream, ca);
+        HIPCHK(hipGetLastError());
+        fl::PairArgs pa{};
+        pa.pair_i = (const uint32_t*)(M + s_pi.off); pa.pair_j = (const uint32_t*)(M + s_pj.off); pa.span_lo = ca.span_lo; pa.span_len = ca.span_len;
+        pa.cons_off = ca.cons_off; pa.cons = ca.cons; pa.same_diff = (uint32_t*)(M + s_sd.off); pa.n_pairs = n_pairs;
+        hipLaunchKernelGGL(fl::pair_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sd.data(), M + s_sd.off, 8ull * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    // (3) the scalar tail (:543-615), same operation order as the reference
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        double max_penalty = 0.;
+        for (uint64_t x = pair_off[i]; x < pair_off[i + 1]; ++x) {
+            const double same = (double)sd[2 * x], diff = (double)sd[2 * x + 1];
+            const double dist = (same + diff) == 0. ? 1. : diff / (same + diff);
+            if (pol[x] * (1. - dist) > max_penalty) max_penalty = pol[x] * (1. - dist);
+        }
+        const uint64_t n_i = grp_off[i + 1] - grp_off[i];
+        const double t1 = 40. * (1. - max_penalty);                                   // constants::HAPQ_CONSTANT
+        const double t2 = std::min(1., (double)n_i / 3.);
+        const double t3 = std::max(0.0, std::log(((double)base_range[i] / (double)block_length) + 1.));
+        const double prod = t1 * t2 * t3;
+        uint64_t hq = prod > 0. ? (prod >= 18446744073709551615. ? ~0ull : (uint64_t)prod) : 0;      // `as usize`: saturating, NaN -> 0
+        if (n_i == 1) hq = 0;
+        hapq[i] = (uint8_t)std::min<uint64_t>(hq, 60);
+        rel_err[i] = st[4ull * i + 1] / avgerr;
+    }
+    *avg_err = avgerr;
     return 0;
 }
 

@@ -49,9 +49,14 @@ __global__ __launch_bounds__(256) void stats_kernel(StatsArgs g) {
         for (uint32_t pr = tid; pr <= hi - lo; pr += 256) {
             uint32_t support = 0, mx = 0;
             bool any = false;
+            uint32_t cn[A];
+            bool all = true;
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
-                const uint32_t cnt = hist[(uint64_t)pr * A + a];
+            for (int a = 0; a < A; ++a) { cn[a] = hist[(uint64_t)pr * A + a]; all = all && cn[a] != 0; }
+#pragma unroll
+            for (int x = 0; x < A; ++x) {            // the inner map's iteration order: ascending, except 0,2,1,3 with all four alleles (hapq_kernel.h)
+                const int a = (A == 4 && all) ? (x == 1 ? 2 : x == 2 ? 1 : x) : x;
+                const uint32_t cnt = cn[a];
                 if (cnt) { any = true; if (cnt > support) mx = cnt; support += cnt; }      // :619-625
             }
             if (any) { nz++; sup += support; err += support - mx; }

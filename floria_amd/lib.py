@@ -25,6 +25,7 @@ SYMBOLS = [
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
     "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
     "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered", "floria_hip_haploset_stats",
+    "floria_hip_hapq",
 ]
 
 
@@ -192,6 +193,21 @@ class FloriaHip:
         _check(load().floria_hip_haploset_stats(self._h, arr, C.c_uint32(len(contigs)), capi.ptr(gc, C.c_uint32), capi.ptr(off, C.c_uint64),
                                                 capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), capi.ptr(out, C.c_double)))
         return out
+
+    def hapq(self, contig, groups, ranges, snp_to_genome_pos, block_length):
+        """get_hapq (part_block_manip.rs:517-616) for one contig's haplosets -> (hapq uint8 [n], rel_err float64 [n], avg_err)."""
+        off = np.zeros(len(groups) + 1, np.uint64)
+        off[1:] = np.cumsum([len(g) for g in groups])
+        reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
+        rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+        pos = np.ascontiguousarray(snp_to_genome_pos, np.uint64)
+        hq = np.zeros(len(groups), np.uint8)
+        rel = np.zeros(len(groups), np.float64)
+        avg = C.c_double(0)
+        _check(load().floria_hip_hapq(self._h, contig._h, capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
+                                      C.c_uint32(len(groups)), capi.ptr(pos, C.c_uint64), C.c_uint32(len(pos)), C.c_uint64(int(block_length)),
+                                      capi.ptr(hq, C.c_uint8), capi.ptr(rel, C.c_double), C.byref(avg)))
+        return hq, rel, avg.value
 
     # S2 --------------------------------------------------------------------------------------------
     def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon, read_orders=None):

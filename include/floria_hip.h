@@ -215,6 +215,15 @@ int  floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* con
                                const uint32_t* grp_contig, const uint64_t* grp_off, const uint32_t* grp_read,
                                const uint32_t* grp_range, uint32_t n_groups, double* out4);
 
+/* part_block_manip::get_hapq (part_block_manip.rs:517-616 — the HAPQ and REL_ERR fields of the vartig / haploset headers and the
+ * avg_err column of the contig ploidy table) for the haplosets of one contig: groups are read-id lists (counter_ids) with their
+ * inclusive 1-based SNP ranges; snp_to_genome_pos[s-1] is the base position of SNP s; block_length is the run's -l.
+ * hapq[g] in 0..60, rel_err[g] = err_g / avg_err (NaN / inf exactly where the reference's f64 division gives them). */
+int  floria_hip_hapq(floria_hip_ctx* ctx, const floria_hip_contig* contig,
+                     const uint64_t* grp_off, const uint32_t* grp_read, const uint32_t* grp_range, uint32_t n_groups,
+                     const uint64_t* snp_to_genome_pos, uint32_t n_snps, uint64_t block_length,
+                     uint8_t* hapq, double* rel_err, double* avg_err);
+
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */

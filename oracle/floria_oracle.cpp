@@ -919,8 +919,29 @@ int floria_oracle_hap_graph(const floria_pileup* pileup, const uint32_t* blk_sta
     return 0;
 }
 
-// get_errors_cov_from_frags (utils_frags.rs:596-655) for one haploset: unit-count histogram over [lo, hi]; alleles visited in
-// ascending order (the reference's inner-map order; immaterial for biallelic sites).
+// Iteration order of the inner allele map `FxHashMap<Genotype, GenotypeCount>` (types_structs.rs:15), derived — NOT observed, there is
+// no Rust toolchain here — from fxhash 0.2.1 (hash(u8 k) = k * 0x517cc1b727220a95) and hashbrown's layout (slot = hash & bucket_mask,
+// buckets scanned in ascending index; 4 buckets for <= 3 keys, 8 buckets from the 4th key on): keys {0,1,2,3} land in slots
+// {0,1,2,3} of a 4-bucket table and in slots {0,5,2,7} of an 8-bucket one, so the order is ascending for <= 3 present alleles and
+// 0,2,1,3 when all four are present.
+static inline void allele_order(uint8_t present, int order[FLORIA_MAX_ALLELES], int* n) {
+    static const int asc[4] = {0, 1, 2, 3}, four[4] = {0, 2, 1, 3};
+    const int* o = (present & 15) == 15 ? four : asc;
+    *n = 0;
+    for (int x = 0; x < 4; ++x) if ((present >> o[x]) & 1) order[(*n)++] = o[x];
+}
+// consensus allele of a site: `.iter().max_by_key(|entry| entry.1)` (utils_frags.rs:674-688) — the LAST maximal element in
+// iteration order
+static inline int consensus_allele(const Site& s) {
+    int order[FLORIA_MAX_ALLELES], n;
+    allele_order(s.present, order, &n);
+    int best = order[0];
+    for (int x = 1; x < n; ++x) if (s.q[order[x]] >= s.q[best]) best = order[x];
+    return best;
+}
+
+// get_errors_cov_from_frags (utils_frags.rs:596-655) for one haploset: unit-count histogram over [lo, hi]; alleles visited in the
+// inner map's iteration order (allele_order below: ascending, except 0,2,1,3 at a site with all four alleles).
 int floria_oracle_haploset_stats(const floria_pileup* pileup, const uint32_t* reads, uint32_t n, uint32_t lo, uint32_t hi, double* out4) {
     int rc = validate(pileup);
     if (rc) return rc;
@@ -934,7 +955,10 @@ int floria_oracle_haploset_stats(const floria_pileup* pileup, const uint32_t* re
         const Site* s = hap_map.find((uint32_t)pos);
         if (s && s->present) {
             nonzero++;
-            for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) {
+            int order[FLORIA_MAX_ALLELES], na;
+            allele_order(s->present, order, &na);                                     // the inner map's iteration order (see allele_order)
+            for (int x = 0; x < na; ++x) {
+                const int a = order[x];
                 const double count = (double)s->q[a];
                 if (count > snp_support) max_count_pos = count;                      // :622-624 (compares with the running sum)
                 snp_support += count;
@@ -948,6 +972,73 @@ int floria_oracle_haploset_stats(const floria_pileup* pileup, const uint32_t* re
     out4[1] = errors / total_support;
     out4[2] = errors;
     out4[3] = total_support;
+    return 0;
+}
+
+// part_block_manip::get_hapq (part_block_manip.rs:517-616) for the haplosets of one contig: HAPQ and REL_ERR per haploset and the
+// contig's avg_err.  groups = read-id lists (counter_ids), grp_range = their inclusive SNP ranges (1-based), snp_to_genome_pos is
+// 0-based by SNP index - 1 as in the reference.  Order-independent: `find_overlapping_blocks` (rust-lapper: half-open overlap
+// start < other.stop && stop > other.start, :484) only feeds a running maximum.
+int floria_oracle_hapq(const floria_pileup* pileup, const uint64_t* grp_off, const uint32_t* grp_read, const uint32_t* grp_range,
+                       uint32_t n_groups, const uint64_t* snp_to_genome_pos, uint32_t n_snps, uint64_t block_length,
+                       uint8_t* hapq_out, double* rel_err_out, double* avg_err_out) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    Pile P{pileup};
+    std::vector<std::vector<uint32_t>> parts(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) parts[g].assign(grp_read + grp_off[g], grp_read + grp_off[g + 1]);
+    double weight = 0., error = 0.;
+    std::vector<double> errs(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) {                                       // :529-539
+        double o4[4];
+        rc = floria_oracle_haploset_stats(pileup, parts[g].data(), (uint32_t)parts[g].size(), grp_range[2 * g], grp_range[2 * g + 1], o4);
+        if (rc) return rc;
+        weight += o4[3]; error += o4[2]; errs[g] = o4[1];
+    }
+    const double avg_err = error / weight;                                          // :540
+    HapBlock all = hap_block_from_partition(P, parts, true);                        // :541
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        const uint32_t x1 = grp_range[2 * i], x2 = grp_range[2 * i + 1];
+        double max_penalty = 0.;
+        for (uint32_t j = 0; j < n_groups; ++j) {                                   // find_overlapping_blocks :453-513
+            if (j == i) continue;
+            const uint32_t y1 = grp_range[2 * j], y2 = grp_range[2 * j + 1];
+            if (!(y1 < x2 && y2 > x1)) continue;                                    // Lapper::find(x1, x2)
+            const uint32_t a = x2 - y1 + 1, b = y2 - x1 + 1;                        // overlap_percent :13-24
+            const uint32_t intersect = a < b ? a : b;
+            double ol = (double)intersect / (double)(x2 - x1 + 1);
+            if (ol > 1.) ol = 1.;
+            if (!(ol > 0.05)) continue;                                             // :505
+            double same = 0., diff = 0.;                                            // distance_between_haplotypes :659-700, range = (MIN, MAX)
+            all.blocks[i].for_each([&](uint32_t pos, const Site& s1) {
+                const Site* s2 = all.blocks[j].find(pos);
+                if (!s2) return;
+                if (consensus_allele(s1) == consensus_allele(*s2)) same += 1.; else diff += 1.;
+            });
+            const double dist = (same + diff) == 0. ? 1. : diff / (same + diff);    // :563-567
+            if (ol * (1. - dist) > max_penalty) max_penalty = ol * (1. - dist);     // :568-572
+        }
+        uint32_t r0 = 0xffffffffu, r1 = 0;                                          // :584-592
+        for (uint32_t r : parts[i]) {
+            if (pileup->first[r] < r0) r0 = pileup->first[r];
+            if (pileup->last[r] >= r1) r1 = pileup->last[r];
+        }
+        uint64_t base_range = 0;
+        if (!(r0 > r1)) {
+            if (x1 == 0 || x2 == 0 || x1 > n_snps || x2 > n_snps) { g_err = "haploset range outside snp_to_genome_pos"; return FLORIA_E_INVALID; }
+            base_range = snp_to_genome_pos[x2 - 1] - snp_to_genome_pos[x1 - 1];     // :598-599
+        }
+        const double t1 = 40. * (1. - max_penalty);                                 // HAPQ_CONSTANT
+        const double len = (double)parts[i].size();
+        const double t2 = std::min(1., len / 3.);
+        const double t3 = std::max(0.0, std::log(((double)base_range / (double)block_length) + 1.));
+        const double prod = t1 * t2 * t3;
+        uint64_t hq = prod > 0. ? (prod >= 18446744073709551615. ? ~0ull : (uint64_t)prod) : 0;    // `as usize` saturates, NaN -> 0
+        if (parts[i].size() == 1) hq = 0;
+        hapq_out[i] = (uint8_t)std::min<uint64_t>(hq, 60);
+        rel_err_out[i] = errs[i] / avg_err;                                         // :614
+    }
+    *avg_err_out = avg_err;
     return 0;
 }
 

@@ -161,3 +161,20 @@ def haploset_stats(pileup, reads, lo, hi):
     out = np.zeros(4, np.float64)
     _check(lib().floria_oracle_haploset_stats(C.byref(cp), capi.ptr(r, C.c_uint32), C.c_uint32(len(r)), C.c_uint32(lo), C.c_uint32(hi), capi.ptr(out, C.c_double)))
     return out
+
+
+def hapq(pileup, groups, ranges, snp_to_genome_pos, block_length):
+    """get_hapq for one contig's haplosets -> (hapq uint8 [n], rel_err float64 [n], avg_err)."""
+    cp = pileup.as_c()
+    off = np.zeros(len(groups) + 1, np.uint64)
+    off[1:] = np.cumsum([len(g) for g in groups])
+    reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
+    rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+    pos = np.ascontiguousarray(snp_to_genome_pos, np.uint64)
+    hq = np.zeros(len(groups) + 1, np.uint8)
+    rel = np.zeros(len(groups) + 1, np.float64)
+    avg = C.c_double(0)
+    _check(lib().floria_oracle_hapq(C.byref(cp), capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32),
+                                    C.c_uint32(len(groups)), capi.ptr(pos, C.c_uint64), C.c_uint32(len(pos)), C.c_uint64(int(block_length)),
+                                    capi.ptr(hq, C.c_uint8), capi.ptr(rel, C.c_double), C.byref(avg)))
+    return hq[:-1], rel[:-1], avg.value

@@ -427,3 +427,51 @@ def test_specialised_and_generic_slab_kernels_agree(gpu_ctx, hip_lib, oracle_mod
     assert_block_results_equal(ro, spec, "specialised")
     assert_block_results_equal(ro, gen, "generic")
     assert spec.min_prune_margin == gen.min_prune_margin == ro.min_prune_margin
+
+
+def _same_f64(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64)) or (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]))
+
+
+@pytest.mark.parametrize("cfg,idx,scale,bl", [(1, 0, 1.0, None), (4, 3, 0.5, 10000), (3, 1, 0.2, 500)])
+def test_hapq_parity(gpu_ctx, hip_lib, oracle_mod, cfg, idx, scale, bl):
+    # get_hapq (part_block_manip.rs:517-616): HAPQ / REL_ERR / avg_err of the haplosets S2 returns (overlapping ranges of adjacent blocks)
+    C = synth.CONFIGS[cfg]
+    bl = bl or C["block_length"]
+    c = synth.make_config_contig(cfg, idx, scale)
+    s, e = hip_lib.get_range_with_lengths(c.snp_pos, bl)
+    rc = gpu_ctx.upload(c.pileup)
+    r = gpu_ctx.phase_blocks(rc, s, e, hip_lib.make_params(EPS, C["max_ploidy"], C["beam"]))
+    g, rg = groups_from_blocks(r, s, e)
+    # the raw block partitions overlap by a third of a block (graph_processing.rs:337): plenty of overlapping pairs
+    g.append(np.zeros(0, np.uint32)); rg.append((1, 2))                                  # an empty haploset
+    hq, rel, avg = gpu_ctx.hapq(rc, g, rg, c.snp_pos, bl)
+    ohq, orel, oavg = oracle_mod.hapq(c.pileup, g, rg, c.snp_pos, bl)
+    assert np.array_equal(hq, ohq), (hq[:20], ohq[:20])
+    assert _same_f64(rel, orel) and _same_f64([avg], [oavg])
+    assert hq.max() <= 60 and len(set(hq.tolist())) > 1
+    rc.free()
+
+
+def test_hapq_four_alleles_ties_and_q0(gpu_ctx, hip_lib, oracle_mod):
+    # multi-allelic sites with equal qualities (ties everywhere) and q=0 cells: the consensus tie rule and the inner-map order
+    rng = np.random.default_rng(77)
+    pile = random_pileup(rng, 400, 60, 3, max_len=20, alleles=4, qlo=20, qhi=20, err=0.3, q0_frac=0.1)
+    ids = np.arange(pile.n_reads, dtype=np.uint32)
+    groups, ranges = [], []
+    for k in range(24):                                                  # random overlapping haplosets, some tiny
+        lo = int(rng.integers(1, 50)); hi = min(60, lo + int(rng.integers(1, 25)))
+        m = (pile.first <= hi) & (pile.last >= lo)
+        pick = ids[m][rng.random(int(m.sum())) < (0.5 if k % 3 else 0.05)]
+        groups.append(pick.astype(np.uint32)); ranges.append((lo, hi))
+    pos = np.cumsum(rng.integers(50, 400, size=60)).astype(np.uint64)
+    rc = gpu_ctx.upload(pile)
+    hq, rel, avg = gpu_ctx.hapq(rc, groups, ranges, pos, 2000)
+    ohq, orel, oavg = oracle_mod.hapq(pile, groups, ranges, pos, 2000)
+    assert np.array_equal(hq, ohq), (hq, ohq)
+    assert _same_f64(rel, orel) and _same_f64([avg], [oavg])
+    st = gpu_ctx.haploset_stats([rc], np.zeros(len(groups), np.uint32), groups, ranges)
+    for k in range(len(groups)):
+        assert _same_f64(st[k], oracle_mod.haploset_stats(pile, groups[k], ranges[k][0], ranges[k][1])), k
+    rc.free()

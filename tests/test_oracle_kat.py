@@ -152,3 +152,38 @@ def test_kat5_haploset_stats_by_hand(oracle_mod):
     cov, err, total_err, total_cov = oracle_mod.haploset_stats(p, [0, 1, 2], 1, 4)
     # supports 3, 3, 1 (SNP 4 uncovered): total 7 over 3 covered SNPs; errors = (3-2) + 0 + 0 = 1
     assert total_cov == 7.0 and total_err == 1.0 and cov == 7.0 / 3.0 and err == 1.0 / 7.0
+
+
+def test_kat6_hapq_by_hand(oracle_mod):
+    # part_block_manip.rs:517-616 by hand.  SNPs 1000 bp apart, -l 1000.
+    #  H0: 2 reads over SNPs 1..4, all allele 0            range (1,4)
+    #  H1: 3 reads over SNPs 3..6: 0,1,1,1 — one of them reads allele 1 at SNP 3 (a minority)   range (3,6)
+    #  H2: a single read over SNPs 8..9                     range (8,9)  -> HAPQ 0 (one read)
+    #  H3: 2 reads over SNPs 11..12 that disagree at SNP 11 with equal quality (a TIE), H4: 2 clean reads 1,0 over 11..12
+    q = 30
+    reads = [([1, 2, 3, 4], [0, 0, 0, 0], [q] * 4), ([1, 2, 3, 4], [0, 0, 0, 0], [q] * 4),
+             ([3, 4, 5, 6], [0, 1, 1, 1], [q] * 4), ([3, 4, 5, 6], [0, 1, 1, 1], [q] * 4), ([3, 4, 5, 6], [1, 1, 1, 1], [q] * 4),
+             ([8, 9], [0, 0], [q] * 2),
+             ([11, 12], [0, 0], [q] * 2), ([11, 12], [1, 0], [q] * 2),
+             ([11, 12], [1, 0], [q] * 2), ([11, 12], [1, 0], [q] * 2)]
+    p = Pileup.from_reads(reads)
+    # ids after the Frag::cmp sort: find each group's reads by content
+    def ids(first, alleles):
+        out = [r for r in range(p.n_reads) if p.first[r] == first and list(p.allele[p.read_off[r]:p.read_off[r + 1]]) == alleles]
+        return out
+    h0 = ids(1, [0, 0, 0, 0]); h1 = ids(3, [0, 1, 1, 1]) + ids(3, [1, 1, 1, 1]); h2 = ids(8, [0, 0])
+    h3 = ids(11, [0, 0]) + ids(11, [1, 0])[:1]; h4 = ids(11, [1, 0])[1:]
+    assert [len(x) for x in (h0, h1, h2, h3, h4)] == [2, 3, 1, 2, 2]
+    pos = 100 + 1000 * np.arange(12, dtype=np.uint64)
+    hq, rel, avg = oracle_mod.hapq(p, [h0, h1, h2, h3, h4], [(1, 4), (3, 6), (8, 9), (11, 12), (11, 12)], pos, 1000)
+    import math
+    # H0 vs H1: overlap_percent = min(4-3+1, 6-1+1)/4 = 0.5; shared SNPs 3 (0 vs 0: same) and 4 (0 vs 1: diff) -> dist 0.5 -> penalty 0.25
+    assert hq[0] == int(40 * 0.75 * (2 / 3) * math.log(3000 / 1000 + 1))         # 27
+    assert hq[1] == int(40 * 0.75 * 1.0 * math.log(3000 / 1000 + 1))             # 41
+    assert hq[2] == 0
+    # the tie at SNP 11 of H3 resolves to allele 1 (last maximal entry of the inner map, ascending allele order): H3 == H4 on both SNPs,
+    # dist 0, penalty 1 -> t1 = 0.  (Resolved to allele 0 it would be 40*0.5*(2/3)*ln 2 = 9.)
+    assert hq[3] == 0 and hq[4] == 0
+    # errors: H1 has one minority cell (SNP 3), H3 one (the tie: support 2, max 1); coverage 8 + 12 + 2 + 4 + 4 = 30
+    assert avg == 2.0 / 30.0
+    assert rel[0] == 0.0 and rel[1] == (1.0 / 12.0) / avg and rel[3] == (1.0 / 4.0) / avg and rel[4] == 0.0
