@@ -113,4 +113,22 @@ std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPositi
     return {std::move(np), std::move(nr)};
 }
 
+HapqResult get_hapq(Session& s, const std::vector<std::vector<const Frag*>>& parts, const std::vector<GnPosition>& snp_to_genome_pos,
+                    const std::vector<std::pair<SnpPosition, SnpPosition>>& ranges, const Options& o) {
+    if (!s.contig() || !s.frags()) throw Error(FLORIA_E_INVALID, "no contig loaded");
+    std::vector<uint64_t> off{0};
+    std::vector<uint32_t> reads, rng;
+    for (size_t g = 0; g < parts.size(); ++g) {
+        for (const Frag* f : parts[g]) reads.push_back((uint32_t)f->counter_id);
+        off.push_back(reads.size());
+        rng.push_back(ranges[g].first); rng.push_back(ranges[g].second);
+    }
+    std::vector<uint64_t> pos(snp_to_genome_pos.begin(), snp_to_genome_pos.end());
+    HapqResult r;
+    r.hapqs.assign(parts.size(), 0); r.rel_err.assign(parts.size(), 0.0); r.avg_err = 0.0;
+    check(floria_hip_hapq(s.ctx(), s.contig(), off.data(), reads.data(), rng.data(), (uint32_t)parts.size(), pos.data(), (uint32_t)pos.size(),
+                          (uint64_t)o.block_length, r.hapqs.data(), r.rel_err.data(), &r.avg_err));
+    return r;
+}
+
 }  // namespace floria

@@ -103,4 +103,9 @@ std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPositi
     const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec, const Options& options, const std::vector<GnPosition>& snp_to_genome_pos,
     const std::vector<uint32_t>* visit_order = nullptr);
 
+// part_block_manip.rs:517-616: (hapqs, rel_err per haploset, avg_err) — the HAPQ / REL_ERR header fields and the contig table's avg_err.
+struct HapqResult { std::vector<uint8_t> hapqs; std::vector<double> rel_err; double avg_err; };
+HapqResult get_hapq(Session& s, const std::vector<std::vector<const Frag*>>& parts, const std::vector<GnPosition>& snp_to_genome_pos,
+                    const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec, const Options& options);
+
 }  // namespace floria

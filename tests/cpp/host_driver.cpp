@@ -51,6 +51,10 @@ int main(int argc, char** argv) {
             for (auto* f : fin.first[g]) printf(" %zu", f->counter_id);
             printf("\n");
         }
+        auto hq = floria::get_hapq(session, fin.first, snp_to_genome_pos, fin.second, opt);      // file_writer.rs:40-41
+        printf("HAPQ");
+        for (size_t g = 0; g < hq.hapqs.size(); ++g) printf(" %u", (unsigned)hq.hapqs[g]);
+        printf("\n");
         // error behaviour: non-increasing VCF positions are fatal in the reference (utils_frags.rs:422-425)
         try {
             floria::get_range_with_lengths({10, 20, 15, 40}, 100, 33, 0.0005);

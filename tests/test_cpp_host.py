@@ -43,7 +43,7 @@ def test_cpp_host_matches_oracle(hip_lib, oracle_mod, tmp_path, cfg, idx, scale)
     out = subprocess.run([build_driver(), str(fx), str(eps), str(C["block_length"]), str(C["max_ploidy"]), str(C["beam"])],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
-    nodes, groups, err = [], [], None
+    nodes, groups, err, hapq = [], [], None, None
     for line in out.stdout.splitlines():
         t = line.split()
         if t[0] == "NODE":
@@ -56,6 +56,8 @@ def test_cpp_host_matches_oracle(hip_lib, oracle_mod, tmp_path, cfg, idx, scale)
             groups.append(((int(t[1]), int(t[2])), [int(x) for x in t[4:]]))
         elif t[0] == "ERRCHECK":
             err = t
+        elif t[0] == "HAPQ":
+            hapq = [int(x) for x in t[1:]]
     assert err and err[1] == "-1" and "not increasing" in " ".join(err)          # utils_frags.rs:422-425
     # ---- S1 + hap graph vs the oracle -------------------------------------------------------------------------------
     s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
@@ -90,3 +92,7 @@ def test_cpp_host_matches_oracle(hip_lib, oracle_mod, tmp_path, cfg, idx, scale)
     assert go.n_groups == len(groups)
     for k, (rng, reads) in enumerate(groups):
         assert rng == (int(go.range[k][0]), int(go.range[k][1])) and reads == [int(x) for x in go.group(k)]
+    # ---- get_hapq on the reassigned haplosets vs the oracle (part_block_manip.rs:517-616) ------------------------------------------
+    ohq, _, _ = oracle_mod.hapq(c.pileup, [go.group(k) for k in range(go.n_groups)], [tuple(int(x) for x in go.range[k]) for k in range(go.n_groups)],
+                                c.snp_pos, C["block_length"])
+    assert hapq == [int(x) for x in ohq]
