@@ -157,6 +157,7 @@ void beam_slab_kernel(BeamArgs g) {
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
+    unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0;
 #endif
 
     for (;;) {
@@ -292,6 +293,9 @@ void beam_slab_kernel(BeamArgs g) {
             BEAM_TICK(0);
 
             // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
+#ifdef FLORIA_PROF
+            c_nlive += nlive; c_nin += nin; c_nstates += nstates; c_L += L;
+#endif
             uint32_t Gs = 1, lgGs = 0;
             while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
             const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
@@ -303,18 +307,26 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
                 uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
                 uint32_t m = 0;
-                {   // positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel]
+                {   // positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel] (in ~45 % of the steps, 1-2 positions).  The
+                    // multipliers depend on the position only, so they are requested together with the sums: one memory round trip, no
+                    // branch on the loaded value (a zero sum contributes zero).
                     for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
                         if (act) {
+                            uint64_t v[A], r1[A], r2[A], p1[A], p2[A];
+                            const char* vp = pool + (slab_off + (uint32_t)pr * pos_bytes);
+#pragma unroll
+                            for (int h = 0; h < A / 2; ++h) { const ulonglong2 w2 = *(const ulonglong2*)(vp + 16 * h); v[2 * h] = w2.x; v[2 * h + 1] = w2.y; }
 #pragma unroll
                             for (int al = 0; al < A; ++al) {
-                                const uint64_t v = *(const uint64_t*)(pool + (slab_off + (uint32_t)pr * pos_bytes + al * 8));
-                                if (v) {
-                                    const uint64_t qv = Q0 ? (v & QMASK63) : v;
-                                    const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al);
-                                    t1 += g.Rq1[hx] * qv; t2 += g.Rq2[hx] * qv;
-                                    if (Q0) { t1 += g.Rp1[hx]; t2 += g.Rp2[hx]; }
-                                }
+                                const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al);
+                                r1[al] = g.Rq1[hx]; r2[al] = g.Rq2[hx];
+                                if (Q0) { p1[al] = g.Rp1[hx]; p2[al] = g.Rp2[hx]; }
+                            }
+#pragma unroll
+                            for (int al = 0; al < A; ++al) {
+                                const uint64_t qv = Q0 ? (v[al] & QMASK63) : v[al];
+                                t1 += r1[al] * qv; t2 += r2[al] * qv;
+                                if (Q0) { t1 += v[al] ? p1[al] : 0ull; t2 += v[al] ? p2[al] : 0ull; }
                             }
                         }
                     }
@@ -684,7 +696,8 @@ void beam_slab_kernel(BeamArgs g) {
     if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g.prof[16 + i], t_acc[i]);
                      atomicAdd(&g.prof[24], wall_clock64() - t_wall0); atomicAdd(&g.prof[25], clock64() - t_core0); atomicAdd(&g.prof[26], 1ull);
                      atomicAdd(&g.prof[26 + g.ploidy], wall_clock64() - t_wall0);
-                     atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
+                     atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
+                     atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);
