@@ -79,7 +79,7 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
     L.off_coff = take(2 * SLAB_TILE * 4); L.off_caw = take(2 * SLAB_TILE * 4);
     L.off_crp1 = take(q0 ? SLAB_TILE * 8 : 0); L.off_crp2 = take(q0 ? SLAB_TILE * 8 : 0);
     for (int i = 0; i < 2; ++i) {
-        L.off_q[i] = take(LM * 8); L.off_h1[i] = take(LM * 8); L.off_h2[i] = take(LM * 8); L.off_m[i] = take(LM * 4);
+        L.off_q[i] = take((LM + 1) * 8); L.off_h1[i] = take((LM + 1) * 8); L.off_h2[i] = take((LM + 1) * 8); L.off_m[i] = take((LM + 1) * 4);   // +1: see the entry table of phase B
         L.off_sl[i] = take(NS * 2);
     }
     L.off_live = take(NS * 2); L.off_s2l = take(NS * 2);
@@ -186,8 +186,6 @@ void beam_slab_kernel(BeamArgs g) {
         if (lane < p) ST_sl(0)[lane] = 0;
         int32_t hi_rel = -1;
         uint32_t start_rel = 0;
-        uint64_t ev_s = 0, ev_h1 = 0, ev_h2 = 0, ev_q = 0;
-        uint32_t ev_m = 0, ev_pk = 0;
         RegHeap H; H.hp_s = 0; H.hp_id = 0; H.len = 0;
         // software pipeline over reads (every request is issued in the shadow of phase A's slab loads):
         //   step i top:   LDS buffer i&1 holds read i's cells (raw snp / attribute words, written by LDS-DMA during step i-1),
@@ -410,8 +408,10 @@ void beam_slab_kernel(BeamArgs g) {
             uint64_t evalid = 0;
             H.len = 0;
             bool bulk = false;                       // this step took the no-duplicate / no-eviction path
-            uint64_t b_q = 0, b_h1 = 0, b_h2 = 0;    // its children (lane = (state, partition) pair)
-            uint32_t b_m = 0, src_map = 0;           // lane r = child lane of entry r
+            uint64_t b_h1 = 0, b_h2 = 0;             // its children's state hashes (lane = (state, partition) pair)
+            uint32_t src_map = 0;                    // lane r = child lane of entry r
+            uint64_t* const E_s = ST_q(cur ^ 1); uint64_t* const E_h1 = ST_h1(cur ^ 1); uint64_t* const E_h2 = ST_h2(cur ^ 1);
+            uint32_t* const E_pk = ST_m(cur ^ 1);
             for (uint32_t a0 = 0; a0 < nstates; a0 += S) {
                 const uint32_t a = a0 + my_sl;
                 const bool act = lane_pair && a < nstates;
@@ -486,7 +486,7 @@ void beam_slab_kernel(BeamArgs g) {
                         const bool coll = pass && tab[slot] != (uint8_t)lane;
                         if (!__any(coll)) {
                             bulk = true;
-                            b_q = cq; b_h1 = ch1; b_h2 = ch2; b_m = cm;
+                            b_h1 = ch1; b_h2 = ch2;
                             uint32_t r = 0;
                             while (passmask) {
                                 const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
@@ -505,13 +505,14 @@ void beam_slab_kernel(BeamArgs g) {
                     const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
                     passmask &= passmask - 1;
                     const uint64_t s_s = rl64(cs, src), s_h1 = rl64(ch1, src), s_h2 = rl64(ch2, src);
-                    const bool dup = ((evalid >> lane) & 1) && ev_h1 == s_h1 && ev_h2 == s_h2 && ev_s >= s_s;
+                    // general path (several batches, possible duplicates or evictions: ~3 % of the steps): the entry table (score, hash,
+                    // parent | partition) lives in the NEXT parity's state arrays, which are dead until phase M — lane e tests entry e
+                    bool dup = false;
+                    if ((evalid >> lane) & 1) dup = E_h1[lane] == s_h1 && E_h2[lane] == s_h2 && E_s[lane] >= s_s;
                     if (__ballot(dup)) continue;
                     const uint32_t id = (uint32_t)__ffsll((unsigned long long)~evalid) - 1;
                     evalid |= 1ull << id;
-                    wl64(ev_s, s_s, id); wl64(ev_h1, s_h1, id); wl64(ev_h2, s_h2, id);
-                    wl64(ev_q, rl64(cq, src), id); wl32(ev_m, rl32(cm, src), id);
-                    wl32(ev_pk, (a0 + rl32(my_sl, src)) | (rl32(my_k, src) << 16), id);
+                    if (lane == 0) { E_s[id] = s_s; E_h1[id] = s_h1; E_h2[id] = s_h2; E_pk[id] = (a0 + rl32(my_sl, src)) | (rl32(my_k, src) << 16); }
                     H.push(s_s, id);
 #ifdef FLORIA_PROF
                     c_push++; if (H.len > limit) c_pop++;
@@ -525,17 +526,20 @@ void beam_slab_kernel(BeamArgs g) {
             const uint32_t nnext = H.len;
             const bool surv = lane < nnext;
             const uint32_t eid = surv ? H.hp_id : 0;
-            uint64_t n_q, n_h1, n_h2;
-            uint32_t n_m, n_pk;
+            uint64_t n_q = 0, n_h1 = 0, n_h2 = 0;
+            uint32_t n_m = 0, n_pk = 0;
             if (bulk) {
                 const int esrc = (int)__shfl(src_map, (int)eid);
-                n_q = shfl_u64(b_q, esrc); n_h1 = shfl_u64(b_h1, esrc); n_h2 = shfl_u64(b_h2, esrc);
-                n_m = __shfl(b_m, esrc); n_pk = __shfl(my_sl | (my_k << 16), esrc);
-            } else {
-                n_q = shfl_u64(ev_q, (int)eid); n_h1 = shfl_u64(ev_h1, (int)eid); n_h2 = shfl_u64(ev_h2, (int)eid);
-                n_m = __shfl(ev_m, (int)eid); n_pk = __shfl(ev_pk, (int)eid);
+                n_h1 = shfl_u64(b_h1, esrc); n_h2 = shfl_u64(b_h2, esrc);
+                n_pk = __shfl(my_sl | (my_k << 16), esrc);
+            } else if (surv) {
+                n_h1 = E_h1[eid]; n_h2 = E_h2[eid]; n_pk = E_pk[eid];
             }
             const uint32_t pj = n_pk & 0xffff, kj = n_pk >> 16;
+            if (surv) {                            // the child's (sum of diffs, #eps) = its parent's + the read's distance to the extended slab
+                const uint32_t li = s2l[st_sl[pj * p + kj]];
+                n_q = st_q[pj] + r_qd[li]; n_m = st_m[pj] + r_m[li];
+            }
             uint64_t* nx_q = ST_q(cur ^ 1); uint64_t* nx_h1 = ST_h1(cur ^ 1); uint64_t* nx_h2 = ST_h2(cur ^ 1);
             uint32_t* nx_m = ST_m(cur ^ 1); uint16_t* nx_sl = ST_sl(cur ^ 1);
             for (uint32_t x = lane; x < NS; x += 64) { ref[x] = 0; leader[x] = 0xffffffffu; }
