@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return 
 constexpr int SLAB_NS_MAX = 512;
 constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
 #ifndef FLORIA_SLAB_U
-#define FLORIA_SLAB_U 4
+#define FLORIA_SLAB_U 6
 #endif
 constexpr int SLAB_U = FLORIA_SLAB_U;      // ploidy * (ploidy*beam) slabs per resident job
 
