@@ -112,6 +112,10 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     uint32_t* m_cb = (uint32_t*)(smem + moved_bytes);
     uint32_t* m_lk = m_cb + meta_n;                                                   // cell count | partition << 24
     uint64_t* hist = HL ? (uint64_t*)(smem + moved_bytes + meta_bytes) : g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
+    // HL: one CODE byte per (position, partition) next to the histogram — bit a = allele a attains the position's maximal phred sum, 0 =
+    // nothing observed — refreshed after the build and after every batch of moves; the distance pass (70 % of the kernel) then reads
+    // p bytes per cell instead of p 16-byte histogram pieces and needs no 64-bit compares
+    uint8_t* codes = (uint8_t*)(smem + moved_bytes + meta_bytes + (((size_t)g.span_max * PA * 8 + 15) & ~(size_t)15));
     double* dist = g.dist_pool + (uint64_t)blockIdx.x * g.n_max * p;
     uint64_t* cgain = g.cand_gain_pool + (uint64_t)blockIdx.x * g.cand_cap;
     uint32_t* ckey = g.cand_key_pool + (uint64_t)blockIdx.x * g.cand_cap;
@@ -153,6 +157,20 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         auto read_meta = [&](uint32_t i, uint32_t& cb, uint32_t& len, uint32_t& k) {
             if (meta) { cb = m_cb[i]; const uint32_t lk = m_lk[i]; len = lk & 0xffffffu; k = lk >> 24; }
             else { const uint32_t r = reads[i]; cb = G(cd.read_off)[r]; len = G(cd.read_off)[r + 1] - cb; k = part[i]; }
+        };
+        auto refresh_codes = [&]() {
+            if (!HL) return;
+            for (uint32_t x = tid; x < span * p; x += OPT_THREADS) {            // x = position * p + partition
+                const uint64_t* cp = hist + (uint64_t)x * A;
+                uint64_t q[A], mx = 0;
+#pragma unroll
+                for (int a = 0; a < A; ++a) { q[a] = cp[a] & QMASK44; mx = q[a] > mx ? q[a] : mx; }
+                uint32_t c = 0;
+#pragma unroll
+                for (int a = 0; a < A; ++a) c |= (mx != 0 && q[a] == mx) ? (1u << a) : 0u;
+                codes[x] = (uint8_t)c;
+            }
+            __syncthreads();
         };
         // 16 lanes per read (4 reads per wavefront, 16 per workgroup pass): 64-B coalesced cell segments, up to 8 cells
         // per lane loaded before the first atomic
@@ -207,6 +225,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
 
+        refresh_codes();
         OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
@@ -235,14 +254,25 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                             if (aqs[u] != 0xffffffffu) {
                                 const uint32_t al = aqs[u] >> 28;
                                 const uint64_t w = (aqs[u] & 0x0fffffffu);
-                                const uint64_t* row = hist + (uint64_t)(sn[u] - pos0) * PA;
+                                if (HL) {
+                                    const uint8_t* crow = codes + (sn[u] - pos0) * p;
 #pragma unroll
-                                for (int k = 0; k < KMAX; ++k) {
-                                    if ((uint32_t)k < p) {
-                                        uint64_t mx = 0, va = 0;
+                                    for (int k = 0; k < KMAX; ++k) {
+                                        if ((uint32_t)k < p) {
+                                            const uint32_t c = crow[k];
+                                            acc[k] += c == 0 ? 1ull : (((c >> al) & 1u) ? 0ull : (w << 16));
+                                        }
+                                    }
+                                } else {
+                                    const uint64_t* row = hist + (uint64_t)(sn[u] - pos0) * PA;
 #pragma unroll
-                                        for (int x = 0; x < A; ++x) { const uint64_t q = row[k * A + x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
-                                        acc[k] += mx == 0 ? 1ull : ((va != mx) ? (w << 16) : 0ull);
+                                    for (int k = 0; k < KMAX; ++k) {
+                                        if ((uint32_t)k < p) {
+                                            uint64_t mx = 0, va = 0;
+#pragma unroll
+                                            for (int x = 0; x < A; ++x) { const uint64_t q = row[k * A + x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
+                                            acc[k] += mx == 0 ? 1ull : ((va != mx) ? (w << 16) : 0ull);
+                                        }
                                     }
                                 }
                             }
@@ -326,6 +356,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         if (lane == 0) part[rl] = (uint8_t)to;
                     }
                     __syncthreads();
+                    refresh_codes();
                 };
                 apply_moves(false);
                 OPT_TICK(6);     // moves
