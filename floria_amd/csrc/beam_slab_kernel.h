@@ -480,7 +480,7 @@ void beam_slab_kernel(BeamArgs g) {
                     if (npass != 0 && npass <= limit) {
                         volatile uint8_t* tab = (volatile uint8_t*)s_pk;     // 256 B, free until phase M; volatile: other LANES write the slot too,
                                                                              // the compiler must not forward this lane's store to its load
-                        s_pk[lane] = 0xffffffffu;
+                        // (no clearing needed: every passing lane overwrites its own slot, so it reads back its own id or another PASSING lane's)
                         const uint32_t slot = (uint32_t)(ch1 ^ (ch1 >> 31) ^ (ch2 >> 17)) & 255u;
                         if (pass) tab[slot] = (uint8_t)lane;
                         const bool coll = pass && tab[slot] != (uint8_t)lane;
