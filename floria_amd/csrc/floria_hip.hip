@@ -1137,23 +1137,39 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         const floria_hip_contig* c = contigs[ci];
         cdev[ci] = c->dev;
         const uint32_t N = c->n_reads;
-        std::vector<std::pair<uint32_t, uint32_t>> pairs;                      // (read, local group): read -> groups, part_block_manip.rs:185-193
+        // read -> groups (part_block_manip.rs:185-193) by counting sort: groups are visited in ascending local id, so every read's candidate
+        // list comes out ascending; groups are sets (a repeated id inside one group counts once)
         std::vector<uint32_t> p0(cg[ci].size(), UINT32_MAX), p1(cg[ci].size(), 0);
+        std::vector<uint64_t> off(N + 1, 0);
+        std::vector<uint32_t> last(N, UINT32_MAX);
         for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
             const uint32_t g = cg[ci][lg];
             for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
                 const uint32_t r = grp_read[i];
                 if (r >= N) return fail(FLORIA_E_INVALID, "group read id out of range");
-                pairs.push_back({r, lg});
+                if (last[r] == lg) continue;
+                last[r] = lg;
+                off[r + 1]++;
                 p0[lg] = std::min(p0[lg], c->h_first[r]); p1[lg] = std::max(p1[lg], c->h_last[r]);
             }
         }
-        std::sort(pairs.begin(), pairs.end());
-        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());       // groups are sets
-        r2g_off_base[ci] = r2g_off_all.size(); r2g_base[ci] = r2g_all.size(); grp_base[ci] = gpos0_all.size(); assign_base[ci] = n_assign;
-        std::vector<uint64_t> off(N + 1, 0);
-        for (auto& pr : pairs) off[pr.first + 1]++;
         for (uint32_t r = 0; r < N; ++r) off[r + 1] += off[r];
+        r2g_off_base[ci] = r2g_off_all.size(); r2g_base[ci] = r2g_all.size(); grp_base[ci] = gpos0_all.size(); assign_base[ci] = n_assign;
+        {
+            const size_t base = r2g_all.size();
+            r2g_all.resize(base + off[N]);
+            std::vector<uint64_t> fill(off.begin(), off.end() - 1);
+            std::fill(last.begin(), last.end(), UINT32_MAX);
+            for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
+                const uint32_t g = cg[ci][lg];
+                for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
+                    const uint32_t r = grp_read[i];
+                    if (last[r] == lg) continue;
+                    last[r] = lg;
+                    r2g_all[base + fill[r]++] = lg;
+                }
+            }
+        }
         if (read_order) {                                   // every read that sits in a group must be visited exactly once
             std::vector<uint8_t> seen(N, 0);
             for (uint64_t i = order_off[ci]; i < order_off[ci + 1]; ++i) {
@@ -1164,7 +1180,6 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
             for (uint32_t r = 0; r < N; ++r) if (off[r + 1] > off[r] && !seen[r]) return fail(FLORIA_E_INVALID, "read_order misses a read that sits in a group");
         }
         r2g_off_all.insert(r2g_off_all.end(), off.begin(), off.end());
-        for (auto& pr : pairs) r2g_all.push_back(pr.second);
         for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
             hist_off_all.push_back(hist_cells);
             gpos0_all.push_back(p0[lg] == UINT32_MAX ? 0 : p0[lg]);

@@ -47,3 +47,20 @@ print(f"{n} contigs, {r.n_blocks} blocks, {len(groups)} block haplosets -> {len(
 print(f"S1 phase_blocks_batch {t_s1:.1f} ms | hap_graph {t_hg:.1f} ms | S2 reassign_batch {t_s2:.1f} ms | haploset_stats {t_st:.1f} ms | hapq (per contig, {n} calls) {t_hq:.1f} ms")
 print("S2 device timing:", {k: round(v, 2) for k, v in tm_s2.items() if k in ("reassign_ms", "h2d_ms", "d2h_ms", "total_ms")})
 print("HAPQ histogram:", np.bincount(np.concatenate(hq), minlength=61)[[0, 10, 20, 30, 40, 50, 60]].tolist(), "...")
+# the C entry point alone (arrays prebuilt): how much of S2 is libfloria_hip.so and how much the Python list handling
+import ctypes as C
+from floria_amd import _capi as capi
+arr = (C.c_void_p * len(res))(*[c._h for c in res])
+gcv = np.ascontiguousarray(gc, np.uint32)
+off = np.zeros(len(groups) + 1, np.uint64); off[1:] = np.cumsum([len(g) for g in groups])
+reads = np.ascontiguousarray(np.concatenate(groups), np.uint32)
+rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+L = lib.load()
+def c_only():
+    out = C.POINTER(C.POINTER(capi.CGroups))()
+    rc = L.floria_hip_reassign_batch(ctx._h, arr, C.c_uint32(len(res)), capi.ptr(gcv, C.c_uint32), capi.ptr(off, C.c_uint64), capi.ptr(reads, C.c_uint32),
+                                     capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), None, None, C.c_double(0.03125), C.byref(out))
+    assert rc == 0
+    L.floria_hip_groups_array_free(out, C.c_uint32(len(res)))
+t_c, _ = timed(c_only)
+print(f"floria_hip_reassign_batch alone: {t_c:.1f} ms")
