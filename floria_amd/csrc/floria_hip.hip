@@ -994,79 +994,104 @@ int floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* cons
     return 0;
 }
 
-// ---- get_hapq (part_block_manip.rs:517-616) for the haplosets of one contig --------------------------------------------------
-int floria_hip_hapq(floria_hip_ctx* ctx, const floria_hip_contig* contig, const uint64_t* grp_off, const uint32_t* grp_read,
-                    const uint32_t* grp_range, uint32_t n_groups, const uint64_t* snp_to_genome_pos, uint32_t n_snps,
-                    uint64_t block_length, uint8_t* hapq, double* rel_err, double* avg_err) {
-    if (!ctx || !contig || !avg_err || (n_groups && (!grp_off || !grp_range || !hapq || !rel_err))) return fail(FLORIA_E_INVALID, "null argument");
-    if (contig->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
+// ---- get_hapq (part_block_manip.rs:517-616) for the haplosets of many contigs (the reference calls it once per contig) ----------
+int floria_hip_hapq_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs, const uint32_t* grp_contig,
+                          const uint64_t* grp_off, const uint32_t* grp_read, const uint32_t* grp_range, uint32_t n_groups,
+                          const uint64_t* const* snp_to_genome_pos, const uint32_t* n_snps, uint64_t block_length,
+                          uint8_t* hapq, double* rel_err, double* avg_err) {
+    if (!ctx || (n_contigs && (!contigs || !avg_err)) || (n_groups && (!grp_off || !grp_range || !hapq || !rel_err))) return fail(FLORIA_E_INVALID, "null argument");
     if (block_length == 0) return fail(FLORIA_E_INVALID, "block_length must be positive");
-    if (n_groups == 0) { *avg_err = std::numeric_limits<double>::quiet_NaN(); return 0; }      // 0. / 0. (:540)
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        if (!contigs[c] || contigs[c]->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
+        avg_err[c] = std::numeric_limits<double>::quiet_NaN();                   // 0. / 0. for a contig without haplosets (:540)
+    }
+    if (n_groups == 0) return 0;
     // (1) get_errors_cov_from_frags per haploset (:529-539)
     std::vector<double> st(4ull * n_groups);
-    const floria_hip_contig* one[1] = {contig};
-    int rc = floria_hip_haploset_stats(ctx, one, 1, nullptr, grp_off, grp_read, grp_range, n_groups, st.data());
+    int rc = floria_hip_haploset_stats(ctx, contigs, n_contigs, grp_contig, grp_off, grp_read, grp_range, n_groups, st.data());
     if (rc) return rc;
-    double weight = 0., error = 0.;
-    for (uint32_t g = 0; g < n_groups; ++g) { weight += st[4ull * g + 3]; error += st[4ull * g + 2]; }
-    const double avgerr = error / weight;
+    std::vector<uint32_t> gc(n_groups, 0);
+    std::vector<double> weight(n_contigs, 0.), error(n_contigs, 0.);
+    for (uint32_t g = 0; g < n_groups; ++g) {                                    // (accumulated in group order inside each contig, as the reference does)
+        gc[g] = grp_contig ? grp_contig[g] : 0;
+        weight[gc[g]] += st[4ull * g + 3]; error[gc[g]] += st[4ull * g + 2];
+    }
+    for (uint32_t c = 0; c < n_contigs; ++c) avg_err[c] = error[c] / weight[c];
     // spans of the haplosets' reads (the consensus haplotype has a key wherever a read has a cell) and base ranges (:584-600)
-    const uint32_t A = contig->n_alleles;
+    uint32_t A = 2;
+    for (uint32_t c = 0; c < n_contigs; ++c) A = std::max(A, contigs[c]->n_alleles);
     std::vector<uint32_t> lo(n_groups, 0), len(n_groups, 0);
     std::vector<uint64_t> coff(n_groups + 1, 0), base_range(n_groups, 0);
     for (uint32_t g = 0; g < n_groups; ++g) {
+        const floria_hip_contig* c = contigs[gc[g]];
         uint32_t r0 = 0xffffffffu, r1 = 0;
         for (uint64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) {
             const uint32_t r = grp_read[i];                                 // (validated by floria_hip_haploset_stats)
-            r0 = std::min(r0, contig->h_first[r]); r1 = std::max(r1, contig->h_last[r]);
+            r0 = std::min(r0, c->h_first[r]); r1 = std::max(r1, c->h_last[r]);
         }
         if (!(r0 > r1)) {
             lo[g] = r0; len[g] = r1 - r0 + 1;
             const uint32_t x1 = grp_range[2 * g], x2 = grp_range[2 * g + 1];
-            if (!snp_to_genome_pos || x1 == 0 || x2 == 0 || x1 > n_snps || x2 > n_snps) return fail(FLORIA_E_INVALID, "haploset range outside snp_to_genome_pos");
-            base_range[g] = snp_to_genome_pos[x2 - 1] - snp_to_genome_pos[x1 - 1];
+            const uint64_t* pos = snp_to_genome_pos ? snp_to_genome_pos[gc[g]] : nullptr;
+            const uint32_t ns = n_snps ? n_snps[gc[g]] : 0;
+            if (!pos || x1 == 0 || x2 == 0 || x1 > ns || x2 > ns) return fail(FLORIA_E_INVALID, "haploset range outside snp_to_genome_pos");
+            base_range[g] = pos[x2 - 1] - pos[x1 - 1];
         }
         coff[g + 1] = coff[g] + len[g];
     }
-    // (2) find_overlapping_blocks (:453-513): rust-lapper's half-open overlap, overlap_percent (:13-24) > 0.05
+    // (2) find_overlapping_blocks (:453-513) inside each contig: rust-lapper's half-open overlap, overlap_percent (:13-24) > 0.05
+    std::vector<std::vector<uint32_t>> by_contig(n_contigs);
+    for (uint32_t g = 0; g < n_groups; ++g) by_contig[gc[g]].push_back(g);
     std::vector<uint32_t> pi, pj;
     std::vector<double> pol;
     std::vector<uint64_t> pair_off(n_groups + 1, 0);
-    for (uint32_t i = 0; i < n_groups; ++i) {
-        const uint32_t x1 = grp_range[2 * i], x2 = grp_range[2 * i + 1];
-        for (uint32_t j = 0; j < n_groups; ++j) {
-            if (j == i) continue;
-            const uint32_t y1 = grp_range[2 * j], y2 = grp_range[2 * j + 1];
-            if (!(y1 < x2 && y2 > x1)) continue;
-            const uint32_t a = x2 - y1 + 1, b = y2 - x1 + 1;
-            double ol = (double)std::min(a, b) / (double)(x2 - x1 + 1);
-            if (ol > 1.) ol = 1.;
-            if (!(ol > 0.05)) continue;
-            pi.push_back(i); pj.push_back(j); pol.push_back(ol);
+    {
+        std::vector<std::vector<uint32_t>> pj_of(n_groups);
+        std::vector<std::vector<double>> ol_of(n_groups);
+        for (uint32_t c = 0; c < n_contigs; ++c)
+            for (uint32_t i : by_contig[c]) {
+                const uint32_t x1 = grp_range[2 * i], x2 = grp_range[2 * i + 1];
+                for (uint32_t j : by_contig[c]) {
+                    if (j == i) continue;
+                    const uint32_t y1 = grp_range[2 * j], y2 = grp_range[2 * j + 1];
+                    if (!(y1 < x2 && y2 > x1)) continue;
+                    const uint32_t a = x2 - y1 + 1, b = y2 - x1 + 1;
+                    double ol = (double)std::min(a, b) / (double)(x2 - x1 + 1);
+                    if (ol > 1.) ol = 1.;
+                    if (!(ol > 0.05)) continue;
+                    pj_of[i].push_back(j); ol_of[i].push_back(ol);
+                }
+            }
+        for (uint32_t i = 0; i < n_groups; ++i) {
+            for (size_t x = 0; x < pj_of[i].size(); ++x) { pi.push_back(i); pj.push_back(pj_of[i][x]); pol.push_back(ol_of[i][x]); }
+            pair_off[i + 1] = pi.size();
         }
-        pair_off[i + 1] = pi.size();
     }
     const uint32_t n_pairs = (uint32_t)pi.size();
     std::vector<uint32_t> sd(2ull * n_pairs + 2, 0);
     if (n_pairs) {
         HIPCHK(hipSetDevice(ctx->device));
         ctx->batch_token = 0;
+        std::vector<fl::ContigDev> cdev(n_contigs);
+        for (uint32_t c = 0; c < n_contigs; ++c) cdev[c] = contigs[c]->dev;
         const uint64_t n_reads_tot = grp_off[n_groups];
         struct Seg { size_t off, bytes; };
         size_t cursor = 0;
         auto seg = [&](size_t bytes) { Seg sg{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return sg; };
-        const Seg s_cd = seg(sizeof(fl::ContigDev)), s_go = seg(8ull * (n_groups + 1)), s_gr = seg(4ull * n_reads_tot + 4), s_lo = seg(4ull * n_groups),
-                  s_len = seg(4ull * n_groups), s_co = seg(8ull * (n_groups + 1)), s_h = seg(8ull * coff[n_groups] * A + 8), s_c = seg(coff[n_groups] + 8),
-                  s_pi = seg(4ull * n_pairs), s_pj = seg(4ull * n_pairs), s_sd = seg(8ull * n_pairs);
+        const Seg s_cd = seg(sizeof(fl::ContigDev) * n_contigs), s_gc = seg(4ull * n_groups), s_go = seg(8ull * (n_groups + 1)), s_gr = seg(4ull * n_reads_tot + 4),
+                  s_lo = seg(4ull * n_groups), s_len = seg(4ull * n_groups), s_co = seg(8ull * (n_groups + 1)), s_h = seg(8ull * coff[n_groups] * A + 8),
+                  s_c = seg(coff[n_groups] + 8), s_pi = seg(4ull * n_pairs), s_pj = seg(4ull * n_pairs), s_sd = seg(8ull * n_pairs);
         rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
         char* M = ctx->misc.as<char>();
         auto h2d = [&](Seg sg, const void* src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(M + sg.off, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess; };
-        HIPCHK(h2d(s_cd, &contig->dev, sizeof(fl::ContigDev))); HIPCHK(h2d(s_go, grp_off, 8ull * (n_groups + 1))); HIPCHK(h2d(s_gr, grp_read, 4ull * n_reads_tot));
+        HIPCHK(h2d(s_cd, cdev.data(), sizeof(fl::ContigDev) * n_contigs)); HIPCHK(h2d(s_gc, gc.data(), 4ull * n_groups));
+        HIPCHK(h2d(s_go, grp_off, 8ull * (n_groups + 1))); HIPCHK(h2d(s_gr, grp_read, 4ull * n_reads_tot));
         HIPCHK(h2d(s_lo, lo.data(), 4ull * n_groups)); HIPCHK(h2d(s_len, len.data(), 4ull * n_groups)); HIPCHK(h2d(s_co, coff.data(), 8ull * (n_groups + 1)));
         HIPCHK(h2d(s_pi, pi.data(), 4ull * n_pairs)); HIPCHK(h2d(s_pj, pj.data(), 4ull * n_pairs));
         HIPCHK(hipMemsetAsync(M + s_h.off, 0, s_h.bytes, ctx->stream));
         fl::ConsensusArgs ca{};
-        ca.contig = (const fl::ContigDev*)(M + s_cd.off); ca.grp_off = (const uint64_t*)(M + s_go.off); ca.grp_read = (const uint32_t*)(M + s_gr.off);
+        ca.contigs = (const fl::ContigDev*)(M + s_cd.off); ca.grp_contig = (const uint32_t*)(M + s_gc.off);
+        ca.grp_off = (const uint64_t*)(M + s_go.off); ca.grp_read = (const uint32_t*)(M + s_gr.off);
         ca.span_lo = (const uint32_t*)(M + s_lo.off); ca.span_len = (const uint32_t*)(M + s_len.off); ca.cons_off = (const uint64_t*)(M + s_co.off);
         ca.hist = (unsigned long long*)(M + s_h.off); ca.cons = (uint8_t*)(M + s_c.off); ca.n_groups = n_groups;
         if (A == 2) hipLaunchKernelGGL(fl::consensus_kernel<2>, dim3(n_groups), dim3(256), 0, ctx->stream, ca);
@@ -1096,10 +1121,18 @@ int floria_hip_hapq(floria_hip_ctx* ctx, const floria_hip_contig* contig, const 
         uint64_t hq = prod > 0. ? (prod >= 18446744073709551615. ? ~0ull : (uint64_t)prod) : 0;      // `as usize`: saturating, NaN -> 0
         if (n_i == 1) hq = 0;
         hapq[i] = (uint8_t)std::min<uint64_t>(hq, 60);
-        rel_err[i] = st[4ull * i + 1] / avgerr;
+        rel_err[i] = st[4ull * i + 1] / avg_err[gc[i]];
     }
-    *avg_err = avgerr;
     return 0;
+}
+
+int floria_hip_hapq(floria_hip_ctx* ctx, const floria_hip_contig* contig, const uint64_t* grp_off, const uint32_t* grp_read,
+                    const uint32_t* grp_range, uint32_t n_groups, const uint64_t* snp_to_genome_pos, uint32_t n_snps,
+                    uint64_t block_length, uint8_t* hapq, double* rel_err, double* avg_err) {
+    if (!contig || !avg_err) return fail(FLORIA_E_INVALID, "null argument");
+    const floria_hip_contig* one[1] = {contig};
+    const uint64_t* pos[1] = {snp_to_genome_pos};
+    return floria_hip_hapq_batch(ctx, one, 1, nullptr, grp_off, grp_read, grp_range, n_groups, pos, &n_snps, block_length, hapq, rel_err, avg_err);
 }
 
 // ---- S2 --------------------------------------------------------------------------------------------------------

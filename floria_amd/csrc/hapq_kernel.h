@@ -16,7 +16,8 @@
 namespace fl {
 
 struct ConsensusArgs {
-    const ContigDev* contig;        // one contig
+    const ContigDev* contigs;
+    const uint32_t* grp_contig;     // [n_groups]
     const uint64_t* grp_off;        // [n_groups+1] into grp_read
     const uint32_t* grp_read;
     const uint32_t* span_lo;        // [n_groups] smallest first_position of the haploset's reads (1-based SNP index)
@@ -34,7 +35,7 @@ template <int A>
 __global__ __launch_bounds__(256) void consensus_kernel(ConsensusArgs g) {
     const uint32_t gi = blockIdx.x, tid = threadIdx.x;
     if (gi >= g.n_groups) return;
-    const ContigDev cd = *g.contig;
+    const ContigDev cd = g.contigs[g.grp_contig[gi]];
     const uint32_t lo = g.span_lo[gi], len = g.span_len[gi];
     unsigned long long* hist = g.hist + g.cons_off[gi] * A;
     const uint32_t grp = tid >> 4, sub = tid & 15;

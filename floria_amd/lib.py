@@ -25,7 +25,7 @@ SYMBOLS = [
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
     "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
     "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered", "floria_hip_haploset_stats",
-    "floria_hip_hapq",
+    "floria_hip_hapq", "floria_hip_hapq_batch",
 ]
 
 
@@ -208,6 +208,25 @@ class FloriaHip:
                                       C.c_uint32(len(groups)), capi.ptr(pos, C.c_uint64), C.c_uint32(len(pos)), C.c_uint64(int(block_length)),
                                       capi.ptr(hq, C.c_uint8), capi.ptr(rel, C.c_double), C.byref(avg)))
         return hq, rel, avg.value
+
+    def hapq_batch(self, contigs, grp_contig, groups, ranges, snp_positions, block_length):
+        """get_hapq for the haplosets of many contigs in one call -> (hapq uint8 [n], rel_err float64 [n], avg_err float64 [n_contigs])."""
+        arr = (C.c_void_p * len(contigs))(*[c._h for c in contigs])
+        gc = np.ascontiguousarray(grp_contig, np.uint32)
+        off = np.zeros(len(groups) + 1, np.uint64)
+        off[1:] = np.cumsum([len(g) for g in groups])
+        reads = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint32) for g in groups]) if len(groups) else np.zeros(0, np.uint32), np.uint32)
+        rng = np.ascontiguousarray(np.asarray(ranges, np.uint32).reshape(-1))
+        pos = [np.ascontiguousarray(p, np.uint64) for p in snp_positions]
+        pp = (C.POINTER(C.c_uint64) * len(pos))(*[capi.ptr(p, C.c_uint64) for p in pos])
+        ns = np.ascontiguousarray([len(p) for p in pos], np.uint32)
+        hq = np.zeros(len(groups), np.uint8)
+        rel = np.zeros(len(groups), np.float64)
+        avg = np.zeros(len(contigs), np.float64)
+        _check(load().floria_hip_hapq_batch(self._h, arr, C.c_uint32(len(contigs)), capi.ptr(gc, C.c_uint32), capi.ptr(off, C.c_uint64),
+                                            capi.ptr(reads, C.c_uint32), capi.ptr(rng, C.c_uint32), C.c_uint32(len(groups)), pp, capi.ptr(ns, C.c_uint32),
+                                            C.c_uint64(int(block_length)), capi.ptr(hq, C.c_uint8), capi.ptr(rel, C.c_double), capi.ptr(avg, C.c_double)))
+        return hq, rel, avg
 
     # S2 --------------------------------------------------------------------------------------------
     def reassign_batch(self, contigs, grp_contig, groups, ranges, epsilon, read_orders=None):

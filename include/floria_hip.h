@@ -224,6 +224,13 @@ int  floria_hip_hapq(floria_hip_ctx* ctx, const floria_hip_contig* contig,
                      const uint64_t* snp_to_genome_pos, uint32_t n_snps, uint64_t block_length,
                      uint8_t* hapq, double* rel_err, double* avg_err);
 
+/* The same for the haplosets of many contigs in one call (grp_contig[g] indexes `contigs`, pairs are searched inside a contig,
+ * snp_to_genome_pos[c] / n_snps[c] / avg_err[c] are per contig): three launches for the whole run instead of three per contig. */
+int  floria_hip_hapq_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs, const uint32_t* grp_contig,
+                           const uint64_t* grp_off, const uint32_t* grp_read, const uint32_t* grp_range, uint32_t n_groups,
+                           const uint64_t* const* snp_to_genome_pos, const uint32_t* n_snps, uint64_t block_length,
+                           uint8_t* hapq, double* rel_err, double* avg_err);
+
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */

@@ -43,8 +43,10 @@ def all_hapq():
         tot.append(ctx.hapq(res[ci], [fg[k] for k in idx], [fr[k] for k in idx], contigs[ci].snp_pos, 10000)[0])
     return tot
 t_hq, hq = timed(all_hapq, 1)
+t_hqb, hqb = timed(lambda: ctx.hapq_batch(res, fc, fg, fr, [c.snp_pos for c in contigs], 10000), 2)
+assert np.array_equal(np.concatenate(hq), hqb[0])
 print(f"{n} contigs, {r.n_blocks} blocks, {len(groups)} block haplosets -> {len(fg)} final haplosets")
-print(f"S1 phase_blocks_batch {t_s1:.1f} ms | hap_graph {t_hg:.1f} ms | S2 reassign_batch {t_s2:.1f} ms | haploset_stats {t_st:.1f} ms | hapq (per contig, {n} calls) {t_hq:.1f} ms")
+print(f"S1 phase_blocks_batch {t_s1:.1f} ms | hap_graph {t_hg:.1f} ms | S2 reassign_batch {t_s2:.1f} ms | haploset_stats {t_st:.1f} ms | hapq (per contig, {n} calls) {t_hq:.1f} ms | hapq_batch {t_hqb:.1f} ms")
 print("S2 device timing:", {k: round(v, 2) for k, v in tm_s2.items() if k in ("reassign_ms", "h2d_ms", "d2h_ms", "total_ms")})
 print("HAPQ histogram:", np.bincount(np.concatenate(hq), minlength=61)[[0, 10, 20, 30, 40, 50, 60]].tolist(), "...")
 # the C entry point alone (arrays prebuilt): how much of S2 is libfloria_hip.so and how much the Python list handling

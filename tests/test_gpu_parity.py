@@ -475,3 +475,30 @@ def test_hapq_four_alleles_ties_and_q0(gpu_ctx, hip_lib, oracle_mod):
     for k in range(len(groups)):
         assert _same_f64(st[k], oracle_mod.haploset_stats(pile, groups[k], ranges[k][0], ranges[k][1])), k
     rc.free()
+
+
+def test_hapq_batch_equals_per_contig(gpu_ctx, hip_lib, oracle_mod):
+    contigs = [synth.make_config_contig(4, i, 0.4) for i in range(3)] + [synth.make_config_contig(1, 0, 1.0)]
+    res = [gpu_ctx.upload(c.pileup) for c in contigs]
+    groups, ranges, gc, per = [], [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+        r = gpu_ctx.phase_blocks(res[i], s, e, hip_lib.make_params(EPS))
+        g, rg = groups_from_blocks(r, s, e)
+        per.append(gpu_ctx.hapq(res[i], g, rg, c.snp_pos, 10000))
+        groups += g; ranges += rg; gc += [i] * len(g)
+    # interleave the groups of different contigs: only the order inside a contig matters
+    order = np.argsort(np.array(gc) * 0 + np.arange(len(gc)) % 7, kind="stable")
+    hq, rel, avg = gpu_ctx.hapq_batch(res, [gc[k] for k in order], [groups[k] for k in order], [ranges[k] for k in order],
+                                      [c.snp_pos for c in contigs], 10000)
+    back = np.empty(len(order), np.int64); back[order] = np.arange(len(order))
+    hq, rel = hq[back], rel[back]
+    o = 0
+    for i in range(len(contigs)):
+        n = len(per[i][0])
+        assert np.array_equal(hq[o:o + n], per[i][0]) and _same_f64(rel[o:o + n], per[i][1]) and _same_f64([avg[i]], [per[i][2]])
+        ohq, orel, oavg = oracle_mod.hapq(contigs[i].pileup, groups[o:o + n], ranges[o:o + n], contigs[i].snp_pos, 10000)
+        assert np.array_equal(per[i][0], ohq) and _same_f64(per[i][1], orel) and _same_f64([per[i][2]], [oavg])
+        o += n
+    for x in res:
+        x.free()
