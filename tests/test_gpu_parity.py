@@ -502,3 +502,21 @@ def test_hapq_batch_equals_per_contig(gpu_ctx, hip_lib, oracle_mod):
         o += n
     for x in res:
         x.free()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_pileups_default_beam_width(gpu_ctx, hip_lib, oracle_mod, seed):
+    # beam width 10, biallelic, no q=0 cells: the ploidy-specialised instances (4 waves per SIMD for ploidy 2-3), the bulk insert path and its
+    # hash-slot fallback, on inputs with many exact ties (equal qualities), noisy reads and very uneven read lengths
+    rng = np.random.default_rng(9000 + seed)
+    ploidy = int(rng.integers(1, 6))
+    pile = random_pileup(rng, int(rng.integers(200, 900)), int(rng.integers(15, 150)), ploidy, max_len=int(rng.integers(2, 90)),
+                         alleles=2, err=float(rng.choice([0.0, 0.02, 0.08, 0.25])), drop=float(rng.choice([0.0, 0.1, 0.4])),
+                         qlo=30 if seed % 3 == 0 else 3, qhi=30 if seed % 3 == 0 else 41)
+    S = int(pile.last.max())
+    s = np.array([1, max(1, S // 4), max(1, S // 2)]); e = np.array([max(1, S // 2), max(1, 3 * S // 4), S])
+    P = int(rng.integers(2, 6))
+    eps = [EPS, 0.04, 0.0625][seed % 3]
+    ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, s, e, eps=eps, P=P, B=10)
+    assert_block_results_equal(ro, rg, f"seed {seed}")
+    assert rg.min_prune_margin == ro.min_prune_margin
