@@ -357,7 +357,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         if (const char* te = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(te); if (tv == 1024 || tv == 512 || tv == 128) threads = (uint32_t)tv; }   // dev knob
         const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
         const size_t hist_bytes = (size_t)span_max * p * A * 8;
-        const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 8 + 15) & ~(size_t)15) : 0;
+        const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 12 + 15) & ~(size_t)15) : 0;
         const bool hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
         const size_t code_bytes = hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
         const size_t lds = moved_bytes + meta_bytes + (hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0) + 16;

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     __shared__ uint32_t s_errm[MAX_PLOIDY];
     __shared__ uint32_t s_size[MAX_PLOIDY];
     __shared__ uint32_t s_ncand, s_nmoves, s_job;
+    __shared__ uint32_t s_chg_lo, s_chg_hi;          // positions whose code byte changed in the last batch of moves (HL)
     __shared__ double s_score;
     uint32_t* s_moved = (uint32_t*)smem;
 
@@ -108,9 +109,10 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     constexpr int KMAX = TP ? TP : MAX_PLOIDY;
     const uint32_t moved_bytes = (((g.n_max + 31) / 32) * 4 + 15) & ~15u;
     const uint32_t meta_n = g.n_max <= (uint32_t)OPT_META_MAX ? g.n_max : 0;            // 0 = read the metadata from HBM every time
-    const uint32_t meta_bytes = (meta_n * 8 + 15) & ~15u;
+    const uint32_t meta_bytes = (meta_n * 12 + 15) & ~15u;
     uint32_t* m_cb = (uint32_t*)(smem + moved_bytes);
     uint32_t* m_lk = m_cb + meta_n;                                                   // cell count | partition << 24
+    uint32_t* m_fl = m_lk + meta_n;                                                   // first | last << 16 position index of the read (span <= 65535)
     uint64_t* hist = HL ? (uint64_t*)(smem + moved_bytes + meta_bytes) : g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
     // HL: one CODE byte per (position, partition) next to the histogram — bit a = allele a attains the position's maximal phred sum, 0 =
     // nothing observed — refreshed after the build and after every batch of moves; the distance pass (70 % of the kernel) then reads
@@ -151,15 +153,19 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             const uint32_t r = reads[i], k = pin[i];
             part[i] = (uint8_t)k;
             atomicAdd(&s_size[k], 1u);
-            if (meta) { const uint32_t cb = G(cd.read_off)[r]; m_cb[i] = cb; m_lk[i] = (G(cd.read_off)[r + 1] - cb) | (k << 24); }
+            if (meta) { const uint32_t cb = G(cd.read_off)[r]; m_cb[i] = cb; m_lk[i] = (G(cd.read_off)[r + 1] - cb) | (k << 24);
+                        m_fl[i] = (G(cd.first)[r] - pos0) | ((G(cd.last)[r] - pos0) << 16); }
         }
         __syncthreads();
         auto read_meta = [&](uint32_t i, uint32_t& cb, uint32_t& len, uint32_t& k) {
             if (meta) { cb = m_cb[i]; const uint32_t lk = m_lk[i]; len = lk & 0xffffffu; k = lk >> 24; }
             else { const uint32_t r = reads[i]; cb = G(cd.read_off)[r]; len = G(cd.read_off)[r + 1] - cb; k = part[i]; }
         };
-        auto refresh_codes = [&]() {
+        // `track`: record the interval of positions whose code changed — a read's distances depend on the codes at its positions only,
+        // so after a batch of moves only the reads that reach into that interval are re-evaluated (moves rarely flip a consensus)
+        auto refresh_codes = [&](bool track) {
             if (!HL) return;
+            if (track) { if (tid == 0) { s_chg_lo = 0xffffffffu; s_chg_hi = 0; } __syncthreads(); }
             for (uint32_t x = tid; x < span * p; x += OPT_THREADS) {            // x = position * p + partition
                 const uint64_t* cp = hist + (uint64_t)x * A;
                 uint64_t q[A], mx = 0;
@@ -168,7 +174,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 uint32_t c = 0;
 #pragma unroll
                 for (int a = 0; a < A; ++a) c |= (mx != 0 && q[a] == mx) ? (1u << a) : 0u;
-                codes[x] = (uint8_t)c;
+                if (!track) codes[x] = (uint8_t)c;
+                else if (codes[x] != (uint8_t)c) { codes[x] = (uint8_t)c; const uint32_t pr = x / p; atomicMin(&s_chg_lo, pr); atomicMax(&s_chg_hi, pr); }
             }
             __syncthreads();
         };
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
 
-        refresh_codes();
+        refresh_codes(false);
         OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
@@ -239,9 +246,19 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 // ---- opt_iterate (:292-358): distance of every read to every partition ------------------------
                 // 16 lanes per read: every lane classifies its cells against all p partitions (p x 16 B of one histogram row),
                 // packed partial (diff Q24 << 16 | #eps) per partition, DPP row all-reduce, lane k of the row stores
+#ifdef FLORIA_OPT_FULL_DIST
+                const bool incremental = false;
+#else
+                const bool incremental = HL && meta && it > 0 && span <= 65535u;
+#endif
+                const uint32_t chg_lo = incremental ? s_chg_lo : 0u, chg_hi = incremental ? s_chg_hi : 0xffffffffu;
                 for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                     uint32_t cb = 0, len = 0, kk = 0;
                     if (i < n) read_meta(i, cb, len, kk);
+                    if (incremental && i < n) {             // no code changed at any position of this read: its distances stand
+                        const uint32_t fl = m_fl[i];
+                        if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) len = 0;
+                    }
                     uint64_t acc[KMAX];
 #pragma unroll
                     for (int k = 0; k < KMAX; ++k) acc[k] = 0;
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     for (int k = 0; k < KMAX; ++k) {
                         if ((uint32_t)k < p) {
                             const uint64_t t = row16_sum_u64(acc[k]);
-                            if (sub == (uint32_t)k && i < n) dist[i * p + k] = qm_to_f64(t >> 16, t & 0xffff, g.eps);
+                            if (sub == (uint32_t)k && i < n && len != 0) dist[i * p + k] = qm_to_f64(t >> 16, t & 0xffff, g.eps);
                         }
                     }
                 }
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         if (lane == 0) part[rl] = (uint8_t)to;
                     }
                     __syncthreads();
-                    refresh_codes();
+                    refresh_codes(true);
                 };
                 apply_moves(false);
                 OPT_TICK(6);     // moves
