@@ -153,8 +153,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             const uint32_t r = reads[i], k = pin[i];
             part[i] = (uint8_t)k;
             atomicAdd(&s_size[k], 1u);
-            if (meta) { const uint32_t cb = G(cd.read_off)[r]; m_cb[i] = cb; m_lk[i] = (G(cd.read_off)[r + 1] - cb) | (k << 24);
-                        m_fl[i] = (G(cd.first)[r] - pos0) | ((G(cd.last)[r] - pos0) << 16); }
+            if (meta) { const uint4 mr = *(const uint4*)(cd.meta + 8 * (uint64_t)r);     // {cell offset, #cells, first, last}: one 16-B load
+                        m_cb[i] = mr.x; m_lk[i] = mr.y | (k << 24); m_fl[i] = (mr.z - pos0) | ((mr.w - pos0) << 16); }
         }
         __syncthreads();
         auto read_meta = [&](uint32_t i, uint32_t& cb, uint32_t& len, uint32_t& k) {
