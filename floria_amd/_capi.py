@@ -54,7 +54,8 @@ class CTiming(C.Structure):
                 ("total_ms", C.c_double), ("beam_launches", C.c_uint32), ("optimize_launches", C.c_uint32),
                 ("algorithmic_bytes", C.c_uint64), ("beam_steps", C.c_uint64),
                 ("beam_launch_bytes", C.c_uint64), ("jobs", C.c_uint64),
-                ("streams", C.c_uint32), ("reserved", C.c_uint32), ("phase_ms", C.c_double)]
+                ("streams", C.c_uint32), ("stage_width", C.c_uint32), ("phase_ms", C.c_double),
+                ("upload_pinned_bytes", C.c_uint64), ("upload_staged_bytes", C.c_uint64)]
 
 
 def ptr(a, ctype):

@@ -44,7 +44,8 @@ struct BeamArgs {
     double    eps, div_factor, cutoff;
     const uint64_t *Rq1, *Rp1, *Rq2, *Rp2;   // [span_max*A] random multipliers of the linear state hash
     uint8_t*  part_out;            // [blk_read_off[n_blocks]] partition of every read of every block
-    unsigned long long* min_margin_bits;
+    double*   job_margin;          // [n_blocks*max_ploidy] min |p_k - lse - ln(PROB_CUTOFF)| over the pruning decisions of the (block, ploidy) job
+    uint32_t  max_ploidy;
     uint32_t* diag;                // [0] = count of binom evaluations beyond the table, [1] = free-list underflow
     unsigned long long* steps_done;
     unsigned long long* prof;      // [32] phase cycle counters (-DFLORIA_PROF)
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = g.job_block[job];
         if (g.blk_done[b]) continue;
+        min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
@@ -449,12 +451,14 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
             }
             atomicAdd(g.steps_done, (unsigned long long)n);
         }
+        {
+            const double jm = wave_min_f64(min_margin);
+            if (lane == 0) g.job_margin[(uint64_t)b * g.max_ploidy + g.ploidy - 1] = jm;
+        }
         __syncthreads();
     }
-    min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);
     if (lane == 0) {
-        atomicMin(g.min_margin_bits, (unsigned long long)__double_as_longlong(min_margin));
         if (n_fallback) atomicAdd(&g.diag[0], n_fallback);
     }
 }

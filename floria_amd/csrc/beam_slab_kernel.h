@@ -167,6 +167,7 @@ void beam_slab_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = uni(g.job_block[job]);
         if (g.blk_done[b]) continue;
+        min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
@@ -692,6 +693,7 @@ void beam_slab_kernel(BeamArgs g) {
                 }
             }
             if (lane == 0) atomicAdd(g.steps_done, (unsigned long long)n);
+            { const double jm = wave_min_f64(min_margin); if (lane == 0) g.job_margin[(uint64_t)b * g.max_ploidy + p - 1] = jm; }
         }
         __syncthreads();
         BEAM_TICK(6);
@@ -703,10 +705,8 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
-    min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);
     if (lane == 0) {
-        atomicMin(g.min_margin_bits, (unsigned long long)__double_as_longlong(min_margin));
         if (n_fallback) atomicAdd(&g.diag[0], n_fallback);
     }
 }

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = uni(g.job_block[job]);
         if (g.blk_done[b]) continue;
+        min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
@@ -454,13 +455,12 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 }
                 atomicAdd(g.steps_done, (unsigned long long)n);
             }
+            { const double jm = wave_min_f64(min_margin); if (lane == 0) g.job_margin[(uint64_t)b * g.max_ploidy + g.ploidy - 1] = jm; }
         }
         __syncthreads();
     }
-    min_margin = wave_min_f64(min_margin);
     n_fallback = wave_sum_u32(n_fallback);
     if (lane == 0) {
-        atomicMin(g.min_margin_bits, (unsigned long long)__double_as_longlong(min_margin));
         if (n_fallback) atomicAdd(&g.diag[0], n_fallback);
     }
 }

@@ -21,7 +21,9 @@
 #include <numeric>
 #include <string>
 #include <utility>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/floria_hip.h"
@@ -35,6 +37,7 @@
 #include "blocks_kernel.h"
 #include "graph_kernel.h"
 #include "stats_kernel.h"
+#include "upload_kernel.h"
 
 static_assert(FLORIA_MAX_PLOIDY == fl::MAX_PLOIDY, "ploidy limits out of sync");
 
@@ -69,6 +72,24 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
+};
+
+// Pageable sources go through a ring of pinned staging buffers filled by a few host threads (a single pageable hipMemcpy is
+// staged by the runtime on one thread at a few GB/s); pinned sources are handed to the DMA engine as they are.
+struct StagePool {
+    static constexpr size_t SEG = 16u << 20;      // large pieces: every copy in a stream pays ~0.2 ms of completion-signal latency
+    static constexpr uint32_t NBUF = 8;
+    char* buf[NBUF] = {};
+    hipEvent_t ev[NBUF] = {};
+    bool used[NBUF] = {};
+    int init() {
+        for (uint32_t i = 0; i < NBUF; ++i) if (!buf[i]) {
+            if (hipHostMalloc((void**)&buf[i], SEG, hipHostMallocDefault) != hipSuccess) return fail(FLORIA_E_NOMEM, "hipHostMalloc(staging) failed");
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return fail(FLORIA_E_DEVICE, "hipEventCreate failed");
+        }
+        return 0;
+    }
+    void release() { for (uint32_t i = 0; i < NBUF; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); buf[i] = nullptr; ev[i] = nullptr; used[i] = false; } }
 };
 
 uint64_t splitmix64(uint64_t& s) {
@@ -108,16 +129,32 @@ struct BigCache {
 BigCache g_big;
 }  // namespace
 
+// Tuning / test knobs of a context (floria_hip_set_option); the defaults are what bench.py measures.  Read from the environment
+// ONCE, at floria_hip_create (FLORIA_HIP_GROUPS, FLORIA_HIP_BEAM, FLORIA_HIP_NO_SPECIALIZED, FLORIA_HIP_NO_P1_SHORTCUT,
+// FLORIA_HIP_OPT_THREADS, FLORIA_HIP_OPT_GLOBAL, FLORIA_HIP_SPECULATE); none of them changes results.
+struct Knobs {
+    uint32_t groups = 0;          // job groups (0 = auto: 2 when the batch has >= 2048 non-empty blocks)
+    uint32_t beam_path = 0;       // 0 auto | 1 generic | 2 fast | 3 slab | 4 wide
+    uint32_t no_specialized = 0;  // runtime ploidy / beam width instead of the template instances
+    uint32_t no_p1_shortcut = 0;  // run the beam kernel for ploidy 1 too
+    uint32_t opt_threads = 0;     // 0 auto | 128 | 512 | 1024
+    uint32_t opt_global = 0;      // optimise histogram in HBM
+    int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P}
+};
+
+struct Arena;
+
 struct floria_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint32_t user_slots = 0, user_groups = 0;
+    uint32_t user_slots = 0;
+    Knobs knobs;
     int n_cu = 256;
-    // job groups: the (block, ploidy) launch triples of disjoint block groups run on their own streams, so one group's
-    // launch tail (persistent waves draining their last jobs) is filled by the other groups' kernels
+    // launch lanes (job group x position inside a ploidy stage): every lane has its own stream and scratch slice, see run_phase
     static constexpr uint32_t MAX_GROUPS = 8;
-    hipStream_t gstream[MAX_GROUPS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    static constexpr uint32_t MAX_LANES = 32;
+    hipStream_t gstream[MAX_LANES] = {};
+    hipEvent_t ev_fork[MAX_LANES] = {}, ev_join[MAX_LANES] = {};
     hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
     hipEvent_t ev_rids = nullptr;
     // cached tables
@@ -126,8 +163,8 @@ struct floria_hip_ctx {
     DevBuf d_binom;
     DevBuf d_hash;            // Rq1 | Rp1 | Rq2 | Rp2, each hash_len u64
     uint32_t hash_len = 0;
-    std::vector<uint64_t> h_rq1, h_rq2;   // host copies of the Rq tables (per-read hash constants are computed at upload)
     uint32_t w24[256];
+    DevBuf d_w24;             // the same table on the device (flatten_kernel)
     uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
     // scratch pools
     DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
@@ -140,46 +177,42 @@ struct floria_hip_ctx {
     uint32_t last_nall = 2;
     std::vector<uint32_t> last_bc, last_start, last_end;
     DevBuf graph_buf, graph_hist, graph_sort;
+    // uploads
+    DevBuf up_tmp;                            // raw allele / qual bytes + the flatten kernel's tables (transient per upload)
+    std::vector<Arena*> arena_cache;          // released batch arenas, reused by the next upload
+    StagePool stage;                          // pinned staging ring for pageable sources
+    uint32_t stage_threads = 8;
+};
+
+// A batch of contigs uploaded together shares ONE device allocation (an arena): raw CSR regions filled by DMA, flattened
+// regions written by flatten_kernel.  The arena is released when its last contig handle is freed (and then kept in a small
+// per-context cache, so a host that uploads batch after batch never reallocates).
+struct Arena {
+    floria_hip_ctx* ctx = nullptr;
+    DevBuf buf;
+    uint32_t n_contigs = 0, refs = 0;
+    uint64_t R = 0, C = 0;                                   // reads / cells of the batch
+    size_t off_ro = 0, off_first = 0, off_last = 0;          // region offsets (bytes)
+    std::vector<uint64_t> read_prefix;                       // [n_contigs+1]
+    // host copies of first/last (haplogroup bookkeeping of S2 / get_hapq), fetched from the device on first use
+    bool host_meta = false;
+    std::vector<uint32_t> h_first, h_last;
 };
 
 struct floria_hip_contig {
     floria_hip_ctx* ctx = nullptr;
+    Arena* arena = nullptr;
+    uint32_t idx = 0;           // position inside the arena's batch
     uint32_t n_reads = 0;
     uint64_t n_cells = 0;
     uint32_t max_len = 0;       // max cells per read
     uint32_t n_alleles = 2;     // 2 or 4 (kernel template)
     bool has_q0 = false;        // some cell has qual 0 (weight 0): presence != (weight sum > 0)
-    std::vector<uint32_t> h_first, h_last, h_read_off;
-    DevBuf d_read_off, d_first, d_last, d_snp, d_aq, d_tw, d_meta;
+    const uint32_t *h_first = nullptr, *h_last = nullptr;   // valid after host_meta(c)
     fl::ContigDev dev{};
 };
 
 namespace {
-
-int validate_pileup(const floria_pileup* p, uint32_t* max_len, uint32_t* max_allele) {
-    if (!p) return fail(FLORIA_E_INVALID, "null pileup");
-    if (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last))
-        return fail(FLORIA_E_INVALID, "null pileup field");
-    uint32_t ml = 0, ma = 0;
-    for (uint32_t r = 0; r < p->n_reads; ++r) {
-        const uint32_t b = p->read_off[r], e = p->read_off[r + 1];
-        if (e <= b) return fail(FLORIA_E_INVALID, "read " + std::to_string(r) + " has no cells");
-        if (p->snp[b] != p->first[r] || p->snp[e - 1] != p->last[r]) return fail(FLORIA_E_INVALID, "first/last of read " + std::to_string(r) + " do not match its cells");
-        if (p->snp[b] == 0) return fail(FLORIA_E_INVALID, "SNP positions are 1-based");
-        for (uint32_t c = b; c < e; ++c) {
-            if (c > b && p->snp[c] <= p->snp[c - 1]) return fail(FLORIA_E_INVALID, "cells of read " + std::to_string(r) + " not strictly ascending");
-            if (p->allele[c] >= FLORIA_MAX_ALLELES) return fail(FLORIA_E_UNSUPPORTED, "allele index > 3 (read " + std::to_string(r) + ")");
-            ma = std::max<uint32_t>(ma, p->allele[c]);
-        }
-        ml = std::max(ml, e - b);
-        if (r > 0) {   // Frag::cmp (types_structs.rs:87-93)
-            const bool ok = p->first[r - 1] < p->first[r] || (p->first[r - 1] == p->first[r] && p->last[r - 1] >= p->last[r]);
-            if (!ok) return fail(FLORIA_E_INVALID, "reads not sorted by Frag::cmp at read " + std::to_string(r));
-        }
-    }
-    *max_len = ml; *max_allele = ma;
-    return 0;
-}
 
 int ensure_binom(floria_hip_ctx* ctx, double eps, uint32_t nmax) {
     nmax = std::min(nmax, BINOM_NMAX_CAP);
@@ -225,8 +258,6 @@ int ensure_hash(floria_hip_ctx* ctx, uint32_t len) {
     HIPCHK(hipMemcpyAsync(ctx->d_hash.p, t.data(), t.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hash_len = len;
-    ctx->h_rq1.assign(t.begin(), t.begin() + len);
-    ctx->h_rq2.assign(t.begin() + 2 * (size_t)len, t.begin() + 3 * (size_t)len);
     return 0;
 }
 
@@ -261,217 +292,279 @@ struct EventTimer {
 enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5, K_PHASE = 6 };
 
 void sync_all(floria_hip_ctx* ctx) {
-    for (uint32_t g = 0; g < floria_hip_ctx::MAX_GROUPS; ++g) if (ctx->gstream[g]) (void)hipStreamSynchronize(ctx->gstream[g]);
+    for (uint32_t g = 0; g < floria_hip_ctx::MAX_LANES; ++g) if (ctx->gstream[g]) (void)hipStreamSynchronize(ctx->gstream[g]);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(ctx->stream);
 }
 
-// One launch triple (beam -> optimise -> stop rule) per ploidy and JOB GROUP.  `jobs` holds the non-empty blocks, longest
-// first inside each group; group g owns jobs [group_off[g], group_off[g+1]) and runs on its own stream with its own scratch.
+// ---- S1 launch plan ---------------------------------------------------------------------------------------------------------
+// The per-ploidy loop of get_local_hap_blocks (graph_processing.rs:132-252) runs as STAGES: a stage is a set of consecutive
+// ploidies whose (beam -> optimise) chains run concurrently, each on its own stream with its own scratch slice ("lane"), followed
+// by the stop rule (select_kernel) for the stage's ploidies in ascending order.  The default is one ploidy per stage (no
+// speculative work: the launches of ploidy p+1 skip the blocks whose stop rule fired at p).  A ploidy run never reads an earlier
+// ploidy's result (only the stop rule does, :198-251), so running several ploidies of a block at once gives identical results;
+// it trades extra (block, ploidy) jobs for a shorter dependent chain and is used when the batch cannot fill the chip.
+// JOB GROUPS: the non-empty blocks are dealt into G groups whose stage sequences run independently on separate streams, so one
+// group's launch tail (persistent waves draining their last jobs) is filled by the other group's kernels.
+// A lane (group g, position j inside the stage) owns the SAME byte slice of every scratch pool for the whole call — sized for
+// the largest ploidy — so kernels of different groups/ploidies that are live at the same time can never alias.
+struct PloidyPlan {
+    uint32_t p = 0, LM = 0;
+    bool shortcut = false, wide = false, slab = false, fast = false, beam_spec = false;
+    uint64_t state_bytes = 0, hist_stride = 0;
+    fl::SlabLds SL{}; fl::WideLds WL{}; fl::BeamLds LY{};
+    uint32_t beam_slots = 0;
+    uint64_t cand_cap = 1;
+    uint32_t threads = 128, opt_slots = 0;
+    size_t opt_lds = 0;
+    bool hl = false, opt_spec = false;
+};
+
 template <int A>
 int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const std::vector<uint32_t>& group_off,
               const uint32_t* d_jobs, uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
-              uint8_t* d_beam_part, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
-              uint32_t* d_tried, uint32_t* d_queue, unsigned long long* d_margin, uint32_t* d_diag,
+              uint8_t* d_beam_part, const std::vector<std::vector<uint32_t>>& stages, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
+              uint32_t* d_tried, uint32_t* d_queue, double* d_margin, uint32_t* d_diag,
               unsigned long long* d_steps, EventTimer& T, bool& p1_shortcut) {
     const uint32_t P = prm->max_ploidy, B = prm->beam;
+    const Knobs& K = ctx->knobs;
     p1_shortcut = false;
     const uint32_t n_jobs = (uint32_t)jobs.size();
     const uint32_t G = (uint32_t)group_off.size() - 1;
     if (n_jobs == 0) return 0;
+    uint32_t W = 1;                                        // widest stage
+    for (auto& st : stages) W = std::max<uint32_t>(W, (uint32_t)st.size());
+    const uint32_t n_lanes = G * W;
+    if (n_lanes > floria_hip_ctx::MAX_LANES) return fail(FLORIA_E_INVALID, "internal: too many launch lanes");
+    uint32_t nj_max = 0;
+    for (uint32_t g = 0; g < G; ++g) nj_max = std::max(nj_max, group_off[g + 1] - group_off[g]);
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const double cutoff = std::log(PROB_CUTOFF);      // graph_processing.rs:146
-    // fork: every group stream starts after what the main stream has queued so far (uploads, memsets, block_reads_kernel)
-    hipStream_t gs[floria_hip_ctx::MAX_GROUPS];
-    gs[0] = ctx->stream;
-    if (G > 1) {
-        if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        for (uint32_t g = 1; g < G; ++g) {                 // group 0 stays on the main stream (HIP maps streams onto few hardware queues)
-            if (!ctx->gstream[g]) HIPCHK(hipStreamCreateWithFlags(&ctx->gstream[g], hipStreamNonBlocking));
-            if (!ctx->ev_join[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[g], hipEventDisableTiming));
-            gs[g] = ctx->gstream[g];
-        }
-    }
-    const int t_phase = T.begin(K_PHASE);
-    bool forked = false;
-    auto fork = [&]() -> int {
-        if (G > 1 && !forked) {
-            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-            for (uint32_t g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(gs[g], ctx->ev_fork, 0));
-            forked = true;
-        }
-        return 0;
-    };
+
+    // ---- plan every ploidy once: kernel choice, grid, scratch per slot -------------------------------------------------------
+    std::vector<PloidyPlan> plan(P + 1);
+    const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
     for (uint32_t p = 1; p <= P; ++p) {
-        const uint32_t LM = p * B;
+        PloidyPlan& q = plan[p];
+        q.p = p; q.LM = p * B;
+        const uint32_t LM = q.LM;
         if (LM > 65000) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam too large");
-        // ---- beam search ---------------------------------------------------------------------------------------
         // ploidy 1 has nothing to search: one state, one partition, every child passes (p_k - lse == 0 > ln 0.01), the
         // partition is "all reads in haplotype 0" (global_clustering.rs:74-134 with ploidy == 1) -> a memset.
-        const bool shortcut = p == 1 && !getenv("FLORIA_HIP_NO_P1_SHORTCUT");
-        if (shortcut) {
-            HIPCHK(hipMemsetAsync(d_beam_part, 0, tot_reads, ctx->stream));
-            p1_shortcut = true;
-        }
-        if (int rc = fork()) return rc;
-        // sizes shared by the groups of this ploidy
-        const uint64_t state_bytes = (uint64_t)LM * span_max * p * A * 8;
+        q.shortcut = p == 1 && !K.no_p1_shortcut;
+        q.state_bytes = (uint64_t)LM * span_max * p * A * 8;
         // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
-        const uint64_t hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 128 + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + 64 dummy u64 words (beam_slab_kernel's branch-free tails)
-        const fl::SlabLds SL = fl::slab_lds_layout(LM, p, any_q0);
-        const fl::WideLds WL = fl::wide_lds_layout(LM, p, any_q0);
-        const fl::BeamLds LY = fl::beam_lds_layout(LM);
-        const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (SL.total + 256)));
-        const uint32_t waves_per_simd = (A == 2 && !any_q0 && B == 10 && p >= 2 && p <= FLORIA_SLAB_LOW_P_MAX && !getenv("FLORIA_HIP_NO_SPECIALIZED")) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES;
-        uint32_t beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * waves_per_simd, by_lds);
-        beam_slots = std::min(beam_slots, n_jobs);
-        const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
-        while (beam_slots > 1 && (state_bytes + hist_stride * 4) * beam_slots * G > budget) beam_slots /= 2;
-        const char* force = getenv("FLORIA_HIP_BEAM");       // dev/test knob: generic | fast | slab | wide
-        const bool fits32 = (uint64_t)LM * span_max * p * A * 8 < 0xf0000000ull;
+        q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 128 + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + 64 dummy u64 words (beam_slab_kernel's branch-free tails)
+        q.SL = fl::slab_lds_layout(LM, p, any_q0);
+        q.WL = fl::wide_lds_layout(LM, p, any_q0);
+        q.LY = fl::beam_lds_layout(LM);
+        q.beam_spec = A == 2 && !any_q0 && B == 10 && p >= 2 && p <= 5 && !K.no_specialized;
+        const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.SL.total + 256)));
+        const uint32_t waves_per_simd = (q.beam_spec && p <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES;
+        q.beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * waves_per_simd, by_lds);
+        q.beam_slots = std::min(q.beam_slots, nj_max);
+        const bool fits32 = q.state_bytes < 0xf0000000ull;
         const bool small = LM <= 63 && fits32;
-        bool wide = !small && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && WL.total <= 150 * 1024;
-        if (force && !strcmp(force, "wide") && fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && WL.total <= 150 * 1024) wide = true;
-        if (force && strcmp(force, "wide")) wide = false;
-        bool slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && SL.total <= 60 * 1024;
-        bool fast = small;
-        if (force && !strcmp(force, "generic")) { slab = false; fast = false; }
-        if (force && !strcmp(force, "fast")) slab = false;
-        if (!shortcut) {
-            int rc = ctx->state_pool.ensure(state_bytes * beam_slots * G); if (rc) return rc;
-            rc = ctx->hist_pool.ensure(hist_stride * 4 * beam_slots * G); if (rc) return rc;
-            if (LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
-            if (!wide && !slab && !fast && LY.total > 48 * 1024)
-                HIPCHK(hipFuncSetAttribute((const void*)fl::beam_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY.total));
-            if (wide && WL.total > 48 * 1024) {
-                if (any_q0) HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
-                else HIPCHK(hipFuncSetAttribute((const void*)fl::beam_wide_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WL.total));
-            }
+        const bool wide_ok = fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && q.WL.total <= 150 * 1024;
+        q.wide = !small && wide_ok;
+        q.slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && q.SL.total <= 60 * 1024;
+        q.fast = small;
+        switch (K.beam_path) {                               // dev/test knob
+            case 1: q.wide = false; q.slab = false; q.fast = false; break;     // generic
+            case 2: q.wide = false; q.slab = false; break;                     // fast (where it applies)
+            case 3: q.wide = false; break;                                     // slab (where it applies)
+            case 4: q.wide = wide_ok; break;                                   // wide (where it applies)
+            default: break;
         }
-        // optimise: sizes
-        uint64_t cand_cap = 1;
-        while (cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) cand_cap <<= 1;
-        const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
+        if (!q.shortcut) {
+            if (q.LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
+            if (q.wide) q.beam_slots = std::min<uint32_t>(q.beam_slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.WL.total + 512))));
+        }
+        // optimise
+        while (q.cand_cap < (uint64_t)n_max * std::max(1u, p - 1)) q.cand_cap <<= 1;
         uint32_t threads = mean_n >= 384 ? 1024 : (mean_n >= 96 ? 512 : 128);
-        if (const char* te = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(te); if (tv == 1024 || tv == 512 || tv == 128) threads = (uint32_t)tv; }   // dev knob
+        if (K.opt_threads == 1024 || K.opt_threads == 512 || K.opt_threads == 128) threads = K.opt_threads;
         const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
         const size_t hist_bytes = (size_t)span_max * p * A * 8;
         const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 12 + 15) & ~(size_t)15) : 0;
-        const bool hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !getenv("FLORIA_HIP_OPT_GLOBAL");
-        const size_t code_bytes = hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
-        const size_t lds = moved_bytes + meta_bytes + (hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0) + 16;
+        q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global;
+        const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
+        q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0) + 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
-        if (A == 2 && hl && p <= 5 && threads == 1024 && !getenv("FLORIA_HIP_OPT_THREADS") && !getenv("FLORIA_HIP_NO_SPECIALIZED")) threads = 512;
-        uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads));
+        if (A == 2 && q.hl && p <= 5 && threads == 1024 && !K.opt_threads && !K.no_specialized) threads = 512;
+        q.threads = threads;
+        q.opt_spec = A == 2 && q.hl && threads >= 512 && p <= 5 && !K.no_specialized;
+        uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (q.opt_lds + 8 * 1024)), 2048 / threads));
         per_cu = std::min<uint32_t>(per_cu, 8);
-        const uint32_t opt_slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, n_jobs);
-        {
-            int rc = ctx->opt_hist.ensure((uint64_t)opt_slots * G * span_max * p * A * 8); if (rc) return rc;
-            rc = ctx->opt_dist.ensure((uint64_t)opt_slots * G * n_max * p * 8); if (rc) return rc;
-            rc = ctx->opt_gain.ensure((uint64_t)opt_slots * G * cand_cap * 8); if (rc) return rc;
-            rc = ctx->opt_key.ensure((uint64_t)opt_slots * G * cand_cap * 4); if (rc) return rc;
-            rc = ctx->opt_moves.ensure((uint64_t)opt_slots * G * n_max * 4); if (rc) return rc;
-        }
+        q.opt_slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, nj_max);
+    }
+    // ---- scratch: one fixed slice per lane, sized for the largest ploidy -----------------------------------------------------
+    const uint64_t budget = (uint64_t)((double)(free_b + ctx->state_pool.cap + ctx->hist_pool.cap) * 0.6);
+    for (;;) {
+        uint64_t need = 0;
+        for (uint32_t p = 1; p <= P; ++p) if (!plan[p].shortcut) need = std::max(need, (plan[p].state_bytes + plan[p].hist_stride * 4) * plan[p].beam_slots);
+        if (need * n_lanes <= budget) break;
+        bool shrunk = false;
+        for (uint32_t p = 1; p <= P; ++p) if (!plan[p].shortcut && (plan[p].state_bytes + plan[p].hist_stride * 4) * plan[p].beam_slots == need && plan[p].beam_slots > 1) { plan[p].beam_slots /= 2; shrunk = true; }
+        if (!shrunk) break;
+    }
+    uint64_t sl_state = 0, sl_hist = 0, sl_ohist = 0, sl_odist = 0, sl_ogain = 0, sl_okey = 0, sl_omoves = 0;
+    auto up256 = [](uint64_t x) -> uint64_t { return (x + 255) & ~(uint64_t)255; };
+    for (uint32_t p = 1; p <= P; ++p) {
+        const PloidyPlan& q = plan[p];
+        if (!q.shortcut) { sl_state = std::max(sl_state, up256(q.state_bytes * q.beam_slots)); sl_hist = std::max(sl_hist, up256(q.hist_stride * 4 * q.beam_slots)); }
+        sl_ohist = std::max(sl_ohist, up256((uint64_t)q.opt_slots * span_max * p * A * 8));
+        sl_odist = std::max(sl_odist, up256((uint64_t)q.opt_slots * n_max * p * 8));
+        sl_ogain = std::max(sl_ogain, up256((uint64_t)q.opt_slots * q.cand_cap * 8));
+        sl_okey = std::max(sl_okey, up256((uint64_t)q.opt_slots * q.cand_cap * 4));
+        sl_omoves = std::max(sl_omoves, up256((uint64_t)q.opt_slots * n_max * 4));
+    }
+    {   // (a pool that has to grow is freed first: hipFree synchronises the device, and nothing of this call is in flight yet)
+        int rc = ctx->state_pool.ensure(sl_state * n_lanes); if (rc) return rc;
+        rc = ctx->hist_pool.ensure(sl_hist * n_lanes); if (rc) return rc;
+        rc = ctx->opt_hist.ensure(sl_ohist * n_lanes); if (rc) return rc;
+        rc = ctx->opt_dist.ensure(sl_odist * n_lanes); if (rc) return rc;
+        rc = ctx->opt_gain.ensure(sl_ogain * n_lanes); if (rc) return rc;
+        rc = ctx->opt_key.ensure(sl_okey * n_lanes); if (rc) return rc;
+        rc = ctx->opt_moves.ensure(sl_omoves * n_lanes); if (rc) return rc;
+    }
+    // ---- streams and events: lane (g, j) runs on its own stream; lane (0, 0) is the context's main stream ---------------------
+    hipStream_t ls[floria_hip_ctx::MAX_LANES];
+    for (uint32_t l = 0; l < n_lanes; ++l) {
+        if (l == 0) { ls[0] = ctx->stream; continue; }
+        if (!ctx->gstream[l]) HIPCHK(hipStreamCreateWithFlags(&ctx->gstream[l], hipStreamNonBlocking));
+        if (!ctx->ev_join[l]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[l], hipEventDisableTiming));
+        if (!ctx->ev_fork[l]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork[l], hipEventDisableTiming));
+        ls[l] = ctx->gstream[l];
+    }
+    if (!ctx->ev_fork[0]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork[0], hipEventDisableTiming));
+    const int t_phase = T.begin(K_PHASE);
+    // ploidy 1 (always position 0 of the first stage) without a search: its beam partition is all zeros, for every group's reads
+    if (plan[1].shortcut) { HIPCHK(hipMemsetAsync(d_beam_part, 0, tot_reads, ctx->stream)); p1_shortcut = true; }
+    // fork: every group's first lane starts after what the main stream has queued so far (uploads, memsets, block_reads_kernel)
+    if (G > 1) {
+        HIPCHK(hipEventRecord(ctx->ev_fork[0], ctx->stream));
+        for (uint32_t g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(ls[g * W], ctx->ev_fork[0], 0));
+    }
+    const uint64_t* H = ctx->d_hash.as<uint64_t>();
+    for (size_t si = 0; si < stages.size(); ++si) {
+        const std::vector<uint32_t>& stage = stages[si];
         for (uint32_t g = 0; g < G; ++g) {
             const uint32_t nj = group_off[g + 1] - group_off[g];
             if (nj == 0) continue;
-            hipStream_t st = gs[g];
             const uint32_t* gjobs = d_jobs + group_off[g];
-            uint32_t* gqueue = d_queue + 2 * g;              // [0] beam, [1] optimise
-            if (!shortcut) {
-                const uint32_t slots = std::min(beam_slots, nj);
-                fl::BeamArgs a{};
-                a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
-                a.queue_head = gqueue; a.blk_done = d_done;
-                a.state_pool = ctx->state_pool.as<uint64_t>() + (state_bytes / 8) * beam_slots * g;
-                a.hist_pool = ctx->hist_pool.as<uint32_t>() + hist_stride * beam_slots * g; a.hist_stride = hist_stride;
-                a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
-                a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
-                const uint64_t* H = ctx->d_hash.as<uint64_t>();
-                a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
-                a.part_out = d_beam_part; a.min_margin_bits = d_margin; a.diag = d_diag; a.steps_done = d_steps;
-                a.prof = (unsigned long long*)(d_diag + 4);
-                HIPCHK(hipMemsetAsync(gqueue, 0, 4, st));
-                int t = T.begin(K_BEAM, st);
-                if (wide) {
-                    const uint32_t wslots = std::min<uint32_t>(slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (WL.total + 512))));
-                    if (any_q0) hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(wslots), dim3(64), WL.total, st, a);
-                    else hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(wslots), dim3(64), WL.total, st, a);
-                } else if (slab) {
-                    const bool spec = A == 2 && !any_q0 && B == 10 && p >= 2 && p <= 5 && !getenv("FLORIA_HIP_NO_SPECIALIZED");
-                    if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), SL.total, st, a);
-                    else if (spec && p == 2) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), SL.total, st, a);
-                    else if (spec && p == 3) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), SL.total, st, a);
-                    else if (spec && p == 4) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), SL.total, st, a);
-                    else if (spec && p == 5) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), SL.total, st, a);
-                    else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), SL.total, st, a);
-                } else if (fast) {
-                    const fl::FastLds FL = fl::fast_lds_layout(LM, any_q0);
-                    if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, st, a);
-                    else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, st, a);
-                } else
-                    hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), LY.total, st, a);
-                T.end(t);
-                HIPCHK(hipGetLastError());
-                ctx->timing.beam_launches++;
+            hipStream_t s0 = ls[g * W];
+            if (stage.size() > 1) {                          // the stage's extra lanes start after the group's previous stop rule
+                HIPCHK(hipEventRecord(ctx->ev_fork[g * W], s0));
+                for (uint32_t j = 1; j < stage.size(); ++j) HIPCHK(hipStreamWaitEvent(ls[g * W + j], ctx->ev_fork[g * W], 0));
             }
-            // ---- optimise + MEC stats ------------------------------------------------------------------------------
-            {
-                const uint32_t slots = std::min(opt_slots, nj);
-                const uint64_t so = (uint64_t)opt_slots * g;
-                fl::OptArgs a{};
-                a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.max_ploidy = P; a.span_max = span_max; a.n_max = n_max;
-                a.queue_head = gqueue + 1; a.blk_done = d_done; a.eps = prm->epsilon;
-                a.part_in = d_beam_part; a.part_out = d_planes + (uint64_t)(p - 1) * tot_reads;
-                a.hist_pool = ctx->opt_hist.as<uint64_t>() + so * span_max * p * A; a.dist_pool = ctx->opt_dist.as<double>() + so * n_max * p;
-                a.cand_gain_pool = ctx->opt_gain.as<uint64_t>() + so * cand_cap; a.cand_key_pool = ctx->opt_key.as<uint32_t>() + so * cand_cap;
-                a.moves_pool = ctx->opt_moves.as<uint32_t>() + so * n_max; a.cand_cap = cand_cap;
-                a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
-                a.prof = (unsigned long long*)(d_diag + 4);
-                HIPCHK(hipMemsetAsync(gqueue + 1, 0, 4, st));
-                int t = T.begin(K_OPT, st);
-                auto launch = [&](auto kern) -> hipError_t {
-                    if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
-                    hipLaunchKernelGGL(kern, dim3(slots), dim3(threads), lds, st, a);
-                    return hipGetLastError();
-                };
-                hipError_t le;
-                const bool ospec = A == 2 && hl && threads >= 512 && p <= 5 && !getenv("FLORIA_HIP_NO_SPECIALIZED");
-                if (ospec && threads == 1024)
-                    le = p == 1 ? launch(fl::optimize_kernel<2, true, 1024, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 1024, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 1024, 3>)
-                       : p == 4 ? launch(fl::optimize_kernel<2, true, 1024, 4>) : launch(fl::optimize_kernel<2, true, 1024, 5>);
-                else if (ospec)
-                    le = p == 1 ? launch(fl::optimize_kernel<2, true, 512, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 512, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 512, 3>)
-                       : p == 4 ? launch(fl::optimize_kernel<2, true, 512, 4>) : launch(fl::optimize_kernel<2, true, 512, 5>);
-                else if (hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
-                else    le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512>) : launch(fl::optimize_kernel<A, false, 128>);
-                T.end(t);
-                if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));
-                ctx->timing.optimize_launches++;
+            for (uint32_t j = 0; j < stage.size(); ++j) {
+                const uint32_t p = stage[j], lane = g * W + j;
+                const PloidyPlan& q = plan[p];
+                hipStream_t st = ls[lane];
+                uint32_t* gqueue = d_queue + 2 * lane;           // [0] beam, [1] optimise
+                uint8_t* lane_part = d_beam_part + (uint64_t)j * (tot_reads + 16);
+                // ---- beam search -----------------------------------------------------------------------------------------
+                if (!q.shortcut) {
+                    const uint32_t slots = std::min(q.beam_slots, nj);
+                    fl::BeamArgs a{};
+                    a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
+                    a.queue_head = gqueue; a.blk_done = d_done;
+                    a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane);
+                    a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
+                    a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
+                    a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
+                    a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
+                    a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
+                    a.prof = (unsigned long long*)(d_diag + 4);
+                    HIPCHK(hipMemsetAsync(gqueue, 0, 4, st));
+                    auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
+                        return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
+                    };
+                    int t = T.begin(K_BEAM, st);
+                    if (q.wide) {
+                        if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
+                        else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(slots), dim3(64), q.WL.total, st, a); }
+                    } else if (q.slab) {
+                        if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                        else if (q.beam_spec && p == 2) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
+                        else if (q.beam_spec && p == 3) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
+                        else if (q.beam_spec && p == 4) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
+                        else if (q.beam_spec && p == 5) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
+                        else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), q.SL.total, st, a);
+                    } else if (q.fast) {
+                        const fl::FastLds FL = fl::fast_lds_layout(q.LM, any_q0);
+                        if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, st, a);
+                        else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, st, a);
+                    } else {
+                        HIPCHK(big_lds((const void*)fl::beam_kernel<A>, q.LY.total));
+                        hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), q.LY.total, st, a);
+                    }
+                    T.end(t);
+                    HIPCHK(hipGetLastError());
+                    ctx->timing.beam_launches++;
+                }
+                // ---- optimise + MEC stats ------------------------------------------------------------------------------
+                {
+                    const uint32_t slots = std::min(q.opt_slots, nj);
+                    const uint32_t threads = q.threads;
+                    const size_t lds = q.opt_lds;
+                    fl::OptArgs a{};
+                    a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.max_ploidy = P; a.span_max = span_max; a.n_max = n_max;
+                    a.queue_head = gqueue + 1; a.blk_done = d_done; a.eps = prm->epsilon;
+                    a.part_in = lane_part; a.part_out = d_planes + (uint64_t)(p - 1) * tot_reads;
+                    a.hist_pool = (uint64_t*)(ctx->opt_hist.as<char>() + sl_ohist * lane); a.dist_pool = (double*)(ctx->opt_dist.as<char>() + sl_odist * lane);
+                    a.cand_gain_pool = (uint64_t*)(ctx->opt_gain.as<char>() + sl_ogain * lane); a.cand_key_pool = (uint32_t*)(ctx->opt_key.as<char>() + sl_okey * lane);
+                    a.moves_pool = (uint32_t*)(ctx->opt_moves.as<char>() + sl_omoves * lane); a.cand_cap = q.cand_cap;
+                    a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
+                    a.prof = (unsigned long long*)(d_diag + 4);
+                    HIPCHK(hipMemsetAsync(gqueue + 1, 0, 4, st));
+                    int t = T.begin(K_OPT, st);
+                    auto launch = [&](auto kern) -> hipError_t {
+                        if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
+                        hipLaunchKernelGGL(kern, dim3(slots), dim3(threads), lds, st, a);
+                        return hipGetLastError();
+                    };
+                    hipError_t le;
+                    if (q.opt_spec && threads == 1024)
+                        le = p == 1 ? launch(fl::optimize_kernel<2, true, 1024, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 1024, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 1024, 3>)
+                           : p == 4 ? launch(fl::optimize_kernel<2, true, 1024, 4>) : launch(fl::optimize_kernel<2, true, 1024, 5>);
+                    else if (q.opt_spec)
+                        le = p == 1 ? launch(fl::optimize_kernel<2, true, 512, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 512, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 512, 3>)
+                           : p == 4 ? launch(fl::optimize_kernel<2, true, 512, 4>) : launch(fl::optimize_kernel<2, true, 512, 5>);
+                    else if (q.hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512>) : launch(fl::optimize_kernel<A, true, 128>);
+                    else    le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512>) : launch(fl::optimize_kernel<A, false, 128>);
+                    T.end(t);
+                    if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));
+                    ctx->timing.optimize_launches++;
+                }
             }
-            // ---- stop rule ---------------------------------------------------------------------------------------------
-            {
+            // join the stage's extra lanes, then the stop rule for the stage's ploidies in ascending order (graph_processing.rs:198-251)
+            for (uint32_t j = 1; j < stage.size(); ++j) { HIPCHK(hipEventRecord(ctx->ev_join[g * W + j], ls[g * W + j])); HIPCHK(hipStreamWaitEvent(s0, ctx->ev_join[g * W + j], 0)); }
+            for (uint32_t j = 0; j < stage.size(); ++j) {
+                const uint32_t p = stage[j];
                 fl::SelectArgs s{};
                 s.job_block = gjobs; s.n_jobs = nj; s.ploidy = p; s.max_ploidy = P; s.stopping_heuristic = prm->stopping_heuristic; s.eps = prm->epsilon;
                 const double eps = prm->epsilon, pl = (double)p;    // graph_processing.rs:204-220
                 if (prm->ploidy_sensitivity == 1)      s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 0.50) + 1.00));
                 else if (prm->ploidy_sensitivity == 2) s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1. / 3.));
                 else                                   s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1.00));
-                s.mec = d_mec; s.num_alleles = d_na; s.blk_done = d_done; s.best_ploidy = d_best; s.tried = d_tried;
-                int t = T.begin(K_SEL, st);
-                hipLaunchKernelGGL(fl::select_kernel, dim3((nj + 255) / 256), dim3(256), 0, st, s);
+                s.mec = d_mec; s.num_alleles = d_na; s.iters = d_iters; s.blk_done = d_done; s.best_ploidy = d_best; s.tried = d_tried;
+                s.clear_from = (j + 1 == stage.size() && stage.size() > 1) ? 1 : 0;      // last select of a speculative stage: forget the ploidies beyond `tried`
+                s.stage_last = stage.back();
+                int t = T.begin(K_SEL, s0);
+                hipLaunchKernelGGL(fl::select_kernel, dim3((nj + 255) / 256), dim3(256), 0, s0, s);
                 T.end(t);
                 HIPCHK(hipGetLastError());
             }
         }
     }
     // join: the main stream continues after every group
-    if (G > 1 && forked) {
-        for (uint32_t g = 1; g < G; ++g) { HIPCHK(hipEventRecord(ctx->ev_join[g], gs[g])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g], 0)); }
-    }
+    for (uint32_t g = 1; g < G; ++g) { HIPCHK(hipEventRecord(ctx->ev_join[g * W], ls[g * W])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g * W], 0)); }
     T.end(t_phase);
     ctx->timing.streams = G;
+    ctx->timing.stage_width = W;
     return 0;
 }
 
@@ -513,6 +606,19 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(fl::c_rk2), c->Rk2, sizeof(c->Rk2));
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(FLORIA_E_DEVICE, std::string("hash multiplier upload: ") + hipGetErrorString(e)); }
     if (int rc = ensure_hash(c, 4 * fl::HASH_M)) { (void)hipStreamDestroy(c->stream); delete c; return rc; }
+    if (c->d_w24.ensure(sizeof(w24)) || hipMemcpy(c->d_w24.p, w24, sizeof(w24), hipMemcpyHostToDevice) != hipSuccess) { floria_hip_destroy(c); return fail(FLORIA_E_DEVICE, "weight table upload failed"); }
+    {   // development knobs: environment defaults, read once (floria_hip_set_option overrides them)
+        Knobs& K = c->knobs;
+        if (const char* v = getenv("FLORIA_HIP_GROUPS")) K.groups = (uint32_t)std::max(0, std::min<int>(atoi(v), floria_hip_ctx::MAX_GROUPS));
+        if (const char* v = getenv("FLORIA_HIP_BEAM")) K.beam_path = !strcmp(v, "generic") ? 1 : !strcmp(v, "fast") ? 2 : !strcmp(v, "slab") ? 3 : !strcmp(v, "wide") ? 4 : 0;
+        K.no_specialized = getenv("FLORIA_HIP_NO_SPECIALIZED") != nullptr;
+        K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
+        if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
+        K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
+        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(2, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
+        else c->stage_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    }
     *out = c;
     return 0;
 }
@@ -520,13 +626,15 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
 void floria_hip_destroy(floria_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0, &c->graph_buf, &c->graph_hist, &c->graph_sort}) b->release();
-    for (uint32_t g = 0; g < floria_hip_ctx::MAX_GROUPS; ++g) {
+    sync_all(c);
+    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->d_w24, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0, &c->graph_buf, &c->graph_hist, &c->graph_sort, &c->up_tmp}) b->release();
+    for (Arena* a : c->arena_cache) { a->buf.release(); delete a; }
+    c->stage.release();
+    for (uint32_t g = 0; g < floria_hip_ctx::MAX_LANES; ++g) {
         if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
+        if (c->ev_fork[g]) (void)hipEventDestroy(c->ev_fork[g]);
     }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_rids) (void)hipEventDestroy(c->ev_rids);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
@@ -536,6 +644,23 @@ void floria_hip_destroy(floria_hip_ctx* c) {
 int floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots) {
     if (!ctx) return fail(FLORIA_E_INVALID, "null ctx");
     ctx->user_slots = beam_slots;
+    return 0;
+}
+
+int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return fail(FLORIA_E_INVALID, "null argument");
+    const std::string k(key);
+    Knobs& K = ctx->knobs;
+    if (k == "groups") K.groups = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
+    else if (k == "beam_path") { if (value < 0 || value > 4) return fail(FLORIA_E_INVALID, "beam_path: 0 auto | 1 generic | 2 fast | 3 slab | 4 wide"); K.beam_path = (uint32_t)value; }
+    else if (k == "no_specialized") K.no_specialized = value != 0;
+    else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
+    else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
+    else if (k == "opt_global") K.opt_global = value != 0;
+    else if (k == "speculate") { if (value < -1 || value > 2) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2"); K.speculate = (int32_t)value; }
+    else if (k == "slots") ctx->user_slots = (uint32_t)std::max<int64_t>(0, value);
+    else if (k == "stage_threads") ctx->stage_threads = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
+    else return fail(FLORIA_E_INVALID, "unknown option '" + k + "'");
     return 0;
 }
 
@@ -582,62 +707,296 @@ int floria_hip_block_ranges(const uint64_t* g, uint32_t n, uint64_t block_length
 void floria_hip_ranges_free(floria_ranges* r) { if (r) { free(r->start); free(r->end); free(r); } }
 
 // ---- contig upload ------------------------------------------------------------------------------------------
-int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria_hip_contig** out) {
-    if (!ctx || !out) return fail(FLORIA_E_INVALID, "null argument");
-    *out = nullptr;
-    uint32_t ml = 0, ma = 0;
-    int rc = validate_pileup(p, &ml, &ma);
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(ctx->device));
-    floria_hip_contig* c = new floria_hip_contig();
-    c->ctx = ctx; c->n_reads = p->n_reads; c->max_len = ml; c->n_alleles = ma >= 2 ? 4 : 2;
-    const uint64_t nc = p->n_reads ? p->read_off[p->n_reads] : 0;
-    c->n_cells = nc;
-    c->h_first.assign(p->first, p->first + p->n_reads);
-    c->h_last.assign(p->last, p->last + p->n_reads);
-    c->h_read_off.assign(p->read_off, p->read_off + p->n_reads + (p->n_reads ? 1 : 0));
-    std::vector<uint32_t> aq(nc);     // allele << 28 | Q24 weight of the cell (weights are < 2^24)
-    std::vector<uint64_t> tw((size_t)p->n_reads * 2, 0);
-    std::vector<uint32_t> meta((size_t)p->n_reads * 8, 0);
-    for (uint32_t r = 0; r < p->n_reads; ++r) {
-        uint64_t t1 = 0, t2 = 0;
-        for (uint64_t i = p->read_off[r]; i < p->read_off[r + 1]; ++i) {
-            aq[i] = ((uint32_t)p->allele[i] << 28) | ctx->w24[p->qual[i]];
-            if (p->qual[i] == 0) c->has_q0 = true;
-            const uint32_t idx = fl::hash_idx(p->snp[i], p->allele[i]);
-            const uint64_t w = ctx->w24[p->qual[i]];
-            t1 += ctx->h_rq1[idx] * w; t2 += ctx->h_rq2[idx] * w;
+// Pinned host memory for hosts that marshal their `Vec<Frag>` straight into upload buffers: arrays that live here go to the
+// device by DMA with no staging copy.
+void* floria_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(FLORIA_E_NOMEM, "hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+void floria_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+}  // extern "C"
+
+namespace {
+
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// One host->device transfer plan entry: `bytes` from `src` to `dst` (contiguous on both sides).
+struct CopyRun { const char* src; char* dst; size_t bytes; };
+
+int issue_copies(floria_hip_ctx* ctx, std::vector<CopyRun>& runs, uint64_t* pinned_bytes, uint64_t* staged_bytes);
+
+Arena* arena_get(floria_hip_ctx* ctx, size_t bytes);
+void arena_put(Arena* a);
+
+int host_meta(const floria_hip_contig* cc) {
+    floria_hip_contig* c = const_cast<floria_hip_contig*>(cc);
+    Arena* a = c->arena;
+    if (!a->host_meta) {
+        a->h_first.resize(a->R + 1); a->h_last.resize(a->R + 1);
+        if (a->R) {
+            HIPCHK(hipMemcpy(a->h_first.data(), a->buf.as<char>() + a->off_first, 4 * a->R, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(a->h_last.data(), a->buf.as<char>() + a->off_last, 4 * a->R, hipMemcpyDeviceToHost));
         }
-        tw[2 * (size_t)r] = t1; tw[2 * (size_t)r + 1] = t2;
-        uint32_t* mr = &meta[8 * (size_t)r];
-        mr[0] = p->read_off[r]; mr[1] = p->read_off[r + 1] - p->read_off[r]; mr[2] = p->first[r]; mr[3] = p->last[r];
-        mr[4] = (uint32_t)t1; mr[5] = (uint32_t)(t1 >> 32); mr[6] = (uint32_t)t2; mr[7] = (uint32_t)(t2 >> 32);
+        a->host_meta = true;
     }
-    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
-        int r2 = b.ensure(bytes + 16);            // 16-B tail padding: the beam kernel's LDS-DMA moves cells in 16-B pieces
-        if (r2) return r2;
-        if (bytes) { hipError_t e = hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return fail(FLORIA_E_DEVICE, hipGetErrorString(e)); }
-        return 0;
-    };
-    rc = up(c->d_read_off, p->read_off, (size_t)(p->n_reads + 1) * 4 * (p->n_reads ? 1 : 0));
-    if (!rc) rc = up(c->d_first, p->first, (size_t)p->n_reads * 4);
-    if (!rc) rc = up(c->d_last, p->last, (size_t)p->n_reads * 4);
-    if (!rc) rc = up(c->d_snp, p->snp, nc * 4);
-    if (!rc) rc = up(c->d_aq, aq.data(), nc * 4);
-    if (!rc) rc = up(c->d_tw, tw.data(), tw.size() * 8);
-    if (!rc) rc = up(c->d_meta, meta.data(), meta.size() * 4);
-    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(FLORIA_E_DEVICE, "upload sync failed");
-    if (rc) { floria_hip_contig_free(c); return rc; }
-    c->dev.read_off = c->d_read_off.as<uint32_t>(); c->dev.first = c->d_first.as<uint32_t>(); c->dev.last = c->d_last.as<uint32_t>();
-    c->dev.cell_snp = c->d_snp.as<uint32_t>(); c->dev.cell_aw = c->d_aq.as<uint32_t>(); c->dev.tw = c->d_tw.as<uint64_t>(); c->dev.meta = c->d_meta.as<uint32_t>(); c->dev.n_reads = p->n_reads;
-    *out = c;
+    c->h_first = a->h_first.data() + a->read_prefix[c->idx];
+    c->h_last = a->h_last.data() + a->read_prefix[c->idx];
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Upload a batch of contigs: plan the arena, DMA the raw arrays (consecutive contigs whose arrays are back to back in host
+// memory travel as one transfer), validate + flatten on the device (upload_kernel.h), read back the per-contig status.
+int floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, floria_hip_contig** out) {
+    if (!ctx || !out || (n && !pileups)) return fail(FLORIA_E_INVALID, "null argument");
+    for (uint32_t i = 0; i < n; ++i) out[i] = nullptr;
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> rp(n + 1, 0), cp(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const floria_pileup* p = &pileups[i];
+        if (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last)) return fail(FLORIA_E_INVALID, "null pileup field");
+        const uint64_t nc = p->n_reads ? p->read_off[p->n_reads] : 0;
+        rp[i + 1] = rp[i] + p->n_reads; cp[i + 1] = cp[i] + nc;
+    }
+    const uint64_t R = rp[n], C = cp[n];
+    // ---- arena layout -------------------------------------------------------------------------------------------------------
+    size_t cursor = 0;
+    auto seg = [&](size_t bytes) { const size_t o = cursor; cursor += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_ro = seg(4 * (R + n)), o_first = seg(4 * R), o_last = seg(4 * R), o_snp = seg(4 * C + 16), o_aw = seg(4 * C + 16),      // 16-B tails: the
+                 o_tw = seg(16 * R), o_meta = seg(32 * R);                                              // beam kernel's LDS-DMA moves cells in 16-B pieces
+    Arena* A = arena_get(ctx, cursor + 256);
+    if (!A) return FLORIA_E_NOMEM;
+    A->n_contigs = n; A->R = R; A->C = C; A->off_ro = o_ro; A->off_first = o_first; A->off_last = o_last; A->read_prefix = rp; A->host_meta = false;
+    char* D = A->buf.as<char>();
+    // transient: raw allele / qual bytes, the kernel's contig table, prefix and status
+    size_t c2 = 0;
+    auto seg2 = [&](size_t bytes) { const size_t o = c2; c2 += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t t_al = seg2(C + 16), t_q = seg2(C + 16), t_cd = seg2(sizeof(fl::UploadContig) * n), t_rp = seg2(8 * (n + 1)), t_st = seg2(sizeof(fl::UploadStatus) * n);
+    int rc = ctx->up_tmp.ensure(c2 + 256);
+    if (rc) { arena_put(A); return rc; }
+    char* T = ctx->up_tmp.as<char>();
+    std::vector<fl::UploadContig> ucd(n);
+    std::vector<fl::UploadStatus> ust(n);
+    std::vector<CopyRun> runs;
+    auto add_run = [&](const void* src, char* dst, size_t bytes) {
+        if (!bytes) return;
+        if (!runs.empty() && runs.back().src + runs.back().bytes == (const char*)src && runs.back().dst + runs.back().bytes == dst) runs.back().bytes += bytes;
+        else runs.push_back({(const char*)src, dst, bytes});
+    };
+    for (int kind = 0; kind < 6; ++kind)
+        for (uint32_t i = 0; i < n; ++i) {
+            const floria_pileup* p = &pileups[i];
+            if (!p->n_reads) continue;
+            const uint64_t nr = p->n_reads, nc = cp[i + 1] - cp[i];
+            switch (kind) {
+                case 0: add_run(p->read_off, D + o_ro + 4 * (rp[i] + i), 4 * (nr + 1)); break;
+                case 1: add_run(p->first, D + o_first + 4 * rp[i], 4 * nr); break;
+                case 2: add_run(p->last, D + o_last + 4 * rp[i], 4 * nr); break;
+                case 3: add_run(p->snp, D + o_snp + 4 * cp[i], 4 * nc); break;
+                case 4: add_run(p->allele, T + t_al + cp[i], nc); break;
+                default: add_run(p->qual, T + t_q + cp[i], nc); break;
+            }
+        }
+    for (uint32_t i = 0; i < n; ++i) {
+        fl::UploadContig& u = ucd[i];
+        u.read_off = (const uint32_t*)(D + o_ro + 4 * (rp[i] + i)); u.first = (const uint32_t*)(D + o_first + 4 * rp[i]); u.last = (const uint32_t*)(D + o_last + 4 * rp[i]);
+        u.snp = (const uint32_t*)(D + o_snp + 4 * cp[i]); u.allele = (const uint8_t*)(T + t_al + cp[i]); u.qual = (const uint8_t*)(T + t_q + cp[i]);
+        u.cell_aw = (uint32_t*)(D + o_aw + 4 * cp[i]); u.tw = (uint64_t*)(D + o_tw + 16 * rp[i]); u.meta = (uint32_t*)(D + o_meta + 32 * rp[i]);
+        u.n_reads = pileups[i].n_reads; u.n_cells = (uint32_t)(cp[i + 1] - cp[i]);
+        if (cp[i + 1] - cp[i] >= (1ull << 32)) { arena_put(A); return fail(FLORIA_E_UNSUPPORTED, "more than 2^32 cells in one contig"); }
+        ust[i] = fl::UploadStatus{~0ull, 0, 0, 0, 0};
+    }
+    EventTimer Tm(ctx->stream);
+    const int th = Tm.begin(K_H2D);
+    uint64_t pinned_b = 0, staged_b = 0;
+    rc = issue_copies(ctx, runs, &pinned_b, &staged_b);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(T + t_cd, ucd.data(), sizeof(fl::UploadContig) * n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(T + t_rp, rp.data(), 8 * (n + 1), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(T + t_st, ust.data(), sizeof(fl::UploadStatus) * n, hipMemcpyHostToDevice, ctx->stream);
+    }
+    Tm.end(th);
+    int tk = -1;
+    if (!rc && e == hipSuccess && R) {
+        fl::UploadArgs a{};
+        a.contigs = (const fl::UploadContig*)(T + t_cd); a.read_prefix = (const uint64_t*)(T + t_rp); a.status = (fl::UploadStatus*)(T + t_st);
+        a.w24 = ctx->d_w24.as<uint32_t>(); a.Rq1 = ctx->d_hash.as<uint64_t>(); a.Rq2 = ctx->d_hash.as<uint64_t>() + 2ull * ctx->hash_len;
+        a.n_contigs = n; a.n_reads_total = R;
+        tk = Tm.begin(K_SEL);
+        hipLaunchKernelGGL(fl::flatten_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, ctx->stream, a);
+        Tm.end(tk);
+        e = hipGetLastError();
+    }
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(ust.data(), T + t_st, sizeof(fl::UploadStatus) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (!rc && e != hipSuccess) rc = fail(FLORIA_E_DEVICE, std::string("contig upload: ") + hipGetErrorString(e));
+    if (!rc)
+        for (uint32_t i = 0; i < n && !rc; ++i) if (ust[i].err != ~0ull) {
+            const std::string r = std::to_string((unsigned long long)(ust[i].err >> 8)), ci = n > 1 ? " (contig " + std::to_string(i) + " of the batch)" : std::string();
+            switch ((uint32_t)(ust[i].err & 0xff)) {
+                case fl::UP_NO_CELLS:      rc = fail(FLORIA_E_INVALID, "read " + r + " has no cells (or read_off is not monotone)" + ci); break;
+                case fl::UP_FIRST_LAST:    rc = fail(FLORIA_E_INVALID, "first/last of read " + r + " do not match its cells" + ci); break;
+                case fl::UP_ONE_BASED:     rc = fail(FLORIA_E_INVALID, "SNP positions are 1-based" + ci); break;
+                case fl::UP_NOT_ASCENDING: rc = fail(FLORIA_E_INVALID, "cells of read " + r + " not strictly ascending" + ci); break;
+                case fl::UP_ALLELE:        rc = fail(FLORIA_E_UNSUPPORTED, "allele index > 3 (read " + r + ")" + ci); break;
+                default:                   rc = fail(FLORIA_E_INVALID, "reads not sorted by Frag::cmp at read " + r + ci); break;
+            }
+        }
+    if (rc) { arena_put(A); return rc; }
+    ctx->timing = floria_timing{};
+    ctx->timing.h2d_ms = Tm.sum(K_H2D); ctx->timing.select_ms = Tm.sum(K_SEL); ctx->timing.total_ms = Tm.span();
+    ctx->timing.upload_pinned_bytes = pinned_b; ctx->timing.upload_staged_bytes = staged_b;
+    for (uint32_t i = 0; i < n; ++i) {
+        floria_hip_contig* c = new floria_hip_contig();
+        c->ctx = ctx; c->arena = A; c->idx = i; c->n_reads = pileups[i].n_reads; c->n_cells = cp[i + 1] - cp[i];
+        c->max_len = ust[i].max_len; c->n_alleles = ust[i].max_allele >= 2 ? 4 : 2; c->has_q0 = ust[i].has_q0 != 0;
+        c->dev.read_off = ucd[i].read_off; c->dev.first = ucd[i].first; c->dev.last = ucd[i].last; c->dev.cell_snp = ucd[i].snp;
+        c->dev.cell_aw = ucd[i].cell_aw; c->dev.tw = ucd[i].tw; c->dev.meta = ucd[i].meta; c->dev.n_reads = pileups[i].n_reads;
+        out[i] = c;
+    }
+    A->refs = n;
+    return 0;
+}
+
+int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria_hip_contig** out) {
+    if (!ctx || !out || !p) return fail(FLORIA_E_INVALID, p ? "null argument" : "null pileup");
+    return floria_hip_contig_upload_batch(ctx, p, 1, out);
 }
 void floria_hip_contig_free(floria_hip_contig* c) {
     if (!c) return;
-    for (DevBuf* b : {&c->d_read_off, &c->d_first, &c->d_last, &c->d_snp, &c->d_aq, &c->d_tw, &c->d_meta}) b->release();
+    if (c->arena && --c->arena->refs == 0) arena_put(c->arena);
     delete c;
 }
+
+// Diagnostic: copy one resident array of a contig back to the host (tests compare the device-side flatten with the formulas).
+int floria_hip_contig_download(const floria_hip_contig* c, int field, void* dst, size_t bytes) {
+    if (!c || (!dst && bytes)) return fail(FLORIA_E_INVALID, "null argument");
+    const void* src = nullptr;
+    size_t have = 0;
+    switch (field) {
+        case FLORIA_FIELD_READ_OFF: src = c->dev.read_off; have = 4ull * (c->n_reads + (c->n_reads ? 1 : 0)); break;
+        case FLORIA_FIELD_FIRST:    src = c->dev.first;    have = 4ull * c->n_reads; break;
+        case FLORIA_FIELD_LAST:     src = c->dev.last;     have = 4ull * c->n_reads; break;
+        case FLORIA_FIELD_SNP:      src = c->dev.cell_snp; have = 4ull * c->n_cells; break;
+        case FLORIA_FIELD_CELL_AW:  src = c->dev.cell_aw;  have = 4ull * c->n_cells; break;
+        case FLORIA_FIELD_TW:       src = c->dev.tw;       have = 16ull * c->n_reads; break;
+        case FLORIA_FIELD_META:     src = c->dev.meta;     have = 32ull * c->n_reads; break;
+        default: return fail(FLORIA_E_INVALID, "unknown field");
+    }
+    if (bytes > have) return fail(FLORIA_E_INVALID, "field is smaller than the requested size");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+Arena* arena_get(floria_hip_ctx* ctx, size_t bytes) {
+    Arena* a = nullptr;
+    // best fit among the cached arenas, else grow the largest, else a new one
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->arena_cache.size(); ++i) if (ctx->arena_cache[i]->buf.cap >= bytes && (best == (size_t)-1 || ctx->arena_cache[i]->buf.cap < ctx->arena_cache[best]->buf.cap)) best = i;
+    if (best == (size_t)-1 && !ctx->arena_cache.empty()) { best = 0; for (size_t i = 1; i < ctx->arena_cache.size(); ++i) if (ctx->arena_cache[i]->buf.cap > ctx->arena_cache[best]->buf.cap) best = i; }
+    if (best != (size_t)-1) { a = ctx->arena_cache[best]; ctx->arena_cache.erase(ctx->arena_cache.begin() + best); }
+    else { a = new Arena(); a->ctx = ctx; }
+    if (a->buf.ensure(bytes)) { a->buf.release(); delete a; return nullptr; }
+    a->refs = 0; a->host_meta = false;
+    return a;
+}
+void arena_put(Arena* a) {
+    floria_hip_ctx* ctx = a->ctx;
+    a->h_first.clear(); a->h_last.clear(); a->host_meta = false; a->refs = 0;
+    if (ctx->arena_cache.size() < 4) ctx->arena_cache.push_back(a);
+    else { a->buf.release(); delete a; }
+}
+
+int issue_copies(floria_hip_ctx* ctx, std::vector<CopyRun>& runs, uint64_t* pinned_bytes, uint64_t* staged_bytes) {
+    std::vector<CopyRun> staged;          // pageable runs, cut into SEG pieces
+    for (const CopyRun& r : runs) {
+        const bool pin = r.bytes >= 4096 && is_pinned(r.src) && is_pinned(r.src + r.bytes - 1);
+        if (pin) {
+            *pinned_bytes += r.bytes;
+            HIPCHK(hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            *staged_bytes += r.bytes;
+            for (size_t o = 0; o < r.bytes; o += StagePool::SEG) staged.push_back({r.src + o, r.dst + o, std::min(StagePool::SEG, r.bytes - o)});
+        }
+    }
+    if (staged.empty()) return 0;
+    size_t tot = 0;
+    for (auto& r : staged) tot += r.bytes;
+    if (tot < (1u << 20)) {                  // small: let the runtime stage it
+        for (auto& r : staged) HIPCHK(hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    if (int rc = ctx->stage.init()) return rc;
+    StagePool& SP = ctx->stage;
+    if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->ev_rids) HIPCHK(hipEventCreateWithFlags(&ctx->ev_rids, hipEventDisableTiming));
+    // Worker threads only memcpy (pageable source -> pinned segment); THIS thread makes every HIP call: it issues the DMA of
+    // segment k as soon as it is filled — alternating between two streams, so the completion latency of one copy hides behind
+    // the next — and hands a staging buffer back to the fillers once the DMA that read it has completed.
+    const uint32_t nseg = (uint32_t)staged.size();
+    const uint32_t nthreads = std::max(1u, std::min<uint32_t>({ctx->stage_threads, nseg, 16u}));
+    std::vector<std::atomic<int>> filled(nseg);
+    for (auto& f : filled) f.store(0);
+    std::atomic<uint32_t> next{0}, freed{StagePool::NBUF};     // segments < freed may be filled (their buffer is free)
+    std::atomic<int> failed{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= nseg) return;
+            while (freed.load(std::memory_order_acquire) <= k) { if (failed.load()) return; std::this_thread::yield(); }
+            memcpy(SP.buf[k % StagePool::NBUF], staged[k].src, staged[k].bytes);
+            filled[k].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(worker);
+    hipStream_t cs[2] = {ctx->stream, ctx->copy_stream};
+    hipError_t e = hipEventRecord(ctx->ev_rids, ctx->stream);                       // the second stream starts after what the first has queued
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rids, 0);
+    uint32_t done = 0;                                                              // DMAs known complete
+    for (uint32_t k = 0; k < nseg && e == hipSuccess; ++k) {
+        while (!filled[k].load(std::memory_order_acquire)) {
+            // while waiting for the fillers, retire completed DMAs so that their buffers can be refilled
+            if (done < k && hipEventQuery(SP.ev[done % StagePool::NBUF]) == hipSuccess) { ++done; freed.store(done + StagePool::NBUF, std::memory_order_release); }
+            else std::this_thread::yield();
+        }
+        e = hipMemcpyAsync(staged[k].dst, SP.buf[k % StagePool::NBUF], staged[k].bytes, hipMemcpyHostToDevice, cs[k & 1]);
+        if (e == hipSuccess) e = hipEventRecord(SP.ev[k % StagePool::NBUF], cs[k & 1]);
+        // the fillers may be blocked on a buffer whose DMA is still running: wait for the oldest one when the ring is exhausted
+        while (e == hipSuccess && done + StagePool::NBUF <= k + 1 && k + 1 < nseg && freed.load() <= k + 1) {
+            e = hipEventSynchronize(SP.ev[done % StagePool::NBUF]);
+            ++done; freed.store(done + StagePool::NBUF, std::memory_order_release);
+        }
+    }
+    if (e != hipSuccess) failed.store(1);
+    freed.store(0xffffffffu);
+    for (auto& t : th) t.join();
+    (void)hipGetLastError();                                                        // hipEventQuery's hipErrorNotReady is not an error
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_rids, ctx->copy_stream);        // the main stream continues after both
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_rids, 0);
+    if (e != hipSuccess) { sync_all(ctx); return fail(FLORIA_E_DEVICE, std::string("staged upload failed: ") + hipGetErrorString(e)); }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
 
 // ---- S1 --------------------------------------------------------------------------------------------------------
 int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
@@ -716,9 +1075,22 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     for (uint32_t b = 0; b < n_blocks; ++b) if (cnt[b]) jobs.push_back(b);
     std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return cnt[a] > cnt[b2]; });
     // job groups (longest-first inside each group, dealt round-robin so every group sees the same size mix)
-    uint32_t G = ctx->user_groups ? ctx->user_groups : 2;
-    if (const char* ge = getenv("FLORIA_HIP_GROUPS")) G = (uint32_t)std::max(1, atoi(ge));
+    uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : 2;
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
+    // ploidy stages (run_phase): one ploidy per stage unless the batch is too small to fill the chip with (block, ploidy) jobs
+    std::vector<std::vector<uint32_t>> stages;
+    {
+        int spec = ctx->knobs.speculate;
+        const bool slab_path = P * prm->beam <= 63 && !ctx->knobs.beam_path;          // the wide-beam kernels own whole CUs: nothing to gain there
+        if (spec < 0) spec = (slab_path && G == 1 && P >= 3 && jobs.size() * 3 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
+        if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
+        if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
+        else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
+                              if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
+        else for (uint32_t p = 1; p <= P; ++p) stages.push_back({p});
+    }
+    uint32_t stage_w = 1;
+    for (auto& st : stages) stage_w = std::max<uint32_t>(stage_w, (uint32_t)st.size());
     std::vector<uint32_t> group_off(G + 1, 0);
     if (G > 1) {
         std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
@@ -732,9 +1104,9 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
 
     // ---- device staging of the per-call arrays ----------------------------------------------------------------------
     cursor = 0;
-    const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg(tot + 16),
+    const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg((uint64_t)stage_w * (tot + 16)),
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
-              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(8 * floria_hip_ctx::MAX_GROUPS + 16), s_margin = seg(16),
+              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(8 * floria_hip_ctx::MAX_LANES + 16), s_margin = seg(8ull * n_blocks * P + 16),
               s_diag = seg(16 + 8 * 32), s_steps = seg(16);
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
     char* M = ctx->misc.as<char>();
@@ -751,7 +1123,6 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     HIPCHK(hipMemsetAsync(M + s_diag.off, 0, 16 + 8 * 32, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_steps.off, 0, 16, ctx->stream));
     const double inf = std::numeric_limits<double>::infinity();
-    HIPCHK(hipMemcpyAsync(M + s_margin.off, &inf, 8, hipMemcpyHostToDevice, ctx->stream));
     T.end(th);
     if (n_blocks) {
         sa.roff = (const uint64_t*)(M0 + s_roff.off); sa.rids = (uint32_t*)(M + s_rids.off);
@@ -785,9 +1156,9 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     bool p1_shortcut = false;
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
     rc = run(ctx, any_q0, bs, jobs, group_off, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
-             (uint8_t*)(M + s_bpart.off), (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
+             (uint8_t*)(M + s_bpart.off), stages, (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
-             (unsigned long long*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
+             (double*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
     if (rc) { sync_all(ctx); return rc; }
     int t_rids = -1;
     if (n_blocks && tot) {              // everything is queued: the copy (pageable destination, the host may block here) overlaps the kernels
@@ -818,7 +1189,8 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     }
     if (e == hipSuccess) e = hipMemcpyAsync(diag, M + s_diag.off, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&steps, M + s_steps.off, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&margin, M + s_margin.off, 8, hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<double> job_margin((size_t)n_blocks * P + 1, inf);
+    if (e == hipSuccess && n_blocks) e = hipMemcpyAsync(job_margin.data(), M + s_margin.off, 8ull * n_blocks * P, hipMemcpyDeviceToHost, ctx->stream);
     T.end(td);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
@@ -828,14 +1200,21 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     { unsigned long long prof[32]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
 #endif
     memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
+    // the pruning decisions of the (block, ploidy) jobs the reference runs, i.e. ploidy <= ploidies_tried (a speculative stage may have run more)
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        for (uint32_t p = (p1_shortcut ? 2 : 1); p <= R->ploidies_tried[b]; ++p) margin = std::min(margin, job_margin[(size_t)b * P + p - 1]);
     if (p1_shortcut && !jobs.empty()) margin = std::min(margin, std::fabs(0.0 - std::log(PROB_CUTOFF)));   // the ploidy-1 decisions: p_k - lse == 0
     R->min_prune_margin = margin;
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
     ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span(); ctx->timing.phase_ms = T.sum(K_PHASE);
     ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
-    for (uint32_t b = 0; b < n_blocks; ++b) {          // a beam launch for ploidy p phases the blocks with tried >= p (ploidy 1 needs no launch)
-        const uint32_t launches_b = R->ploidies_tried[b] - ((p1_shortcut && R->ploidies_tried[b]) ? 1 : 0);
-        ctx->timing.beam_launch_bytes += blk_bytes[b] * launches_b; ctx->timing.jobs += R->ploidies_tried[b];
+    std::vector<uint32_t> stage_first(P + 2, 0);       // first ploidy of the stage that holds ploidy p
+    for (auto& st : stages) for (uint32_t p : st) stage_first[p] = st.front();
+    for (uint32_t b = 0; b < n_blocks; ++b) {          // a beam launch for ploidy p phases the blocks still active when p's stage starts (ploidy 1 needs no launch)
+        const uint32_t tb = R->ploidies_tried[b];
+        uint32_t launches_b = 0;
+        for (uint32_t p = 1; p <= P && tb; ++p) if (tb >= stage_first[p] && !(p == 1 && p1_shortcut)) launches_b++;
+        ctx->timing.beam_launch_bytes += blk_bytes[b] * launches_b; ctx->timing.jobs += tb;
     }
     ctx->batch_token = R->batch_token = ++ctx->token_counter;
     ctx->last_bs = bs; ctx->last_part = (const uint8_t*)(M + s_out.off); ctx->last_best = (const uint32_t*)(M + s_best.off); ctx->last_nall = nall;
@@ -1004,6 +1383,7 @@ int floria_hip_hapq_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* c
     for (uint32_t c = 0; c < n_contigs; ++c) {
         if (!contigs[c] || contigs[c]->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
         avg_err[c] = std::numeric_limits<double>::quiet_NaN();                   // 0. / 0. for a contig without haplosets (:540)
+        if (int rc0 = host_meta(contigs[c])) return rc0;
     }
     if (n_groups == 0) return 0;
     // (1) get_errors_cov_from_frags per haploset (:529-539)
@@ -1153,6 +1533,7 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
     for (uint32_t i = 0; i < n_contigs; ++i) {
         if (!contigs[i] || contigs[i]->ctx != ctx) return fail(FLORIA_E_INVALID, "bad contig handle");
         A = std::max(A, contigs[i]->n_alleles);
+        if (int rc0 = host_meta(contigs[i])) return rc0;
     }
     // groups of each contig, in input order (contig-local group id = rank among the contig's groups)
     std::vector<std::vector<uint32_t>> cg(n_contigs);

@@ -413,30 +413,39 @@ struct SelectArgs {
     uint32_t n_jobs, ploidy, max_ploidy;
     int32_t  stopping_heuristic;
     double   eps, mec_threshold;     // threshold for THIS ploidy, computed on the host with libm pow (:204-220)
-    const double* mec;
-    const double* num_alleles;
+    double* mec;
+    double* num_alleles;
+    uint32_t* iters;
     uint8_t*  blk_done;
     uint32_t* best_ploidy;
     uint32_t* tried;
+    uint32_t clear_from, stage_last; // last select of a speculative stage: forget what the stage computed beyond `tried`
 };
 __global__ void select_kernel(SelectArgs g) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= g.n_jobs) return;
     const uint32_t b = g.job_block[j];
-    if (g.blk_done[b]) return;
     const uint32_t p = g.ploidy;
-    const double mec_p = g.mec[(uint64_t)b * g.max_ploidy + p - 1];
-    const double expected = g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] * g.eps;         // :196
-    uint32_t best = p;
-    bool stop = false;
-    if (p > 1) {
-        const double mec_prev = g.mec[(uint64_t)b * g.max_ploidy + p - 2];
-        if ((mec_p / mec_prev) < g.mec_threshold) { /* do nothing */ }
-        else if (g.stopping_heuristic) { best = p - 1; stop = true; }                         // :233-238
-        if (!stop && mec_p < expected) stop = true;                                           // :240-243
-    } else if (mec_p < expected) stop = true;                                                 // :247-250
-    g.tried[b] = p;
-    if (stop || p == g.max_ploidy) { g.blk_done[b] = 1; g.best_ploidy[b] = best; }
+    if (!g.blk_done[b]) {
+        const double mec_p = g.mec[(uint64_t)b * g.max_ploidy + p - 1];
+        const double expected = g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] * g.eps;         // :196
+        uint32_t best = p;
+        bool stop = false;
+        if (p > 1) {
+            const double mec_prev = g.mec[(uint64_t)b * g.max_ploidy + p - 2];
+            if ((mec_p / mec_prev) < g.mec_threshold) { /* do nothing */ }
+            else if (g.stopping_heuristic) { best = p - 1; stop = true; }                         // :233-238
+            if (!stop && mec_p < expected) stop = true;                                           // :240-243
+        } else if (mec_p < expected) stop = true;                                                 // :247-250
+        g.tried[b] = p;
+        if (stop || p == g.max_ploidy) { g.blk_done[b] = 1; g.best_ploidy[b] = best; }
+    }
+    // a stage that ran several ploidies at once computed ploidies the reference never reaches for this block: the result
+    // reports mec_vector entries of 0 for them, exactly as the one-ploidy-per-stage path leaves them
+    if (g.clear_from && g.blk_done[b])
+        for (uint32_t q = g.tried[b] + 1; q <= g.stage_last; ++q) {
+            g.mec[(uint64_t)b * g.max_ploidy + q - 1] = 0.0; g.num_alleles[(uint64_t)b * g.max_ploidy + q - 1] = 0.0; g.iters[(uint64_t)b * g.max_ploidy + q - 1] = 0;
+        }
 }
 
 // final partition of every read of every block at the chosen ploidy

@@ -1,0 +1,116 @@
+// upload_kernel.h — device side of floria_hip_contig_upload_batch: validate a batch of raw CSR pileups (the invariants of
+// include/floria_hip.h: `Frag` ordering types_structs.rs:87-93, cells strictly ascending, first/last == end cells, 1-based SNP
+// indices, allele index < 4) and flatten them into the resident form the clustering kernels read:
+//
+//   cell_aw[c] = allele << 28 | w24[qual]      phred_scale (utils_frags.rs:702-711) folded into the cell, no LUT in any kernel
+//   tw[2r..]   = sum over the read's cells of Rq{1,2}[hash_idx(snp, allele)] * w   (the read's term of the linear state hash)
+//   meta[8r..] = {cell offset, cell count, first, last, tw1 lo/hi, tw2 lo/hi}       one 32-B record per beam step
+//
+// The raw arrays arrive by DMA straight from the caller's (pinned) memory; nothing is computed per cell on the host.
+// 16 lanes per read, 16 reads per 256-thread workgroup; per-contig status words are reduced with atomics.
+#pragma once
+#include "common.h"
+
+namespace fl {
+
+// error codes, in the order the host-side contract lists them; the smallest (read, code) pair of a contig is reported
+enum : uint32_t { UP_OK = 0, UP_NO_CELLS = 1, UP_FIRST_LAST = 2, UP_ONE_BASED = 3, UP_NOT_ASCENDING = 4, UP_ALLELE = 5, UP_ORDER = 6 };
+
+struct UploadContig {              // raw inputs (device copies) and flattened outputs of one contig
+    const uint32_t* read_off;      // [n_reads+1]
+    const uint32_t* first;
+    const uint32_t* last;
+    const uint32_t* snp;           // [n_cells]
+    const uint8_t*  allele;        // [n_cells] raw, transient
+    const uint8_t*  qual;          // [n_cells] raw, transient
+    uint32_t* cell_aw;
+    uint64_t* tw;
+    uint32_t* meta;
+    uint32_t  n_reads, n_cells;    // n_cells = read_off[n_reads] as the host read it (bounds every cell access)
+};
+struct UploadStatus {              // per contig, zero-initialised except err
+    unsigned long long err;        // min over failing reads of (read << 8 | code); ~0 = valid
+    uint32_t max_len, max_allele, has_q0, pad;
+};
+struct UploadArgs {
+    const UploadContig* contigs;
+    const uint64_t* read_prefix;   // [n_contigs+1] global read index of each contig's first read
+    UploadStatus* status;
+    const uint32_t* w24;           // [256]
+    const uint64_t *Rq1, *Rq2;     // [4*HASH_M]
+    uint32_t n_contigs, pad;
+    uint64_t n_reads_total;
+};
+
+template <int CTRL> __device__ __forceinline__ uint64_t up_dpp64(uint64_t x) {
+    const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, CTRL, 0xf, 0xf, false);
+    const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, false);
+    return ((uint64_t)h << 32) | l;
+}
+
+__global__ __launch_bounds__(256) void flatten_kernel(UploadArgs g) {
+    __shared__ uint32_t s_w24[256];
+    s_w24[threadIdx.x] = g.w24[threadIdx.x];
+    __syncthreads();
+    const uint32_t sub = threadIdx.x & 15;
+    const uint64_t gr = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = gr < g.n_reads_total;
+    // contig of this read: last prefix <= gr  (the 16 lanes of a read search identically; n_contigs is a few thousand at most)
+    uint32_t lo = 0, hi = g.n_contigs;
+    while (live && hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
+    uint64_t t1 = 0, t2 = 0;
+    uint32_t r = 0, b = 0, e = 0, code = UP_OK, ma = 0, q0 = 0;
+    UploadContig cd{};
+    if (live) {
+        cd = g.contigs[lo];
+        r = (uint32_t)(gr - g.read_prefix[lo]);
+        b = G(cd.read_off)[r]; e = G(cd.read_off)[r + 1];
+        auto flag = [&](uint32_t c) { code = (code == UP_OK || c < code) ? c : code; };
+        if (e <= b || e > cd.n_cells) { flag(UP_NO_CELLS); e = b; }
+        else {
+            const uint32_t F = G(cd.first)[r], L = G(cd.last)[r];
+            if (sub == 0) {
+                if (G(cd.snp)[b] != F || G(cd.snp)[e - 1] != L) flag(UP_FIRST_LAST);
+                if (G(cd.snp)[b] == 0) flag(UP_ONE_BASED);
+                if (r > 0) {                                     // Frag::cmp (types_structs.rs:87-93)
+                    const uint32_t Fp = G(cd.first)[r - 1], Lp = G(cd.last)[r - 1];
+                    if (!(Fp < F || (Fp == F && Lp >= L))) flag(UP_ORDER);
+                }
+            }
+            for (uint32_t c = b + sub; c < e; c += 16) {
+                const uint32_t s = G(cd.snp)[c];
+                if (c > b && s <= G(cd.snp)[c - 1]) flag(UP_NOT_ASCENDING);
+                uint32_t al = G(cd.allele)[c];
+                const uint32_t q = G(cd.qual)[c];
+                if (al > 3) { flag(UP_ALLELE); al = 3; }
+                const uint32_t w = s_w24[q];
+                cd.cell_aw[c] = (al << 28) | w;
+                ma = al > ma ? al : ma; q0 |= q == 0 ? 1u : 0u;
+                const uint32_t idx = hash_idx(s, al);
+                t1 += g.Rq1[idx] * (uint64_t)w; t2 += g.Rq2[idx] * (uint64_t)w;
+            }
+        }
+    }
+    // row (16-lane) reductions: DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+    auto row_sum = [](uint64_t v) { v += up_dpp64<0xB1>(v); v += up_dpp64<0x4E>(v); v += up_dpp64<0x141>(v); v += up_dpp64<0x140>(v); return v; };
+    t1 = row_sum(t1); t2 = row_sum(t2);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t oc = __shfl_xor(code, o), om = __shfl_xor(ma, o), oq = __shfl_xor(q0, o);
+        code = (oc != UP_OK && (code == UP_OK || oc < code)) ? oc : code;
+        ma = om > ma ? om : ma; q0 |= oq;
+    }
+    if (live && sub == 0) {
+        cd.tw[2 * (uint64_t)r] = t1; cd.tw[2 * (uint64_t)r + 1] = t2;
+        uint32_t* mr = cd.meta + 8 * (uint64_t)r;
+        *(uint4*)mr = make_uint4(b, e - b, G(cd.first)[r], G(cd.last)[r]);
+        *(uint4*)(mr + 4) = make_uint4((uint32_t)t1, (uint32_t)(t1 >> 32), (uint32_t)t2, (uint32_t)(t2 >> 32));
+        UploadStatus* st = g.status + lo;
+        atomicMax(&st->max_len, e - b);
+        if (ma) atomicMax(&st->max_allele, ma);
+        if (q0) atomicOr(&st->has_q0, 1u);
+        if (code != UP_OK) atomicMin(&st->err, ((unsigned long long)r << 8) | code);
+    }
+}
+
+}  // namespace fl

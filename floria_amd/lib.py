@@ -26,6 +26,8 @@ SYMBOLS = [
     "floria_hip_set_slots", "floria_hip_reassign_batch", "floria_hip_groups_array_free",
     "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered", "floria_hip_haploset_stats",
     "floria_hip_hapq", "floria_hip_hapq_batch",
+    "floria_hip_contig_upload_batch", "floria_hip_host_alloc", "floria_hip_host_free", "floria_hip_set_option",
+    "floria_hip_contig_download",
 ]
 
 
@@ -36,11 +38,14 @@ class FloriaHipError(RuntimeError):
 
 
 def build(force=False):
-    """Compile libfloria_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(_CSRC, "..", "..", "include", "floria_hip.h"))
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _CSRC, "-B", "libfloria_hip.so"], stdout=subprocess.DEVNULL)
+    """Compile libfloria_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  make decides whether the library is
+    stale (every *.h of csrc/ and include/floria_hip.h are prerequisites); where no hipcc exists (the GPU box gets the prebuilt
+    library with the snapshot) an existing library is used as it is."""
+    import shutil
+    have_hipcc = os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")
+    if not have_hipcc and os.path.exists(_SO):
+        return _SO
+    subprocess.check_call(["make", "-C", _CSRC] + (["-B"] if force else []) + ["libfloria_hip.so"], stdout=subprocess.DEVNULL)
     return _SO
 
 
@@ -57,6 +62,11 @@ def load():
             getattr(L, s).restype = None
         L.floria_hip_destroy.argtypes = [C.c_void_p]
         L.floria_hip_contig_free.argtypes = [C.c_void_p]
+        L.floria_hip_host_alloc.restype = C.c_void_p
+        L.floria_hip_host_alloc.argtypes = [C.c_size_t]
+        L.floria_hip_host_free.restype = None
+        L.floria_hip_host_free.argtypes = [C.c_void_p]
+        L.floria_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         _LIB = L
     return _LIB
 
@@ -87,14 +97,82 @@ def get_range_with_lengths(snp_to_genome_pos, block_length, overlap_len=None, mi
     return res
 
 
+class PinnedArena:
+    """Pinned host memory (floria_hip_host_alloc) handed out as numpy arrays: pileups whose arrays live here upload by DMA
+    with no staging copy, and arrays carved consecutively are back to back, so a batch travels as one transfer per field."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self._p = load().floria_hip_host_alloc(C.c_size_t(self.nbytes))
+        if not self._p:
+            raise FloriaHipError(-3, load().floria_hip_last_error().decode())
+        self._buf = (C.c_uint8 * self.nbytes).from_address(self._p)
+        self._cursor = 0
+
+    def take(self, count, dtype):
+        """Next `count` elements of `dtype` (element-aligned, NOT padded: consecutive takes of one dtype are contiguous)."""
+        dt = np.dtype(dtype)
+        off = (self._cursor + dt.itemsize - 1) // dt.itemsize * dt.itemsize
+        end = off + int(count) * dt.itemsize
+        if end > self.nbytes:
+            raise MemoryError("PinnedArena exhausted")
+        self._cursor = end
+        return np.frombuffer(self._buf, dtype=dt, count=int(count), offset=off)
+
+    def free(self):
+        if self._p:
+            self._buf = None
+            load().floria_hip_host_free(C.c_void_p(self._p))
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pin_pileups(pileups):
+    """Copy pileups into ONE pinned arena, field by field (all read_off arrays back to back, then all first, ...):
+    what a host that marshals `Vec<Frag>` into upload buffers writes directly.  Returns (arena, [Pileup views])."""
+    nr = sum(p.n_reads for p in pileups)
+    nc = sum(p.n_cells for p in pileups)
+    arena = PinnedArena(4 * (nr + len(pileups)) + 8 * nr + 6 * nc + 256)
+    fields = {}
+    for name, dt in (("read_off", np.uint32), ("first", np.uint32), ("last", np.uint32), ("snp", np.uint32), ("allele", np.uint8), ("qual", np.uint8)):
+        views = []
+        for p in pileups:
+            src = np.ascontiguousarray(getattr(p, name), dt)
+            v = arena.take(len(src), dt)
+            v[:] = src
+            views.append(v)
+        fields[name] = views
+    out = [Pileup(fields["read_off"][i], fields["snp"][i], fields["allele"][i], fields["qual"][i], fields["first"][i], fields["last"][i]) for i in range(len(pileups))]
+    return arena, out
+
+
 class ResidentContig:
-    def __init__(self, ctx, pileup: Pileup):
+    def __init__(self, ctx, pileup: Pileup = None, handle=None, n_reads=None):
         self.ctx = ctx
+        if handle is not None:
+            self._h = handle
+            self.n_reads = n_reads
+            return
         self.n_reads = pileup.n_reads
         cp = pileup.as_c()
         h = C.c_void_p()
         _check(load().floria_hip_contig_upload(ctx._h, C.byref(cp), C.byref(h)))
         self._h = h
+
+    FIELDS = {"read_off": (0, np.uint32), "first": (1, np.uint32), "last": (2, np.uint32), "snp": (3, np.uint32),
+              "cell_aw": (4, np.uint32), "tw": (5, np.uint64), "meta": (6, np.uint32)}
+
+    def download(self, field, count):
+        """Diagnostic (floria_hip_contig_download): `count` elements of a resident array."""
+        fid, dt = self.FIELDS[field]
+        out = np.zeros(int(count), dt)
+        _check(load().floria_hip_contig_download(self._h, C.c_int(fid), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+        return out
 
     def free(self):
         if self._h:
@@ -106,6 +184,35 @@ class ResidentContig:
             self.free()
         except Exception:
             pass
+
+
+class ContigBatch:
+    """The handles of one floria_hip_contig_upload_batch call, kept as the ctypes array the C entry points take (no per-contig
+    Python objects: a host loop that uploads and phases batch after batch pays only the C calls)."""
+
+    def __init__(self, ctx, handles, n):
+        self.ctx, self._arr, self.n = ctx, handles, n
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        if self._arr is not None:
+            L = load()
+            for i in range(self.n):
+                L.floria_hip_contig_free(C.c_void_p(self._arr[i]))
+            self._arr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def c_pileups(pileups):
+    """ctypes array of floria_pileup for a list of Pileups (keep the Pileups alive while it is in use)."""
+    return (capi.CPileup * len(pileups))(*[p.as_c() for p in pileups])
 
 
 class FloriaHip:
@@ -131,8 +238,27 @@ class FloriaHip:
     def set_slots(self, n):
         _check(load().floria_hip_set_slots(self._h, C.c_uint32(n)))
 
+    def set_option(self, key, value):
+        """Tuning / test knobs (floria_hip_set_option); none changes results."""
+        _check(load().floria_hip_set_option(self._h, key.encode(), C.c_int64(int(value))))
+
     def upload(self, pileup: Pileup):
         return ResidentContig(self, pileup)
+
+    def upload_batch(self, pileups):
+        """floria_hip_contig_upload_batch: one allocation, DMA of the raw arrays, validate + flatten on the device."""
+        n = len(pileups)
+        arr = c_pileups(pileups)
+        hs = (C.c_void_p * n)()
+        _check(load().floria_hip_contig_upload_batch(self._h, arr, C.c_uint32(n), hs))
+        return [ResidentContig(self, handle=C.c_void_p(hs[i]), n_reads=pileups[i].n_reads) for i in range(n)]
+
+    def upload_batch_c(self, carr, n=None):
+        """The same for a prebuilt ctypes floria_pileup array -> ContigBatch."""
+        n = len(carr) if n is None else n
+        hs = (C.c_void_p * n)()
+        _check(load().floria_hip_contig_upload_batch(self._h, carr, C.c_uint32(n), hs))
+        return ContigBatch(self, hs, n)
 
     def timing(self):
         t = capi.CTiming()
@@ -158,7 +284,7 @@ class FloriaHip:
         return res
 
     def phase_blocks_batch(self, contigs, blk_contig, blk_start, blk_end, params, copy_out=True):
-        arr = (C.c_void_p * len(contigs))(*[c._h for c in contigs])
+        arr = contigs._arr if isinstance(contigs, ContigBatch) else (C.c_void_p * len(contigs))(*[c._h for c in contigs])
         bc = np.ascontiguousarray(blk_contig, np.uint32)
         bs = np.ascontiguousarray(blk_start, np.uint32)
         be = np.ascontiguousarray(blk_end, np.uint32)

@@ -133,8 +133,10 @@ typedef struct {
     uint64_t jobs;             /* (block, ploidy) jobs actually run */
     uint32_t streams;          /* job groups of the last S1 call: their launch triples overlap on separate streams, so the
                                 * per-kernel sums above can exceed phase_ms */
-    uint32_t reserved;
+    uint32_t stage_width;      /* ploidies run concurrently per stage (1 = the reference's sequential ploidy loop, no speculative jobs) */
     double   phase_ms;         /* wall time of the per-ploidy launch loop (fork of the first group -> join of the last) */
+    uint64_t upload_pinned_bytes; /* last upload: bytes that went by DMA straight from the caller's pinned memory */
+    uint64_t upload_staged_bytes; /* last upload: bytes staged through the library's pinned ring (pageable sources)  */
 } floria_timing;
 
 typedef struct floria_hip_ctx floria_hip_ctx;
@@ -153,10 +155,33 @@ int  floria_hip_block_ranges(const uint64_t* snp_to_genome_pos, uint32_t n_snps,
                              floria_ranges** out);
 void floria_hip_ranges_free(floria_ranges* r);
 
-/* Upload one contig's pileup to HBM (validates the invariants above).  The handle can be phased
- * any number of times; bench.py times phase_blocks_resident so that inputs are resident in HBM. */
+/* Upload one contig's pileup to HBM.  The invariants above are validated ON THE DEVICE while the pileup is flattened into
+ * its resident form (allele | Q24 weight per cell, per-read hash constants and metadata records): the host touches no cell.
+ * The handle can be phased any number of times. */
 int  floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* pileup, floria_hip_contig** out);
 void floria_hip_contig_free(floria_hip_contig* c);
+
+/* Upload n contigs in one go (what a host does once per batch of contigs it marshals from `Vec<Frag>`, floria.rs:255-293):
+ * one device allocation, the raw arrays by DMA (arrays of consecutive contigs that are back to back in host memory travel as
+ * ONE transfer; sources in floria_hip_host_alloc memory are not staged), one validate + flatten launch, one synchronisation.
+ * out[0..n) receive the handles (each freed with floria_hip_contig_free); on error no handle is returned. */
+int  floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, floria_hip_contig** out);
+
+/* Diagnostic: copy one resident array of a contig back to the host.  CELL_AW = allele << 28 | Q24 weight per cell
+ * (phred_scale, utils_frags.rs:702-711), TW = the two per-read constants of the linear state hash, META = the packed per-read
+ * record {cell offset, cell count, first, last, tw1 lo/hi, tw2 lo/hi}. */
+#define FLORIA_FIELD_READ_OFF 0
+#define FLORIA_FIELD_FIRST    1
+#define FLORIA_FIELD_LAST     2
+#define FLORIA_FIELD_SNP      3
+#define FLORIA_FIELD_CELL_AW  4
+#define FLORIA_FIELD_TW       5
+#define FLORIA_FIELD_META     6
+int  floria_hip_contig_download(const floria_hip_contig* c, int field, void* dst, size_t bytes);
+
+/* Pinned host memory for pileup arrays (NULL on failure). */
+void* floria_hip_host_alloc(size_t bytes);
+void  floria_hip_host_free(void* p);
 
 /* S1: phase n_blocks SNP ranges of one resident contig. */
 int  floria_hip_phase_blocks_resident(floria_hip_ctx* ctx, const floria_hip_contig* contig,
@@ -235,6 +260,12 @@ int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */
 int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
+
+/* Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy
+ * stages: -1 auto, 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}), "beam_path" (0 auto,
+ * 1 generic, 2 fast, 3 slab, 4 wide), "no_specialized", "no_p1_shortcut", "opt_threads" (0|128|512|1024), "opt_global",
+ * "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload). */
+int  floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus
 }

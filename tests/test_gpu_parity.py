@@ -252,13 +252,16 @@ def test_random_medium_pileups_all_beam_paths(gpu_ctx, hip_lib, oracle_mod, seed
     eps = [EPS, 0.04][seed % 2]
     ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, B), threads=4)
     try:
-        for path in ("slab", "fast", "generic", "wide"):
-            os.environ["FLORIA_HIP_BEAM"] = path
-            rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, B))
-            assert_block_results_equal(ro, rg, f"seed {seed} path {path}")
-            assert rg.min_prune_margin == ro.min_prune_margin
+        for code, path in ((3, "slab"), (2, "fast"), (1, "generic"), (4, "wide")):
+            gpu_ctx.set_option("beam_path", code)
+            for spec in (0, 1):                      # one ploidy per stage / all ploidies of a block at once
+                gpu_ctx.set_option("speculate", spec)
+                rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, B))
+                assert_block_results_equal(ro, rg, f"seed {seed} path {path} speculate {spec}")
+                assert rg.min_prune_margin == ro.min_prune_margin
     finally:
-        os.environ.pop("FLORIA_HIP_BEAM", None)
+        gpu_ctx.set_option("beam_path", 0)
+        gpu_ctx.set_option("speculate", -1)
 
 
 def test_ploidy1_shortcut_equals_the_search(gpu_ctx, hip_lib):
@@ -266,11 +269,11 @@ def test_ploidy1_shortcut_equals_the_search(gpu_ctx, hip_lib):
     c = synth.make_config_contig(4, 7, 0.5)
     s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
     a = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
-    os.environ["FLORIA_HIP_NO_P1_SHORTCUT"] = "1"
+    gpu_ctx.set_option("no_p1_shortcut", 1)
     try:
         b = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
     finally:
-        os.environ.pop("FLORIA_HIP_NO_P1_SHORTCUT", None)
+        gpu_ctx.set_option("no_p1_shortcut", 0)
     assert_block_results_equal(a, b, "p1 shortcut")
     assert a.min_prune_margin == b.min_prune_margin
 
@@ -378,15 +381,15 @@ def test_bench_scale_properties(gpu_ctx, hip_lib, oracle_mod, monkeypatch):
         s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
         bc += [i] * len(s); bs += list(s); be += list(e)
     assert len(bc) >= 2048                                           # two job groups by default
-    monkeypatch.setenv("FLORIA_HIP_GROUPS", "1")
+    gpu_ctx.set_option("groups", 1)
     one = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
     assert gpu_ctx.timing()["streams"] == 1
-    monkeypatch.delenv("FLORIA_HIP_GROUPS")
+    gpu_ctx.set_option("groups", 0)
     two = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
     assert gpu_ctx.timing()["streams"] == 2
-    monkeypatch.setenv("FLORIA_HIP_GROUPS", "3")
+    gpu_ctx.set_option("groups", 3)
     three = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
-    monkeypatch.delenv("FLORIA_HIP_GROUPS")
+    gpu_ctx.set_option("groups", 0)
     assert_block_results_equal(one, two, "1 vs 2 job groups")
     assert_block_results_equal(one, three, "1 vs 3 job groups")
     assert one.min_prune_margin == two.min_prune_margin == three.min_prune_margin > 1e-9
@@ -421,9 +424,9 @@ def test_specialised_and_generic_slab_kernels_agree(gpu_ctx, hip_lib, oracle_mod
     s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
     ro = oracle_mod.phase_blocks(c.pileup, s, e, oracle_mod.make_params(EPS), threads=8)
     spec = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
-    monkeypatch.setenv("FLORIA_HIP_NO_SPECIALIZED", "1")
+    gpu_ctx.set_option("no_specialized", 1)
     gen = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
-    monkeypatch.delenv("FLORIA_HIP_NO_SPECIALIZED")
+    gpu_ctx.set_option("no_specialized", 0)
     assert_block_results_equal(ro, spec, "specialised")
     assert_block_results_equal(ro, gen, "generic")
     assert spec.min_prune_margin == gen.min_prune_margin == ro.min_prune_margin
