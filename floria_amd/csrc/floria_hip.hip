@@ -22,6 +22,7 @@
 #include <string>
 #include <utility>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -140,6 +141,9 @@ struct Knobs {
     uint32_t opt_threads = 0;     // 0 auto | 128 | 512 | 1024
     uint32_t opt_global = 0;      // optimise histogram in HBM
     int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P}
+    uint32_t upload_chunks = 0;   // floria_hip_phase_pileups_batch: chunks the cell arrays travel in (0 = auto by size, <= 8)
+    uint32_t upload_split = 0;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
+    uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
 };
 
 struct Arena;
@@ -157,6 +161,9 @@ struct floria_hip_ctx {
     hipEvent_t ev_fork[MAX_LANES] = {}, ev_join[MAX_LANES] = {};
     hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
     hipEvent_t ev_rids = nullptr;
+    hipEvent_t ev_chunk[MAX_GROUPS + 1] = {};  // floria_hip_phase_pileups_batch: chunk g of the cell arrays has landed and is flattened
+    hipEvent_t ev_copied[MAX_GROUPS + 1] = {}; //   ... has landed (the flatten launches run on their own stream, so the DMA queue never waits for a kernel)
+    hipStream_t flat_stream = nullptr;
     // cached tables
     double binom_eps = -1.0;
     uint32_t binom_nmax = 0;
@@ -294,6 +301,7 @@ enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5, K
 void sync_all(floria_hip_ctx* ctx) {
     for (uint32_t g = 0; g < floria_hip_ctx::MAX_LANES; ++g) if (ctx->gstream[g]) (void)hipStreamSynchronize(ctx->gstream[g]);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->flat_stream) (void)hipStreamSynchronize(ctx->flat_stream);
     (void)hipStreamSynchronize(ctx->stream);
 }
 
@@ -323,7 +331,7 @@ struct PloidyPlan {
 template <int A>
 int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const std::vector<uint32_t>& jobs, const std::vector<uint32_t>& group_off,
               const uint32_t* d_jobs, uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
-              uint8_t* d_beam_part, const std::vector<std::vector<uint32_t>>& stages, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
+              uint8_t* d_beam_part, const std::vector<std::vector<uint32_t>>& stages, hipEvent_t* chunk_ev, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
               uint32_t* d_tried, uint32_t* d_queue, double* d_margin, uint32_t* d_diag,
               unsigned long long* d_steps, EventTimer& T, bool& p1_shortcut) {
     const uint32_t P = prm->max_ploidy, B = prm->beam;
@@ -447,6 +455,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         HIPCHK(hipEventRecord(ctx->ev_fork[0], ctx->stream));
         for (uint32_t g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(ls[g * W], ctx->ev_fork[0], 0));
     }
+    // chunked inputs: group g's first lane also waits until chunk g's cells have arrived and been flattened
+    if (chunk_ev) for (uint32_t g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(ls[g * W], chunk_ev[g], 0));
     const uint64_t* H = ctx->d_hash.as<uint64_t>();
     for (size_t si = 0; si < stages.size(); ++si) {
         const std::vector<uint32_t>& stage = stages[si];
@@ -463,7 +473,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                 const uint32_t p = stage[j], lane = g * W + j;
                 const PloidyPlan& q = plan[p];
                 hipStream_t st = ls[lane];
-                uint32_t* gqueue = d_queue + 2 * lane;           // [0] beam, [1] optimise
+                uint32_t* gqueue = d_queue + 2 * ((size_t)lane * P + (p - 1));     // [0] beam, [1] optimise: one counter pair per (lane, ploidy), zeroed once before the
+                                                                                    // loop (a memset between persistent launches is a fill KERNEL that waits for wave slots)
                 uint8_t* lane_part = d_beam_part + (uint64_t)j * (tot_reads + 16);
                 // ---- beam search -----------------------------------------------------------------------------------------
                 if (!q.shortcut) {
@@ -478,7 +489,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
                     a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
                     a.prof = (unsigned long long*)(d_diag + 4);
-                    HIPCHK(hipMemsetAsync(gqueue, 0, 4, st));
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
@@ -519,7 +529,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.moves_pool = (uint32_t*)(ctx->opt_moves.as<char>() + sl_omoves * lane); a.cand_cap = q.cand_cap;
                     a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
                     a.prof = (unsigned long long*)(d_diag + 4);
-                    HIPCHK(hipMemsetAsync(gqueue + 1, 0, 4, st));
                     int t = T.begin(K_OPT, st);
                     auto launch = [&](auto kern) -> hipError_t {
                         if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
@@ -616,6 +625,8 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(2, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(3, atoi(v)));
+        K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
         else c->stage_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     }
@@ -636,6 +647,9 @@ void floria_hip_destroy(floria_hip_ctx* c) {
         if (c->ev_fork[g]) (void)hipEventDestroy(c->ev_fork[g]);
     }
     if (c->ev_rids) (void)hipEventDestroy(c->ev_rids);
+    for (hipEvent_t e : c->ev_chunk) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_copied) if (e) (void)hipEventDestroy(e);
+    if (c->flat_stream) (void)hipStreamDestroy(c->flat_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -658,6 +672,9 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
     else if (k == "opt_global") K.opt_global = value != 0;
     else if (k == "speculate") { if (value < -1 || value > 2) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2"); K.speculate = (int32_t)value; }
+    else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
+    else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 3));
+    else if (k == "trace") K.trace = value != 0;
     else if (k == "slots") ctx->user_slots = (uint32_t)std::max<int64_t>(0, value);
     else if (k == "stage_threads") ctx->stage_threads = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else return fail(FLORIA_E_INVALID, "unknown option '" + k + "'");
@@ -754,6 +771,170 @@ int host_meta(const floria_hip_contig* cc) {
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+
+// The plan of one batch upload: where every array of every contig lands in the arena, which host->device transfers carry it
+// (arrays of consecutive contigs that are back to back in host memory merge into one transfer) and the flatten kernel's tables.
+// The cell arrays (snp, allele, qual — 99 % of the bytes) are planned per CHUNK of consecutive contigs, so that a caller can
+// start work on chunk g while chunk g+1 is still on the wire (floria_hip_phase_pileups_batch).
+struct UploadPlan {
+    uint32_t n = 0, n_chunks = 1;
+    std::vector<uint64_t> rp, cp;                       // read / cell prefix per contig
+    uint64_t R = 0, C = 0;
+    Arena* A = nullptr;
+    char *D = nullptr, *T = nullptr;                    // arena base, transient base
+    size_t t_cd = 0, t_rp = 0, t_st = 0;
+    std::vector<fl::UploadContig> ucd;
+    std::vector<fl::UploadStatus> ust;
+    std::vector<CopyRun> small_runs;                    // read_off, first, last of every contig
+    std::vector<std::vector<CopyRun>> chunk_runs;       // snp, allele, qual per chunk
+    std::vector<uint32_t> chunk_first;                  // [n_chunks+1] contig boundaries
+    std::vector<uint32_t> contig_chunk;                 // [n]
+    bool all_pinned = false;
+};
+
+int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, uint32_t n_chunks, UploadPlan& P) {
+    P.n = n;
+    P.rp.assign(n + 1, 0); P.cp.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const floria_pileup* p = &pileups[i];
+        if (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last)) return fail(FLORIA_E_INVALID, "null pileup field");
+        const uint64_t nc = p->n_reads ? p->read_off[p->n_reads] : 0;
+        if (nc >= (1ull << 32)) return fail(FLORIA_E_UNSUPPORTED, "more than 2^32 cells in one contig");
+        P.rp[i + 1] = P.rp[i] + p->n_reads; P.cp[i + 1] = P.cp[i] + nc;
+    }
+    const uint64_t R = P.R = P.rp[n], C = P.C = P.cp[n];
+    // chunks: consecutive contigs, balanced by cells
+    n_chunks = std::max<uint32_t>(1, std::min<uint32_t>(n_chunks, n));
+    P.n_chunks = n_chunks;
+    P.chunk_first.assign(n_chunks + 1, n); P.chunk_first[0] = 0;
+    P.contig_chunk.assign(n, 0);
+    {
+        // chunk weights: a small first chunk puts the GPU to work early, a small last chunk keeps the chain that starts last short
+        std::vector<double> cum(n_chunks + 1, 0.0);
+        for (uint32_t g = 0; g < n_chunks; ++g) {
+            double w = 1.0;
+            if (ctx->knobs.upload_split == 1 && n_chunks >= 3) w = (g == 0 || g + 1 == n_chunks) ? 0.5 : 1.0;
+            else if (ctx->knobs.upload_split == 2 && n_chunks >= 2) w = g == 0 ? 0.5 : 1.0;
+            else if (ctx->knobs.upload_split == 3 && n_chunks >= 2) w = 1.0 + g;
+            cum[g + 1] = cum[g] + w;
+        }
+        uint32_t g = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            while (g + 1 < n_chunks && (double)P.cp[i] >= (double)C * cum[g + 1] / cum[n_chunks] && i > P.chunk_first[g]) P.chunk_first[++g] = i;
+            P.contig_chunk[i] = g;
+        }
+        for (uint32_t h = g + 1; h < n_chunks; ++h) P.chunk_first[h] = n;          // (fewer non-empty chunks than asked for)
+    }
+    // ---- arena layout -------------------------------------------------------------------------------------------------------
+    size_t cursor = 0;
+    auto seg = [&](size_t bytes) { const size_t o = cursor; cursor += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_ro = seg(4 * (R + n)), o_first = seg(4 * R), o_last = seg(4 * R), o_snp = seg(4 * C + 16), o_aw = seg(4 * C + 16),      // 16-B tails: the
+                 o_tw = seg(16 * R), o_meta = seg(32 * R);                                              // beam kernel's LDS-DMA moves cells in 16-B pieces
+    Arena* A = P.A = arena_get(ctx, cursor + 256);
+    if (!A) return FLORIA_E_NOMEM;
+    A->n_contigs = n; A->R = R; A->C = C; A->off_ro = o_ro; A->off_first = o_first; A->off_last = o_last; A->read_prefix = P.rp; A->host_meta = false;
+    char* D = P.D = A->buf.as<char>();
+    // transient: raw allele / qual bytes, the kernel's contig table, prefix and status
+    size_t c2 = 0;
+    auto seg2 = [&](size_t bytes) { const size_t o = c2; c2 += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t t_al = seg2(C + 16), t_q = seg2(C + 16);
+    P.t_cd = seg2(sizeof(fl::UploadContig) * n); P.t_rp = seg2(8 * (n + 1)); P.t_st = seg2(sizeof(fl::UploadStatus) * n);
+    if (int rc = ctx->up_tmp.ensure(c2 + 256)) { arena_put(A); P.A = nullptr; return rc; }
+    char* T = P.T = ctx->up_tmp.as<char>();
+    P.ucd.resize(n); P.ust.resize(n);
+    auto add_run = [](std::vector<CopyRun>& runs, const void* src, char* dst, size_t bytes) {
+        if (!bytes) return;
+        if (!runs.empty() && runs.back().src + runs.back().bytes == (const char*)src && runs.back().dst + runs.back().bytes == dst) runs.back().bytes += bytes;
+        else runs.push_back({(const char*)src, dst, bytes});
+    };
+    for (int kind = 0; kind < 3; ++kind)
+        for (uint32_t i = 0; i < n; ++i) {
+            const floria_pileup* p = &pileups[i];
+            if (!p->n_reads) continue;
+            const uint64_t nr = p->n_reads;
+            if (kind == 0) add_run(P.small_runs, p->read_off, D + o_ro + 4 * (P.rp[i] + i), 4 * (nr + 1));
+            else if (kind == 1) add_run(P.small_runs, p->first, D + o_first + 4 * P.rp[i], 4 * nr);
+            else add_run(P.small_runs, p->last, D + o_last + 4 * P.rp[i], 4 * nr);
+        }
+    P.chunk_runs.assign(n_chunks, {});
+    for (uint32_t g = 0; g < n_chunks; ++g)
+        for (int kind = 0; kind < 3; ++kind)
+            for (uint32_t i = P.chunk_first[g]; i < P.chunk_first[g + 1]; ++i) {
+                const floria_pileup* p = &pileups[i];
+                if (!p->n_reads) continue;
+                const uint64_t nc = P.cp[i + 1] - P.cp[i];
+                if (kind == 0) add_run(P.chunk_runs[g], p->snp, D + o_snp + 4 * P.cp[i], 4 * nc);
+                else if (kind == 1) add_run(P.chunk_runs[g], p->allele, T + t_al + P.cp[i], nc);
+                else add_run(P.chunk_runs[g], p->qual, T + t_q + P.cp[i], nc);
+            }
+    for (uint32_t i = 0; i < n; ++i) {
+        fl::UploadContig& u = P.ucd[i];
+        u.read_off = (const uint32_t*)(D + o_ro + 4 * (P.rp[i] + i)); u.first = (const uint32_t*)(D + o_first + 4 * P.rp[i]); u.last = (const uint32_t*)(D + o_last + 4 * P.rp[i]);
+        u.snp = (const uint32_t*)(D + o_snp + 4 * P.cp[i]); u.allele = (const uint8_t*)(T + t_al + P.cp[i]); u.qual = (const uint8_t*)(T + t_q + P.cp[i]);
+        u.cell_aw = (uint32_t*)(D + o_aw + 4 * P.cp[i]); u.tw = (uint64_t*)(D + o_tw + 16 * P.rp[i]); u.meta = (uint32_t*)(D + o_meta + 32 * P.rp[i]);
+        u.n_reads = pileups[i].n_reads; u.n_cells = (uint32_t)(P.cp[i + 1] - P.cp[i]);
+        P.ust[i] = fl::UploadStatus{~0ull, 0, 0, 0, 0};
+    }
+    P.all_pinned = true;
+    auto pinned_run = [](const CopyRun& r) { return r.bytes < 4096 || (is_pinned(r.src) && is_pinned(r.src + r.bytes - 1)); };
+    for (auto& r : P.small_runs) P.all_pinned = P.all_pinned && pinned_run(r);
+    for (auto& v : P.chunk_runs) for (auto& r : v) P.all_pinned = P.all_pinned && pinned_run(r);
+    return 0;
+}
+
+// the flatten kernel's tables (contig table, read prefix, fresh status words) — before any flatten launch
+hipError_t issue_tables(floria_hip_ctx* ctx, UploadPlan& P, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(P.T + P.t_cd, P.ucd.data(), sizeof(fl::UploadContig) * P.n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(P.T + P.t_rp, P.rp.data(), 8 * (P.n + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(P.T + P.t_st, P.ust.data(), sizeof(fl::UploadStatus) * P.n, hipMemcpyHostToDevice, st);
+    return e;
+}
+// validate + flatten the reads of chunk g (its cells and the small arrays must have arrived on `st`)
+hipError_t launch_flatten(floria_hip_ctx* ctx, UploadPlan& P, uint32_t g, hipStream_t st) {
+    const uint32_t c0 = P.chunk_first[g], c1 = P.chunk_first[g + 1];
+    const uint64_t nr = P.rp[c1] - P.rp[c0];
+    if (!nr) return hipSuccess;
+    fl::UploadArgs a{};
+    a.contigs = (const fl::UploadContig*)(P.T + P.t_cd) + c0; a.read_prefix = (const uint64_t*)(P.T + P.t_rp) + c0; a.status = (fl::UploadStatus*)(P.T + P.t_st) + c0;
+    a.w24 = ctx->d_w24.as<uint32_t>(); a.Rq1 = ctx->d_hash.as<uint64_t>(); a.Rq2 = ctx->d_hash.as<uint64_t>() + 2ull * ctx->hash_len;
+    a.n_contigs = c1 - c0; a.read_base = P.rp[c0]; a.n_reads_total = nr;
+    hipLaunchKernelGGL(fl::flatten_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+// status words -> error (if any), else the contig handles
+int finish_upload(floria_hip_ctx* ctx, UploadPlan& P, const floria_pileup* pileups, floria_hip_contig** out) {
+    const uint32_t n = P.n;
+    for (uint32_t i = 0; i < n; ++i) if (P.ust[i].err != ~0ull) {
+        const std::string r = std::to_string((unsigned long long)(P.ust[i].err >> 8)), ci = n > 1 ? " (contig " + std::to_string(i) + " of the batch)" : std::string();
+        switch ((uint32_t)(P.ust[i].err & 0xff)) {
+            case fl::UP_NO_CELLS:      return fail(FLORIA_E_INVALID, "read " + r + " has no cells (or read_off is not monotone)" + ci);
+            case fl::UP_FIRST_LAST:    return fail(FLORIA_E_INVALID, "first/last of read " + r + " do not match its cells" + ci);
+            case fl::UP_ONE_BASED:     return fail(FLORIA_E_INVALID, "SNP positions are 1-based" + ci);
+            case fl::UP_NOT_ASCENDING: return fail(FLORIA_E_INVALID, "cells of read " + r + " not strictly ascending" + ci);
+            case fl::UP_ALLELE:        return fail(FLORIA_E_UNSUPPORTED, "allele index > 3 (read " + r + ")" + ci);
+            default:                   return fail(FLORIA_E_INVALID, "reads not sorted by Frag::cmp at read " + r + ci);
+        }
+    }
+    if (!out) return 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        floria_hip_contig* c = new floria_hip_contig();
+        c->ctx = ctx; c->arena = P.A; c->idx = i; c->n_reads = pileups[i].n_reads; c->n_cells = P.cp[i + 1] - P.cp[i];
+        c->max_len = P.ust[i].max_len; c->n_alleles = P.ust[i].max_allele >= 2 ? 4 : 2; c->has_q0 = P.ust[i].has_q0 != 0;
+        c->dev.read_off = P.ucd[i].read_off; c->dev.first = P.ucd[i].first; c->dev.last = P.ucd[i].last; c->dev.cell_snp = P.ucd[i].snp;
+        c->dev.cell_aw = P.ucd[i].cell_aw; c->dev.tw = P.ucd[i].tw; c->dev.meta = P.ucd[i].meta; c->dev.n_reads = pileups[i].n_reads;
+        out[i] = c;
+    }
+    P.A->refs = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 // Upload a batch of contigs: plan the arena, DMA the raw arrays (consecutive contigs whose arrays are back to back in host
 // memory travel as one transfer), validate + flatten on the device (upload_kernel.h), read back the per-contig status.
 int floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, floria_hip_contig** out) {
@@ -761,111 +942,26 @@ int floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     for (uint32_t i = 0; i < n; ++i) out[i] = nullptr;
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(ctx->device));
-    std::vector<uint64_t> rp(n + 1, 0), cp(n + 1, 0);
-    for (uint32_t i = 0; i < n; ++i) {
-        const floria_pileup* p = &pileups[i];
-        if (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last)) return fail(FLORIA_E_INVALID, "null pileup field");
-        const uint64_t nc = p->n_reads ? p->read_off[p->n_reads] : 0;
-        rp[i + 1] = rp[i] + p->n_reads; cp[i + 1] = cp[i] + nc;
-    }
-    const uint64_t R = rp[n], C = cp[n];
-    // ---- arena layout -------------------------------------------------------------------------------------------------------
-    size_t cursor = 0;
-    auto seg = [&](size_t bytes) { const size_t o = cursor; cursor += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_ro = seg(4 * (R + n)), o_first = seg(4 * R), o_last = seg(4 * R), o_snp = seg(4 * C + 16), o_aw = seg(4 * C + 16),      // 16-B tails: the
-                 o_tw = seg(16 * R), o_meta = seg(32 * R);                                              // beam kernel's LDS-DMA moves cells in 16-B pieces
-    Arena* A = arena_get(ctx, cursor + 256);
-    if (!A) return FLORIA_E_NOMEM;
-    A->n_contigs = n; A->R = R; A->C = C; A->off_ro = o_ro; A->off_first = o_first; A->off_last = o_last; A->read_prefix = rp; A->host_meta = false;
-    char* D = A->buf.as<char>();
-    // transient: raw allele / qual bytes, the kernel's contig table, prefix and status
-    size_t c2 = 0;
-    auto seg2 = [&](size_t bytes) { const size_t o = c2; c2 += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t t_al = seg2(C + 16), t_q = seg2(C + 16), t_cd = seg2(sizeof(fl::UploadContig) * n), t_rp = seg2(8 * (n + 1)), t_st = seg2(sizeof(fl::UploadStatus) * n);
-    int rc = ctx->up_tmp.ensure(c2 + 256);
-    if (rc) { arena_put(A); return rc; }
-    char* T = ctx->up_tmp.as<char>();
-    std::vector<fl::UploadContig> ucd(n);
-    std::vector<fl::UploadStatus> ust(n);
-    std::vector<CopyRun> runs;
-    auto add_run = [&](const void* src, char* dst, size_t bytes) {
-        if (!bytes) return;
-        if (!runs.empty() && runs.back().src + runs.back().bytes == (const char*)src && runs.back().dst + runs.back().bytes == dst) runs.back().bytes += bytes;
-        else runs.push_back({(const char*)src, dst, bytes});
-    };
-    for (int kind = 0; kind < 6; ++kind)
-        for (uint32_t i = 0; i < n; ++i) {
-            const floria_pileup* p = &pileups[i];
-            if (!p->n_reads) continue;
-            const uint64_t nr = p->n_reads, nc = cp[i + 1] - cp[i];
-            switch (kind) {
-                case 0: add_run(p->read_off, D + o_ro + 4 * (rp[i] + i), 4 * (nr + 1)); break;
-                case 1: add_run(p->first, D + o_first + 4 * rp[i], 4 * nr); break;
-                case 2: add_run(p->last, D + o_last + 4 * rp[i], 4 * nr); break;
-                case 3: add_run(p->snp, D + o_snp + 4 * cp[i], 4 * nc); break;
-                case 4: add_run(p->allele, T + t_al + cp[i], nc); break;
-                default: add_run(p->qual, T + t_q + cp[i], nc); break;
-            }
-        }
-    for (uint32_t i = 0; i < n; ++i) {
-        fl::UploadContig& u = ucd[i];
-        u.read_off = (const uint32_t*)(D + o_ro + 4 * (rp[i] + i)); u.first = (const uint32_t*)(D + o_first + 4 * rp[i]); u.last = (const uint32_t*)(D + o_last + 4 * rp[i]);
-        u.snp = (const uint32_t*)(D + o_snp + 4 * cp[i]); u.allele = (const uint8_t*)(T + t_al + cp[i]); u.qual = (const uint8_t*)(T + t_q + cp[i]);
-        u.cell_aw = (uint32_t*)(D + o_aw + 4 * cp[i]); u.tw = (uint64_t*)(D + o_tw + 16 * rp[i]); u.meta = (uint32_t*)(D + o_meta + 32 * rp[i]);
-        u.n_reads = pileups[i].n_reads; u.n_cells = (uint32_t)(cp[i + 1] - cp[i]);
-        if (cp[i + 1] - cp[i] >= (1ull << 32)) { arena_put(A); return fail(FLORIA_E_UNSUPPORTED, "more than 2^32 cells in one contig"); }
-        ust[i] = fl::UploadStatus{~0ull, 0, 0, 0, 0};
-    }
+    UploadPlan P;
+    int rc = plan_upload(ctx, pileups, n, 1, P);
+    if (rc) return rc;
     EventTimer Tm(ctx->stream);
     const int th = Tm.begin(K_H2D);
     uint64_t pinned_b = 0, staged_b = 0;
+    std::vector<CopyRun> runs = P.small_runs;
+    runs.insert(runs.end(), P.chunk_runs[0].begin(), P.chunk_runs[0].end());
     rc = issue_copies(ctx, runs, &pinned_b, &staged_b);
-    hipError_t e = hipSuccess;
-    if (!rc) {
-        e = hipMemcpyAsync(T + t_cd, ucd.data(), sizeof(fl::UploadContig) * n, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(T + t_rp, rp.data(), 8 * (n + 1), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(T + t_st, ust.data(), sizeof(fl::UploadStatus) * n, hipMemcpyHostToDevice, ctx->stream);
-    }
+    hipError_t e = rc ? hipSuccess : issue_tables(ctx, P, ctx->stream);
     Tm.end(th);
-    int tk = -1;
-    if (!rc && e == hipSuccess && R) {
-        fl::UploadArgs a{};
-        a.contigs = (const fl::UploadContig*)(T + t_cd); a.read_prefix = (const uint64_t*)(T + t_rp); a.status = (fl::UploadStatus*)(T + t_st);
-        a.w24 = ctx->d_w24.as<uint32_t>(); a.Rq1 = ctx->d_hash.as<uint64_t>(); a.Rq2 = ctx->d_hash.as<uint64_t>() + 2ull * ctx->hash_len;
-        a.n_contigs = n; a.n_reads_total = R;
-        tk = Tm.begin(K_SEL);
-        hipLaunchKernelGGL(fl::flatten_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, ctx->stream, a);
-        Tm.end(tk);
-        e = hipGetLastError();
-    }
-    if (!rc && e == hipSuccess) e = hipMemcpyAsync(ust.data(), T + t_st, sizeof(fl::UploadStatus) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) { const int tk = Tm.begin(K_SEL); e = launch_flatten(ctx, P, 0, ctx->stream); Tm.end(tk); }
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(P.ust.data(), P.T + P.t_st, sizeof(fl::UploadStatus) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (!rc && e != hipSuccess) rc = fail(FLORIA_E_DEVICE, std::string("contig upload: ") + hipGetErrorString(e));
-    if (!rc)
-        for (uint32_t i = 0; i < n && !rc; ++i) if (ust[i].err != ~0ull) {
-            const std::string r = std::to_string((unsigned long long)(ust[i].err >> 8)), ci = n > 1 ? " (contig " + std::to_string(i) + " of the batch)" : std::string();
-            switch ((uint32_t)(ust[i].err & 0xff)) {
-                case fl::UP_NO_CELLS:      rc = fail(FLORIA_E_INVALID, "read " + r + " has no cells (or read_off is not monotone)" + ci); break;
-                case fl::UP_FIRST_LAST:    rc = fail(FLORIA_E_INVALID, "first/last of read " + r + " do not match its cells" + ci); break;
-                case fl::UP_ONE_BASED:     rc = fail(FLORIA_E_INVALID, "SNP positions are 1-based" + ci); break;
-                case fl::UP_NOT_ASCENDING: rc = fail(FLORIA_E_INVALID, "cells of read " + r + " not strictly ascending" + ci); break;
-                case fl::UP_ALLELE:        rc = fail(FLORIA_E_UNSUPPORTED, "allele index > 3 (read " + r + ")" + ci); break;
-                default:                   rc = fail(FLORIA_E_INVALID, "reads not sorted by Frag::cmp at read " + r + ci); break;
-            }
-        }
-    if (rc) { arena_put(A); return rc; }
+    if (!rc) rc = finish_upload(ctx, P, pileups, out);
+    if (rc) { sync_all(ctx); arena_put(P.A); return rc; }
     ctx->timing = floria_timing{};
     ctx->timing.h2d_ms = Tm.sum(K_H2D); ctx->timing.select_ms = Tm.sum(K_SEL); ctx->timing.total_ms = Tm.span();
     ctx->timing.upload_pinned_bytes = pinned_b; ctx->timing.upload_staged_bytes = staged_b;
-    for (uint32_t i = 0; i < n; ++i) {
-        floria_hip_contig* c = new floria_hip_contig();
-        c->ctx = ctx; c->arena = A; c->idx = i; c->n_reads = pileups[i].n_reads; c->n_cells = cp[i + 1] - cp[i];
-        c->max_len = ust[i].max_len; c->n_alleles = ust[i].max_allele >= 2 ? 4 : 2; c->has_q0 = ust[i].has_q0 != 0;
-        c->dev.read_off = ucd[i].read_off; c->dev.first = ucd[i].first; c->dev.last = ucd[i].last; c->dev.cell_snp = ucd[i].snp;
-        c->dev.cell_aw = ucd[i].cell_aw; c->dev.tw = ucd[i].tw; c->dev.meta = ucd[i].meta; c->dev.n_reads = pileups[i].n_reads;
-        out[i] = c;
-    }
-    A->refs = n;
     return 0;
 }
 
@@ -999,36 +1095,51 @@ int issue_copies(floria_hip_ctx* ctx, std::vector<CopyRun>& runs, uint64_t* pinn
 extern "C" {
 
 // ---- S1 --------------------------------------------------------------------------------------------------------
-int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
-                                  const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
-                                  uint32_t n_blocks, const floria_params* prm, floria_block_result** out) {
-    if (!ctx || !out || !prm || (n_blocks && (!blk_start || !blk_end || !contigs))) return fail(FLORIA_E_INVALID, "null argument");
-    *out = nullptr;
+}  // extern "C"
+
+namespace {
+
+// What S1 needs to know about its contigs.  With `chunk_ev` the cell arrays of chunk g (contig_chunk[ci] == g) are still on
+// the wire: they are complete once chunk_ev[g] has fired, and the blocks of chunk g form job group g whose stream waits for it
+// (read_off / first / last of every contig are already ordered before the context's main stream).
+struct S1Contigs {
+    std::vector<fl::ContigDev> cdev;
+    uint32_t len_max = 1, nall = 2;
+    bool any_q0 = false;
+    const uint32_t* contig_chunk = nullptr;
+    uint32_t n_chunks = 0;
+    hipEvent_t* chunk_ev = nullptr;
+};
+
+struct Trace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    explicit Trace(bool o) : on(o), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) const { if (on) fprintf(stderr, "[floria_hip trace] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); }
+};
+
+int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
+            uint32_t n_blocks, const floria_params* prm, floria_block_result** out) {
+    const uint32_t n_contigs = (uint32_t)SC.cdev.size();
+    const Trace TR(ctx->knobs.trace);
+    TR.mark("s1_core enter");
     if (prm->max_ploidy < 1 || prm->max_ploidy > FLORIA_MAX_PLOIDY) return fail(FLORIA_E_INVALID, "max_ploidy must be in 1..16");
     if (prm->beam < 1) return fail(FLORIA_E_INVALID, "beam (max_number_solns) must be >= 1");
     if (!(prm->epsilon > 0.0 && prm->epsilon < 1.0)) return fail(FLORIA_E_INVALID, "epsilon must be in (0,1)");
-    HIPCHK(hipSetDevice(ctx->device));
     ctx->timing = floria_timing{};
     ctx->batch_token = 0;
     const uint32_t P = prm->max_ploidy;
 
     // ---- block read lists: find_reads_in_interval on the device (blocks_kernel.h) -------------------------------
     std::vector<uint32_t> bc(n_blocks, 0);
-    uint32_t n_max = 1, span_max = 1, len_max = 1, nall = 2;
-    bool any_q0 = false;
+    uint32_t n_max = 1, span_max = 1;
+    const uint32_t len_max = SC.len_max, nall = SC.nall;
+    const bool any_q0 = SC.any_q0;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         const uint32_t ci = blk_contig ? blk_contig[b] : 0;
-        if (ci >= n_contigs || !contigs[ci]) return fail(FLORIA_E_INVALID, "blk_contig out of range");
-        if (contigs[ci]->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
+        if (ci >= n_contigs) return fail(FLORIA_E_INVALID, "blk_contig out of range");
         bc[b] = ci;
     }
-    for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) {
-        len_max = std::max(len_max, contigs[i]->max_len);
-        nall = std::max(nall, contigs[i]->n_alleles);
-        any_q0 = any_q0 || contigs[i]->has_q0;
-    }
-    std::vector<fl::ContigDev> cdev(n_contigs);
-    for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) cdev[i] = contigs[i]->dev;
+    const std::vector<fl::ContigDev>& cdev = SC.cdev;
     struct Seg { size_t off, bytes; };
     size_t cursor = 0;
     auto seg = [&](size_t bytes) { Seg s{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return s; };
@@ -1063,6 +1174,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
         HIPCHK(hipMemcpyAsync(blk_bytes.data(), sa.bytes, 8ull * n_blocks, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
+    TR.mark("block counts on the host");
     uint64_t algo_bytes = 0;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         roff[b + 1] = roff[b] + cnt[b];
@@ -1074,15 +1186,29 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     std::vector<uint32_t> jobs;
     for (uint32_t b = 0; b < n_blocks; ++b) if (cnt[b]) jobs.push_back(b);
     std::stable_sort(jobs.begin(), jobs.end(), [&](uint32_t a, uint32_t b2) { return cnt[a] > cnt[b2]; });
-    // job groups (longest-first inside each group, dealt round-robin so every group sees the same size mix)
+    // job groups (longest-first inside each group).  Resident inputs: dealt round-robin so every group sees the same size mix.
+    // Chunked inputs (cells still arriving): group g = the blocks of chunk g, whose stream waits for the chunk's event.
+    const bool chunked = SC.chunk_ev != nullptr && SC.n_chunks > 1;
     uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : 2;
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
+    if (chunked) G = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
+    std::vector<uint32_t> group_off(G + 1, 0);
+    if (chunked) {
+        std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
+        for (uint32_t g = 0; g < G; ++g) { for (uint32_t b : jobs) if (std::min(SC.contig_chunk[bc[b]], G - 1) == g) dealt.push_back(b); group_off[g + 1] = (uint32_t)dealt.size(); }
+        jobs.swap(dealt);
+    } else if (G > 1) {
+        std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
+        for (uint32_t g = 0; g < G; ++g) { for (size_t j = g; j < jobs.size(); j += G) dealt.push_back(jobs[j]); group_off[g + 1] = (uint32_t)dealt.size(); }
+        jobs.swap(dealt);
+    } else group_off[1] = (uint32_t)jobs.size();
     // ploidy stages (run_phase): one ploidy per stage unless the batch is too small to fill the chip with (block, ploidy) jobs
     std::vector<std::vector<uint32_t>> stages;
     {
         int spec = ctx->knobs.speculate;
         const bool slab_path = P * prm->beam <= 63 && !ctx->knobs.beam_path;          // the wide-beam kernels own whole CUs: nothing to gain there
         if (spec < 0) spec = (slab_path && G == 1 && P >= 3 && jobs.size() * 3 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
+        if (chunked) spec = 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
@@ -1091,12 +1217,6 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     }
     uint32_t stage_w = 1;
     for (auto& st : stages) stage_w = std::max<uint32_t>(stage_w, (uint32_t)st.size());
-    std::vector<uint32_t> group_off(G + 1, 0);
-    if (G > 1) {
-        std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
-        for (uint32_t g = 0; g < G; ++g) { for (size_t j = g; j < jobs.size(); j += G) dealt.push_back(jobs[j]); group_off[g + 1] = (uint32_t)dealt.size(); }
-        jobs.swap(dealt);
-    } else group_off[1] = (uint32_t)jobs.size();
 
     rc = ensure_binom(ctx, prm->epsilon, len_max); if (rc) return rc;
     if (span_max > fl::HASH_M) return fail(FLORIA_E_UNSUPPORTED, "a block's reads span more than 65536 SNPs");
@@ -1105,23 +1225,18 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     // ---- device staging of the per-call arrays ----------------------------------------------------------------------
     cursor = 0;
     const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg((uint64_t)stage_w * (tot + 16)),
+              s_margin = seg(8ull * n_blocks * P + 16),
+              // zero-initialised, contiguous (ONE memset): partition output, mec / num_alleles / iters, stop-rule state, queue counters, diagnostics
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
-              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_q = seg(8 * floria_hip_ctx::MAX_LANES + 16), s_margin = seg(8ull * n_blocks * P + 16),
-              s_diag = seg(16 + 8 * 32), s_steps = seg(16);
+              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4),
+              s_q = seg(8ull * floria_hip_ctx::MAX_LANES * FLORIA_MAX_PLOIDY + 16), s_diag = seg(16 + 8 * 32), s_steps = seg(16);
+    const size_t zero_bytes = cursor - s_out.off;
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
     char* M = ctx->misc.as<char>();
     th = T.begin(K_H2D);
     HIPCHK(hipMemcpyAsync(M0 + s_roff.off, roff.data(), 8ull * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream));
     if (!jobs.empty()) HIPCHK(hipMemcpyAsync(M + s_jobs.off, jobs.data(), 4ull * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_mec.off, 0, s_mec.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_na.off, 0, s_na.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_it.off, 0, s_it.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_done.off, 0, s_done.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_best.off, 0, s_best.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_tried.off, 0, s_tried.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_out.off, 0, s_out.bytes, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_diag.off, 0, 16 + 8 * 32, ctx->stream));
-    HIPCHK(hipMemsetAsync(M + s_steps.off, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(M + s_out.off, 0, zero_bytes, ctx->stream));
     const double inf = std::numeric_limits<double>::infinity();
     T.end(th);
     if (n_blocks) {
@@ -1156,10 +1271,11 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     bool p1_shortcut = false;
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
     rc = run(ctx, any_q0, bs, jobs, group_off, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
-             (uint8_t*)(M + s_bpart.off), stages, (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
+             (uint8_t*)(M + s_bpart.off), stages, chunked ? SC.chunk_ev : nullptr, (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
              (double*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
     if (rc) { sync_all(ctx); return rc; }
+    TR.mark("every launch queued");
     int t_rids = -1;
     if (n_blocks && tot) {              // everything is queued: the copy (pageable destination, the host may block here) overlaps the kernels
         HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rids, 0));
@@ -1195,6 +1311,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
     if (e != hipSuccess) { sync_all(ctx); return fail(FLORIA_E_DEVICE, std::string("phase_blocks: ") + hipGetErrorString(e)); }
+    TR.mark("results on the host");
     if (diag[1]) { return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
 #ifdef FLORIA_PROF
     { unsigned long long prof[32]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
@@ -1220,6 +1337,118 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     ctx->last_bs = bs; ctx->last_part = (const uint8_t*)(M + s_out.off); ctx->last_best = (const uint32_t*)(M + s_best.off); ctx->last_nall = nall;
     ctx->last_bc = bc; ctx->last_start.assign(blk_start, blk_start + n_blocks); ctx->last_end.assign(blk_end, blk_end + n_blocks);
     guard.r = nullptr;
+    *out = R;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* contigs, uint32_t n_contigs,
+                                  const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
+                                  uint32_t n_blocks, const floria_params* prm, floria_block_result** out) {
+    if (!ctx || !out || !prm || (n_blocks && (!blk_start || !blk_end || !contigs))) return fail(FLORIA_E_INVALID, "null argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    S1Contigs SC;
+    SC.cdev.resize(n_contigs);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t ci = blk_contig ? blk_contig[b] : 0;
+        if (ci >= n_contigs || !contigs[ci]) return fail(FLORIA_E_INVALID, "blk_contig out of range");
+    }
+    for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) {
+        if (contigs[i]->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
+        SC.cdev[i] = contigs[i]->dev;
+        SC.len_max = std::max(SC.len_max, contigs[i]->max_len);
+        SC.nall = std::max(SC.nall, contigs[i]->n_alleles);
+        SC.any_q0 = SC.any_q0 || contigs[i]->has_q0;
+    }
+    return s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, out);
+}
+
+// S1 straight from host pileups: floria_hip_contig_upload_batch + floria_hip_phase_blocks_batch as ONE pipelined call.  The
+// small arrays (read_off, first, last) go first, so find_reads_in_interval and the launch plan are made while the cell arrays
+// are still on the wire; the cells travel in chunks of consecutive contigs on the copy stream, each followed by its validate +
+// flatten launch, and the blocks of chunk g form job group g, whose kernels start when the chunk has landed.  The PCIe time
+// of all but the first chunk hides behind the kernels of the earlier ones.  The launch plan is made for biallelic pileups
+// without q = 0 cells (known only once every chunk has been validated); a batch that turns out otherwise is phased again from
+// its — by then resident — contigs with the matching kernels, so results never depend on the route.
+int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n_contigs,
+                                   const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
+                                   const floria_params* prm, floria_block_result** out, floria_hip_contig** keep) {
+    if (!ctx || !out || !prm || (n_contigs && !pileups) || (n_blocks && (!blk_start || !blk_end))) return fail(FLORIA_E_INVALID, "null argument");
+    *out = nullptr;
+    if (keep) for (uint32_t i = 0; i < n_contigs; ++i) keep[i] = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (uint32_t b = 0; b < n_blocks; ++b) if ((blk_contig ? blk_contig[b] : 0) >= n_contigs) return fail(FLORIA_E_INVALID, "blk_contig out of range");
+    if (n_contigs == 0) { S1Contigs SC; return s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, out); }
+    uint64_t cells = 0;
+    for (uint32_t i = 0; i < n_contigs; ++i) if (pileups[i].n_reads && pileups[i].read_off) cells += pileups[i].read_off[pileups[i].n_reads];
+    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, cells * 6 / (192ull << 20)));
+    UploadPlan UP;
+    int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(want_chunks, floria_hip_ctx::MAX_GROUPS), UP);
+    if (rc) return rc;
+    std::vector<floria_hip_contig*> handles(n_contigs, nullptr);
+    auto drop = [&](int code) { sync_all(ctx); for (auto* h : handles) if (h) { h->arena = nullptr; delete h; } arena_put(UP.A); return code; };
+    bool pipelined = UP.all_pinned && UP.n_chunks > 1;
+    uint64_t pinned_b = 0, staged_b = 0;
+    floria_block_result* R = nullptr;
+    if (pipelined) {
+        if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        if (!ctx->flat_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->flat_stream, hipStreamNonBlocking));
+        for (uint32_t g = 0; g <= UP.n_chunks; ++g) {
+            if (!ctx->ev_chunk[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_chunk[g], hipEventDisableTiming));
+            if (!ctx->ev_copied[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_copied[g], hipEventDisableTiming));
+        }
+        rc = issue_copies(ctx, UP.small_runs, &pinned_b, &staged_b);                       // main stream: read_off / first / last + tables
+        hipError_t e = rc ? hipSuccess : issue_tables(ctx, UP, ctx->stream);
+        if (!rc && e == hipSuccess) e = hipEventRecord(ctx->ev_chunk[UP.n_chunks], ctx->stream);
+        if (!rc && e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_chunk[UP.n_chunks], 0);
+        if (!rc && e == hipSuccess) e = hipStreamWaitEvent(ctx->flat_stream, ctx->ev_chunk[UP.n_chunks], 0);
+        for (uint32_t g = 0; g < UP.n_chunks && !rc && e == hipSuccess; ++g) {             // copy stream: the cells of chunk g, back to back with chunk g+1;
+            for (const CopyRun& r : UP.chunk_runs[g]) { pinned_b += r.bytes; if (e == hipSuccess) e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyHostToDevice, ctx->copy_stream); }
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev_copied[g], ctx->copy_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->flat_stream, ctx->ev_copied[g], 0);       // flatten stream: validate + flatten chunk g
+            if (e == hipSuccess) e = launch_flatten(ctx, UP, g, ctx->flat_stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev_chunk[g], ctx->flat_stream);
+        }
+        if (!rc && e != hipSuccess) rc = fail(FLORIA_E_DEVICE, std::string("pipelined upload: ") + hipGetErrorString(e));
+        if (rc) return drop(rc);
+        S1Contigs SC;
+        SC.cdev.resize(n_contigs);
+        for (uint32_t i = 0; i < n_contigs; ++i) {
+            fl::ContigDev& d = SC.cdev[i];
+            d.read_off = UP.ucd[i].read_off; d.first = UP.ucd[i].first; d.last = UP.ucd[i].last; d.cell_snp = UP.ucd[i].snp;
+            d.cell_aw = UP.ucd[i].cell_aw; d.tw = UP.ucd[i].tw; d.meta = UP.ucd[i].meta; d.n_reads = pileups[i].n_reads;
+        }
+        SC.len_max = BINOM_NMAX_CAP; SC.nall = 2; SC.any_q0 = false;                      // optimistic plan, verified below
+        SC.contig_chunk = UP.contig_chunk.data(); SC.n_chunks = UP.n_chunks; SC.chunk_ev = ctx->ev_chunk;
+        rc = s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, &R);
+        if (rc) return drop(rc);
+        const floria_timing tm = ctx->timing;
+        hipError_t e2 = hipMemcpy(UP.ust.data(), UP.T + UP.t_st, sizeof(fl::UploadStatus) * n_contigs, hipMemcpyDeviceToHost);
+        if (e2 != hipSuccess) { floria_hip_block_result_free(R); return drop(fail(FLORIA_E_DEVICE, std::string("upload status: ") + hipGetErrorString(e2))); }
+        rc = finish_upload(ctx, UP, pileups, handles.data());
+        if (rc) { floria_hip_block_result_free(R); for (auto*& h : handles) h = nullptr; return drop(rc); }
+        bool plan_ok = true;
+        for (auto* h : handles) plan_ok = plan_ok && h->n_alleles == 2 && !h->has_q0;
+        if (!plan_ok) {                                                                   // rare: phase again with the kernels this batch needs
+            floria_hip_block_result_free(R); R = nullptr;
+            rc = floria_hip_phase_blocks_batch(ctx, handles.data(), n_contigs, blk_contig, blk_start, blk_end, n_blocks, prm, &R);
+            if (rc) { for (auto* h : handles) floria_hip_contig_free(h); return rc; }
+        } else ctx->timing = tm;
+    } else {
+        arena_put(UP.A);                                                                  // (back to the cache: the plain upload takes it from there)
+        rc = floria_hip_contig_upload_batch(ctx, pileups, n_contigs, handles.data());
+        if (rc) return rc;
+        pinned_b = ctx->timing.upload_pinned_bytes; staged_b = ctx->timing.upload_staged_bytes;
+        rc = floria_hip_phase_blocks_batch(ctx, handles.data(), n_contigs, blk_contig, blk_start, blk_end, n_blocks, prm, &R);
+        if (rc) { for (auto* h : handles) floria_hip_contig_free(h); return rc; }
+    }
+    ctx->timing.upload_pinned_bytes = pinned_b; ctx->timing.upload_staged_bytes = staged_b; ctx->timing.upload_chunks = pipelined ? UP.n_chunks : 1;
+    if (keep) for (uint32_t i = 0; i < n_contigs; ++i) keep[i] = handles[i];
+    else { for (auto* h : handles) floria_hip_contig_free(h); ctx->batch_token = 0; R->batch_token = 0; }     // nothing stays resident: no hap graph for this batch
     *out = R;
     return 0;
 }

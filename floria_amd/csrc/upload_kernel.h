@@ -39,7 +39,8 @@ struct UploadArgs {
     const uint32_t* w24;           // [256]
     const uint64_t *Rq1, *Rq2;     // [4*HASH_M]
     uint32_t n_contigs, pad;
-    uint64_t n_reads_total;
+    uint64_t read_base;            // global index of the launch's first read (read_prefix holds global indices)
+    uint64_t n_reads_total;        // reads of this launch
 };
 
 template <int CTRL> __device__ __forceinline__ uint64_t up_dpp64(uint64_t x) {
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void flatten_kernel(UploadArgs g) {
     s_w24[threadIdx.x] = g.w24[threadIdx.x];
     __syncthreads();
     const uint32_t sub = threadIdx.x & 15;
-    const uint64_t gr = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = gr < g.n_reads_total;
+    const uint64_t lr = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4), gr = g.read_base + lr;
+    const bool live = lr < g.n_reads_total;
     // contig of this read: last prefix <= gr  (the 16 lanes of a read search identically; n_contigs is a few thousand at most)
     uint32_t lo = 0, hi = g.n_contigs;
     while (live && hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }

@@ -27,7 +27,7 @@ SYMBOLS = [
     "floria_hip_hap_graph", "floria_hip_hap_graph_free", "floria_hip_reassign_ordered", "floria_hip_haploset_stats",
     "floria_hip_hapq", "floria_hip_hapq_batch",
     "floria_hip_contig_upload_batch", "floria_hip_host_alloc", "floria_hip_host_free", "floria_hip_set_option",
-    "floria_hip_contig_download",
+    "floria_hip_contig_download", "floria_hip_phase_pileups_batch",
 ]
 
 
@@ -294,6 +294,22 @@ class FloriaHip:
         res = capi.BlockResult(out.contents) if copy_out else None
         load().floria_hip_block_result_free(out)
         return res
+
+    def phase_pileups_batch(self, pileups, blk_contig, blk_start, blk_end, params, keep=False, copy_out=True):
+        """floria_hip_phase_pileups_batch: S1 straight from host pileups (a list of Pileups or a prebuilt c_pileups array),
+        transfers pipelined with the kernels.  Returns the BlockResult, or (BlockResult, ContigBatch) with keep=True."""
+        carr = pileups if isinstance(pileups, C.Array) else c_pileups(pileups)
+        n = len(carr)
+        bc = np.ascontiguousarray(blk_contig, np.uint32)
+        bs = np.ascontiguousarray(blk_start, np.uint32)
+        be = np.ascontiguousarray(blk_end, np.uint32)
+        out = C.POINTER(capi.CBlockResult)()
+        hs = (C.c_void_p * n)() if keep else None
+        _check(load().floria_hip_phase_pileups_batch(self._h, carr, C.c_uint32(n), capi.ptr(bc, C.c_uint32), capi.ptr(bs, C.c_uint32),
+                                                     capi.ptr(be, C.c_uint32), C.c_uint32(len(bs)), C.byref(params), C.byref(out), hs))
+        res = capi.BlockResult(out.contents) if copy_out else None
+        load().floria_hip_block_result_free(out)
+        return (res, ContigBatch(self, hs, n)) if keep else res
 
     def hap_graph(self, res):
         """HapNode::new coverage + update_hap_graph out_weights (graph_processing.rs:22-100) for the batch that produced

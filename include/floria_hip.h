@@ -137,6 +137,8 @@ typedef struct {
     double   phase_ms;         /* wall time of the per-ploidy launch loop (fork of the first group -> join of the last) */
     uint64_t upload_pinned_bytes; /* last upload: bytes that went by DMA straight from the caller's pinned memory */
     uint64_t upload_staged_bytes; /* last upload: bytes staged through the library's pinned ring (pageable sources)  */
+    uint32_t upload_chunks;    /* floria_hip_phase_pileups_batch: chunks whose transfer overlapped the kernels (1 = not pipelined) */
+    uint32_t reserved;
 } floria_timing;
 
 typedef struct floria_hip_ctx floria_hip_ctx;
@@ -193,6 +195,17 @@ int  floria_hip_phase_blocks(floria_hip_ctx* ctx, const floria_pileup* pileup,
                              const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
                              const floria_params* params, floria_block_result** out);
 void floria_hip_block_result_free(floria_block_result* r);
+
+/* S1 straight from HOST pileups for many contigs: upload_batch + phase_blocks_batch as one pipelined call — the timed region of
+ * the reference's "Phasing time taken" span (floria.rs:330-337) with the pileups in host memory.  The cell arrays travel in
+ * chunks of consecutive contigs and the blocks of a chunk start phasing when the chunk has landed, so most of the PCIe time
+ * hides behind the kernels (needs sources in floria_hip_host_alloc memory; pageable sources are uploaded first, then phased).
+ * keep == NULL: nothing stays resident.  keep != NULL: keep[0..n_contigs) receive the resident handles (floria_hip_contig_free
+ * each), e.g. for floria_hip_hap_graph / S2 on the same batch.  Results are identical to upload + phase_blocks_batch. */
+int  floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n_contigs,
+                                    const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
+                                    uint32_t n_blocks, const floria_params* params, floria_block_result** out,
+                                    floria_hip_contig** keep);
 
 /* S1 over MANY contigs in one launch sequence (the unit bench.py times: all blocks of all
  * contigs a rank owns are phased together so the device sees >> 256 concurrent jobs).
@@ -264,7 +277,8 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
 /* Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy
  * stages: -1 auto, 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}), "beam_path" (0 auto,
  * 1 generic, 2 fast, 3 slab, 4 wide), "no_specialized", "no_p1_shortcut", "opt_threads" (0|128|512|1024), "opt_global",
- * "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload). */
+ * "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload), "upload_chunks" (chunks of
+ * floria_hip_phase_pileups_batch, 0 = auto). */
 int  floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -151,7 +151,7 @@ def test_device_validation_reports_what_the_contract_says(gpu_ctx, hip_lib):
         (pile([0, 2], [1, 2], [0, 4], [9, 9], [1], [2]), -4, "allele index > 3"),
         (pile([0, 1, 2], [5, 3], [0, 0], [20, 20], [5, 3], [5, 3]), -1, "Frag::cmp"),
         (pile([0, 2, 4], [1, 4, 1, 5], [0, 0, 0, 0], [9, 9, 9, 9], [1, 1], [4, 5]), -1, "Frag::cmp"),       # equal first: last must not ascend
-        (pile([0, 2, 9], [1, 2, 3], [0, 0, 0], [9, 9, 9], [1, 3], [2, 3]), -1, "no cells"),                  # read_off runs past the cells
+        (pile([0, 3, 2], [1, 2, 3], [0, 0, 0], [9, 9, 9], [1, 3], [3, 3]), -1, "no cells"),                  # read_off not monotone: a read runs past n_cells = read_off[n_reads]
     ]
     for bad, code, what in cases:
         with pytest.raises(hip_lib.FloriaHipError) as ei:
@@ -193,7 +193,7 @@ def test_job_groups_on_warm_pools_with_few_slots(gpu_ctx, hip_lib):
             for groups in (1, 2, 2, 3, 1):                               # the repeated entries run on warm pools
                 gpu_ctx.set_option("groups", groups)
                 r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
-                assert gpu_ctx.timing()["streams"] == groups
+                assert gpu_ctx.timing()["streams"] == min(groups, len(bc) // 1024)
                 runs.setdefault("ref", r)
                 assert_block_results_equal(runs["ref"], r, f"slots {slots} groups {groups}")
                 assert r.min_prune_margin == runs["ref"].min_prune_margin
@@ -231,3 +231,75 @@ def test_ploidy_stages_do_not_change_results(gpu_ctx, hip_lib, oracle_mod, cfg, 
     assert np.array_equal(ro.mec.view(np.uint64), out[1].mec[:n0].view(np.uint64)) and np.array_equal(ro.ploidies_tried, out[1].ploidies_tried[:n0])
     for r in res:
         r.free()
+
+
+def test_pipelined_upload_and_phase_equals_upload_then_phase(gpu_ctx, hip_lib, oracle_mod):
+    # floria_hip_phase_pileups_batch streams the cell arrays in chunks and starts a chunk's blocks when it has landed; job groups,
+    # chunk count, pinned or pageable sources and the optimistic biallelic plan must not change a single result
+    contigs = [synth.make_config_contig(4, 700 + i) for i in range(96)]
+    piles = [c.pileup for c in contigs]
+    par = hip_lib.make_params(EPS)
+    bc, bs, be = [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
+        bc += [i] * len(s); bs += list(s); be += list(e)
+    res = gpu_ctx.upload_batch(piles)
+    ref = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+    for r in res:
+        r.free()
+    arena, pinned = hip_lib.pin_pileups(piles)
+    try:
+        for chunks in (0, 1, 2, 3, 4):
+            gpu_ctx.set_option("upload_chunks", chunks)
+            got = gpu_ctx.phase_pileups_batch(pinned, bc, bs, be, par)
+            t = gpu_ctx.timing()
+            assert t["upload_chunks"] == (chunks if chunks else t["upload_chunks"]) and t["upload_staged_bytes"] == 0
+            if chunks > 1:
+                assert t["streams"] == chunks
+            assert_block_results_equal(ref, got, f"pipelined, {chunks} chunks")
+            assert got.min_prune_margin == ref.min_prune_margin
+        gpu_ctx.set_option("upload_chunks", 3)
+        got = gpu_ctx.phase_pileups_batch(piles, bc, bs, be, par)                 # pageable: uploaded first, then phased
+        assert gpu_ctx.timing()["upload_chunks"] == 1 and gpu_ctx.timing()["upload_staged_bytes"] > 0
+        assert_block_results_equal(ref, got, "pageable sources")
+        # resident handles come back on request and serve the later stages (hap graph on the still-resident batch)
+        got, kept = gpu_ctx.phase_pileups_batch(pinned, bc, bs, be, par, keep=True)
+        assert_block_results_equal(ref, got, "keep")
+        hg = gpu_ctx.hap_graph(got)
+        again = gpu_ctx.phase_blocks_batch(kept, bc, bs, be, par)
+        assert_block_results_equal(ref, again, "kept handles")
+        hg2 = gpu_ctx.hap_graph(again)
+        assert np.array_equal(hg.edge_w, hg2.edge_w) and np.array_equal(hg.node_cov.view(np.uint64), hg2.node_cov.view(np.uint64))
+        kept.free()
+        # a batch that breaks the optimistic plan (a 4-allele contig and one with q = 0 cells among biallelic ones) is phased again
+        rng = np.random.default_rng(5)
+        odd = [piles[0], random_pileup(rng, 300, 80, 3, max_len=40, alleles=4), piles[1], random_pileup(rng, 200, 50, 2, max_len=25, q0_frac=0.1)]
+        obc, obs, obe = [], [], []
+        for i, p in enumerate(odd):
+            if i in (0, 2):
+                s, e = hip_lib.get_range_with_lengths(contigs[i // 2].snp_pos, 10000)
+            else:
+                S = int(p.last.max()); s, e = [1, S // 2], [S // 2 + 3, S]
+            obc += [i] * len(s); obs += list(s); obe += list(e)
+        oa, op = hip_lib.pin_pileups(odd)
+        gpu_ctx.set_option("upload_chunks", 2)
+        got = gpu_ctx.phase_pileups_batch(op, obc, obs, obe, par)
+        for i, p in enumerate(odd):
+            sel = [k for k in range(len(obc)) if obc[k] == i]
+            ro = oracle_mod.phase_blocks(p, [obs[k] for k in sel], [obe[k] for k in sel], oracle_mod.make_params(EPS), threads=8)
+            lo, hi = int(got.read_off[sel[0]]), int(got.read_off[sel[-1] + 1])
+            assert np.array_equal(ro.best_ploidy, got.best_ploidy[sel[0]:sel[-1] + 1]) and np.array_equal(ro.part, got.part[lo:hi])
+            assert np.array_equal(ro.mec.view(np.uint64), got.mec[sel[0]:sel[-1] + 1].view(np.uint64))
+        # an invalid contig in a late chunk: the call fails as a whole and the context stays usable
+        bad = Pileup(odd[1].read_off.copy(), odd[1].snp.copy(), odd[1].allele.copy(), odd[1].qual.copy(), odd[1].first.copy(), odd[1].last.copy())
+        bad.snp[5:7] = bad.snp[5:7][::-1]
+        ba, bp = hip_lib.pin_pileups([piles[0], piles[1], piles[2], bad])
+        with pytest.raises(hip_lib.FloriaHipError) as ei:
+            gpu_ctx.phase_pileups_batch(bp, [0, 3], [1, 1], [50, 20], par)
+        assert ei.value.code == -1 and "contig 3" in str(ei.value)
+        got = gpu_ctx.phase_pileups_batch(pinned, bc, bs, be, par)
+        assert_block_results_equal(ref, got, "after a failed call")
+        oa.free(); ba.free()
+    finally:
+        gpu_ctx.set_option("upload_chunks", 0)
+    arena.free()
