@@ -142,7 +142,7 @@ struct Knobs {
     uint32_t opt_global = 0;      // optimise histogram in HBM
     int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P}
     uint32_t upload_chunks = 0;   // floria_hip_phase_pileups_batch: chunks the cell arrays travel in (0 = auto by size, <= 8)
-    uint32_t upload_split = 0;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
+    uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
 };
 
@@ -316,6 +316,14 @@ void sync_all(floria_hip_ctx* ctx) {
 // group's launch tail (persistent waves draining their last jobs) is filled by the other group's kernels.
 // A lane (group g, position j inside the stage) owns the SAME byte slice of every scratch pool for the whole call — sized for
 // the largest ploidy — so kernels of different groups/ploidies that are live at the same time can never alias.
+// threshold of the MEC-ratio stop rule for ploidy p (graph_processing.rs:204-220), libm pow as in the reference
+double mec_threshold(const floria_params* prm, uint32_t p) {
+    const double eps = prm->epsilon, pl = (double)p;
+    if (prm->ploidy_sensitivity == 1) return 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 0.50) + 1.00));
+    if (prm->ploidy_sensitivity == 2) return 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1. / 3.));
+    return 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1.00));
+}
+
 struct PloidyPlan {
     uint32_t p = 0, LM = 0;
     bool shortcut = false, wide = false, slab = false, fast = false, beam_spec = false;
@@ -529,6 +537,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.moves_pool = (uint32_t*)(ctx->opt_moves.as<char>() + sl_omoves * lane); a.cand_cap = q.cand_cap;
                     a.mec = d_mec; a.num_alleles = d_na; a.iters = d_iters;
                     a.prof = (unsigned long long*)(d_diag + 4);
+                    a.fuse_select = stage.size() == 1 ? 1 : 0;
+                    a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
+                    a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
                     int t = T.begin(K_OPT, st);
                     auto launch = [&](auto kern) -> hipError_t {
                         if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
@@ -551,16 +562,13 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             }
             // join the stage's extra lanes, then the stop rule for the stage's ploidies in ascending order (graph_processing.rs:198-251)
             for (uint32_t j = 1; j < stage.size(); ++j) { HIPCHK(hipEventRecord(ctx->ev_join[g * W + j], ls[g * W + j])); HIPCHK(hipStreamWaitEvent(s0, ctx->ev_join[g * W + j], 0)); }
-            for (uint32_t j = 0; j < stage.size(); ++j) {
+            for (uint32_t j = 0; j < stage.size() && stage.size() > 1; ++j) {                  // (a one-ploidy stage decided inside optimize_kernel)
                 const uint32_t p = stage[j];
                 fl::SelectArgs s{};
                 s.job_block = gjobs; s.n_jobs = nj; s.ploidy = p; s.max_ploidy = P; s.stopping_heuristic = prm->stopping_heuristic; s.eps = prm->epsilon;
-                const double eps = prm->epsilon, pl = (double)p;    // graph_processing.rs:204-220
-                if (prm->ploidy_sensitivity == 1)      s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 0.50) + 1.00));
-                else if (prm->ploidy_sensitivity == 2) s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1. / 3.));
-                else                                   s.mec_threshold = 1.0 / (1.0 - eps) / (1.0 + 1.0 / (std::pow(pl, 1.00) + 1.00));
+                s.mec_threshold = mec_threshold(prm, p);
                 s.mec = d_mec; s.num_alleles = d_na; s.iters = d_iters; s.blk_done = d_done; s.best_ploidy = d_best; s.tried = d_tried;
-                s.clear_from = (j + 1 == stage.size() && stage.size() > 1) ? 1 : 0;      // last select of a speculative stage: forget the ploidies beyond `tried`
+                s.clear_from = (j + 1 == stage.size()) ? 1 : 0;      // last select of a speculative stage: forget the ploidies beyond `tried`
                 s.stage_last = stage.back();
                 int t = T.begin(K_SEL, s0);
                 hipLaunchKernelGGL(fl::select_kernel, dim3((nj + 255) / 256), dim3(256), 0, s0, s);
@@ -1385,7 +1393,8 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     if (n_contigs == 0) { S1Contigs SC; return s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, out); }
     uint64_t cells = 0;
     for (uint32_t i = 0; i < n_contigs; ++i) if (pileups[i].n_reads && pileups[i].read_off) cells += pileups[i].read_off[pileups[i].n_reads];
-    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, cells * 6 / (192ull << 20)));
+    // auto: ~0.5 GB of host pileup per chunk, at most 5 (measured on BASELINE config 4, 2.65 GB: 5 chunks, the first one half-size, are best)
+    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(5, cells * 6 / (448ull << 20)));
     UploadPlan UP;
     int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(want_chunks, floria_hip_ctx::MAX_GROUPS), UP);
     if (rc) return rc;
@@ -1396,7 +1405,11 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     floria_block_result* R = nullptr;
     if (pipelined) {
         if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        if (!ctx->flat_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->flat_stream, hipStreamNonBlocking));
+        if (!ctx->flat_stream) {                    // highest priority: when wave slots free up, a waiting flatten launch goes first
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&ctx->flat_stream, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreateWithFlags(&ctx->flat_stream, hipStreamNonBlocking)); }
+        }
         for (uint32_t g = 0; g <= UP.n_chunks; ++g) {
             if (!ctx->ev_chunk[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_chunk[g], hipEventDisableTiming));
             if (!ctx->ev_copied[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_copied[g], hipEventDisableTiming));

@@ -45,6 +45,14 @@ struct OptArgs {
     double*   num_alleles;       // [n_blocks*max_ploidy]
     uint32_t* iters;             // [n_blocks*max_ploidy]   optimisation rounds run (diagnostic)
     unsigned long long* prof;    // [16] cycle counters per phase (only with -DFLORIA_PROF)
+    // the ploidy stop rule (graph_processing.rs:196-251), applied by the job's workgroup right after its MEC statistics when the
+    // stage holds this ploidy alone (a tiny separate launch between two persistent grids waits for wave slots like a big one)
+    uint32_t  fuse_select;
+    int32_t   stopping_heuristic;
+    double    mec_threshold;     // threshold for THIS ploidy, computed on the host with libm pow (:204-220)
+    uint8_t*  blk_done_w;
+    uint32_t* best_ploidy;
+    uint32_t* tried;
 };
 #ifdef FLORIA_PROF
 #define OPT_TICK(ph) do { __syncthreads(); if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[ph], _t - t_last); t_last = _t; } } while (0)
@@ -403,6 +411,19 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             g.mec[(uint64_t)b * g.max_ploidy + p - 1] = mecv;
             g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] = na;
             g.iters[(uint64_t)b * g.max_ploidy + p - 1] = iters_done;
+            if (g.fuse_select) {                                  // == select_kernel below; only this workgroup touches block b in this launch
+                const double expected = na * g.eps;                                                    // :196
+                uint32_t best = p;
+                bool stop = false;
+                if (p > 1) {
+                    const double mec_prev = g.mec[(uint64_t)b * g.max_ploidy + p - 2];
+                    if ((mecv / mec_prev) < g.mec_threshold) { /* do nothing */ }
+                    else if (g.stopping_heuristic) { best = p - 1; stop = true; }                     // :233-238
+                    if (!stop && mecv < expected) stop = true;                                         // :240-243
+                } else if (mecv < expected) stop = true;                                               // :247-250
+                g.tried[b] = p;
+                if (stop || p == g.max_ploidy) { g.blk_done_w[b] = 1; g.best_ploidy[b] = best; }
+            }
         }
     }
 }
