@@ -6,6 +6,12 @@
 //   floria::generate_hap_graph              graph_processing.rs:325-372   (get_local_hap_blocks per block -> process_chunks ->
 //                                                                          update_hap_graph, all on the device)
 //   floria::process_reads_for_final_parts   part_block_manip.rs:174-274
+//   floria::solve_lp_graph                  solve_flow.rs:195-290          (host; exact min-cost flow, see stitch.cpp)
+//   floria::get_disjoint_paths_rewrite      graph_processing.rs:462-750    (host)
+//   floria::get_frags_in_snpless_gaps       part_block_manip.rs:622-675    (host)
+//   floria::write_outputs                   file_writer.rs:21-84,151-165,308-369,699-993   (.vartigs, .haplosets, vartig_info.txt,
+//                                                                          reads_without_snps.tsv, contig_ploidy_info.tsv)
+//   floria::get_vcf_profile, get_contigs_to_phase, get_frags_from_bamvcf_rewrite, get_fasta_seqs   file_reader.rs (ingest.cpp)
 // Where the reference panics or exits (malformed VCF positions, :422-425) these functions throw floria::Error carrying the
 // library's message.  There is no CPU fallback: constructing a Session without a usable MI355X throws.
 #pragma once
@@ -32,13 +38,21 @@ struct Error : std::runtime_error {
 
 // The hot-path fields of `Options` (types_structs.rs:20-51) with the CLI defaults (parse_cmd_line.rs)
 struct Options {
-    double epsilon = 0.04;
+    std::string bam_file, vcf_file, reference_fasta, out_dir = "floria_out_dir";     // -b -v -r -o
+    double epsilon = 0.04;              // -e (auto-estimated from the BAM when absent, parse_cmd_line.rs:72-90)
     size_t max_number_solns = 10;       // -n
     size_t max_ploidy = 5;              // -p
-    size_t block_length = 15000;        // -l
+    size_t block_length = 15000;        // -l (auto-estimated when absent)
     double snp_density = 0.0005;        // -d
-    bool stopping_heuristic = true;
+    bool stopping_heuristic = true;     // !--no-stop-heuristic
     uint8_t ploidy_sensitivity = 2;     // -s
+    size_t num_threads = 10;            // -t (accepted; the blocks run on the GPU)
+    size_t snp_count_filter = 100;      // --snp-count-filter
+    uint8_t mapq_cutoff = 15;           // -m
+    int64_t supp_aln_dist_cutoff = 40000;   // --supp-aln-dist-cutoff
+    bool dont_use_supp_aln = false;     // -X
+    bool overwrite = false;             // --overwrite
+    std::vector<std::string> list_to_phase;   // -G
     bool reassign_short = false;        // hidden flag; not supported (part_block_manip.rs:235-270)
     int device = 0;
 };
@@ -50,6 +64,11 @@ struct Frag {
     std::map<SnpPosition, Genotype> seq_dict;
     std::map<SnpPosition, uint8_t> qual_dict;
     SnpPosition first_position = UINT32_MAX, last_position = 0;
+    // the fields ingest fills for the writers (types_structs.rs:80-84)
+    bool is_paired = false;
+    GnPosition first_pos_base = SIZE_MAX, last_pos_base = SIZE_MAX;      // reference span of the alignment (0-based start, end exclusive)
+    size_t seq_len[2] = {0, 0};                                          // bases of seq_string[0], seq_string[1]
+    std::map<SnpPosition, std::pair<uint8_t, GnPosition>> snp_pos_to_seq_pos;
     void update(SnpPosition snp_pos, Genotype geno, uint8_t qual) {      // update_frag, types_structs.rs:286-324
         seq_dict[snp_pos] = geno; qual_dict[snp_pos] = qual;
         if (snp_pos < first_position) first_position = snp_pos;
@@ -65,7 +84,7 @@ struct Frag {
 // types_structs.rs:155-166
 struct HapNode {
     std::vector<const Frag*> frag_set;                                   // ascending counter_id
-    std::vector<std::pair<size_t, double>> out_edges, in_edges;
+    std::vector<std::pair<size_t, double>> out_edges, in_edges, out_flows;
     size_t column = SIZE_MAX, row = SIZE_MAX, id = SIZE_MAX;
     double cov = 0.0;
     std::pair<SnpPosition, SnpPosition> snp_endpoints;
@@ -102,6 +121,52 @@ std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPositi
     Session& s, const std::vector<std::vector<const Frag*>>& all_joined_path_parts, const std::vector<Frag>& short_frags,
     const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec, const Options& options, const std::vector<GnPosition>& snp_to_genome_pos,
     const std::vector<uint32_t>* visit_order = nullptr);
+
+// solve_flow.rs: FlowUpVec = Vec<((column, row), (column, row), flow)>
+struct FlowUpdate { std::pair<size_t, size_t> n1, n2; double flow; };
+typedef std::vector<FlowUpdate> FlowUpVec;
+FlowUpVec solve_lp_graph(const std::vector<std::vector<HapNode>>& hap_graph);
+std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPosition, SnpPosition>>> get_disjoint_paths_rewrite(
+    std::vector<std::vector<HapNode>>& hap_graph, const FlowUpVec& flow_update_vec, const Options& options);
+std::vector<const Frag*> get_frags_in_snpless_gaps(const std::vector<std::pair<SnpPosition, SnpPosition>>& path_parts, const std::vector<GnPosition>& snp_to_gn_pos,
+                                                   const std::vector<Frag>& snpless_frags, GnPosition block_len, const std::vector<Frag>& final_frags);
+
+// file_writer.rs:21-84.  `out_bam_part_dir` is the contig's output directory (its path is part of every HAP header), `options.out_dir`
+// holds contig_ploidy_info.tsv (appended to; the header is written by write_run_files).  --output-reads (fastq) is not supported.
+void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec,
+                   const std::string& out_bam_part_dir, const std::string& prefix, const std::string& contig, const std::vector<GnPosition>& snp_pos_to_genome_pos,
+                   const Options& options, const std::vector<const Frag*>& snpless_frags, size_t contig_len);
+// parse_cmd_line.rs:116-135: create the output directory (it must not exist unless --overwrite), cmd.log, contig_ploidy_info.tsv header
+void write_run_files(const Options& options, int argc, char** argv);
+
+// ---- ingest (file_reader.rs) ---------------------------------------------------------------------------------------------------
+struct VcfProfile {          // types_structs.rs:53-58, per contig; plus get_genotypes_from_vcf_hts' position vectors (:113-175)
+    std::map<std::string, std::map<GnPosition, std::vector<Genotype>>> vcf_pos_allele_map;
+    std::map<std::string, std::map<GnPosition, SnpPosition>> vcf_pos_to_snp_counter_map;
+    std::map<std::string, std::map<SnpPosition, GnPosition>> vcf_snp_pos_to_gn_pos_map;
+    std::map<std::string, std::vector<GnPosition>> snp_to_genome_pos;
+};
+struct BamRecord {
+    int32_t tid = -1, pos = 0;
+    uint8_t mapq = 0;
+    uint16_t flags = 0;
+    std::string qname;
+    std::vector<uint32_t> cigar;       // len << 4 | op
+    std::string seq;                   // ASCII bases
+    std::vector<uint8_t> qual;
+};
+struct BamFile {
+    std::vector<std::string> target_names;
+    std::vector<uint64_t> target_len;
+    std::vector<BamRecord> records;    // file order
+};
+BamFile read_bam(const std::string& path);                                             // BGZF + BAM, whole file (no index needed)
+std::vector<std::string> get_contigs_to_phase(const BamFile& bam);                     // file_reader.rs:738-746
+VcfProfile get_vcf_profile(const std::string& vcf_file, const std::vector<std::string>& ref_chroms);       // :239-314 (+ :113-175); text VCF, optionally gzipped
+std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file);      // :462-489 (whole sequences)
+// :343-460 + combine_frags :491-659 + frag_from_record :661-736; no realignment yet (alignment.rs)
+std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vcf_profile, const Options& options, const std::string& contig);
+std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam);                   // :749-826
 
 // part_block_manip.rs:517-616: (hapqs, rel_err per haploset, avg_err) — the HAPQ / REL_ERR header fields and the contig table's avg_err.
 struct HapqResult { std::vector<uint8_t> hapqs; std::vector<double> rel_err; double avg_err; };

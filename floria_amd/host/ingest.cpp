@@ -1,0 +1,419 @@
+// ingest.cpp — BAM / VCF / FASTA -> Frags (file_reader.rs), from scratch on zlib: the reference links htslib, which this image
+// does not have.  What is restated:
+//   get_contigs_to_phase           file_reader.rs:738-746   BAM header target names
+//   get_vcf_profile (+ get_genotypes_from_vcf_hts)   :113-175, :239-314   SNP filter: every allele one character of ACGT (any case)
+//   alignment_passed_check         :179-235
+//   frag_from_record               :661-736   CIGAR walk (rust-htslib aligned_pairs_full), allele = index of the read base in the
+//                                             record's allele list, qual = base quality
+//   combine_frags                  :491-659   pair merge, supplementary merge with the distance cutoff
+//   get_frags_from_bamvcf_rewrite  :343-460   (frags with SNPs, frags without)
+//   get_fasta_seqs                 :462-489   whole sequences (the writers need the contig length)
+//   l_epsilon_auto_detect          :749-826   every 1000th pileup column: minority / majority base ratio, read-length quantile
+// Not restated yet: alignment::realign (alignment.rs:7-64, block-aligner, third-party SIMD arithmetic): alleles are taken as
+// called.  For alignments without indels next to a SNP the realignment returns the called allele anyway.
+// The whole BAM is read once and records are bucketed by contig in file order, so no .bai is needed; `count` (the enumerate
+// index frag_from_record stores in counter_id, which breaks ties of Frag::cmp in all_frags.sort(), floria.rs:289) is the
+// record's index among the contig's records, as with the reference's fetch().
+#include "floria_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <unordered_map>
+
+namespace floria {
+
+namespace {
+
+std::vector<unsigned char> slurp(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error(FLORIA_E_INVALID, "cannot open " + path);
+    return std::vector<unsigned char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+// BGZF = concatenated gzip members; inflate them all
+std::vector<unsigned char> bgzf_inflate_all(const std::vector<unsigned char>& in, const std::string& what) {
+    std::vector<unsigned char> out;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) throw Error(FLORIA_E_NOMEM, "inflateInit2 failed");
+    zs.next_in = const_cast<unsigned char*>(in.data());
+    zs.avail_in = (uInt)std::min<size_t>(in.size(), 0x7fffffffu);
+    size_t consumed_total = 0;
+    std::vector<unsigned char> buf(1 << 20);
+    while (consumed_total < in.size()) {
+        zs.next_out = buf.data(); zs.avail_out = (uInt)buf.size();
+        const unsigned char* before = zs.next_in;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        consumed_total += (size_t)(zs.next_in - before);
+        out.insert(out.end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
+        if (rc == Z_STREAM_END) {
+            if (consumed_total >= in.size()) break;
+            inflateReset(&zs);
+            zs.next_in = const_cast<unsigned char*>(in.data()) + consumed_total;
+            zs.avail_in = (uInt)std::min<size_t>(in.size() - consumed_total, 0x7fffffffu);
+        } else if (rc != Z_OK) { inflateEnd(&zs); throw Error(FLORIA_E_INVALID, what + " is not a valid BGZF/gzip file"); }
+        else if (zs.avail_in == 0 && consumed_total < in.size()) {
+            zs.next_in = const_cast<unsigned char*>(in.data()) + consumed_total;
+            zs.avail_in = (uInt)std::min<size_t>(in.size() - consumed_total, 0x7fffffffu);
+        }
+    }
+    inflateEnd(&zs);
+    return out;
+}
+
+struct Cursor {
+    const unsigned char* p; size_t n, o = 0;
+    const std::string& what;
+    void need(size_t k) const { if (o + k > n) throw Error(FLORIA_E_INVALID, what + " is truncated"); }
+    uint32_t u32() { need(4); uint32_t v; memcpy(&v, p + o, 4); o += 4; return v; }
+    int32_t i32() { return (int32_t)u32(); }
+    uint16_t u16() { need(2); uint16_t v; memcpy(&v, p + o, 2); o += 2; return v; }
+    uint8_t u8() { need(1); return p[o++]; }
+};
+
+constexpr uint16_t F_PAIRED1 = 64, F_PAIRED2 = 128, F_SECONDARY = 256, F_SUPP = 2048, F_ERRORS = 1796;
+
+// alignment_passed_check (file_reader.rs:179-235) -> (passed, is_supp)
+std::pair<bool, bool> alignment_passed_check(uint16_t flags, uint8_t mapq, bool use_supplementary, bool filter_supplementary, uint8_t mapq_cutoff) {
+    const bool is_paired = (flags & F_PAIRED1) || (flags & F_PAIRED2);
+    bool is_supp = false;
+    if (flags & F_SUPP) {
+        is_supp = true;
+        if (is_paired) return {false, true};
+        if (!use_supplementary) return {false, true};
+        if (filter_supplementary && mapq < 60) return {false, true};
+    }
+    if (mapq < mapq_cutoff) return {false, is_supp};
+    if (flags & F_ERRORS) return {false, is_supp};
+    if (flags & F_SECONDARY) return {false, is_supp};
+    return {true, is_supp};
+}
+
+inline int cig_op(uint32_t c) { return (int)(c & 15); }
+inline uint32_t cig_len(uint32_t c) { return c >> 4; }
+// M I D N S H P = X  ->  consumes query / reference
+inline bool consumes_q(int op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+inline bool consumes_r(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+int64_t reference_end(const BamRecord& r) {                 // bam_endpos
+    int64_t len = 0;
+    for (uint32_t c : r.cigar) if (consumes_r(cig_op(c))) len += cig_len(c);
+    return (int64_t)r.pos + (len ? len : 1);
+}
+
+// frag_from_record (file_reader.rs:661-736)
+Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPosition>& snp_positions, const std::map<GnPosition, std::vector<Genotype>>& pos_allele_map, size_t counter_id) {
+    Frag frag;
+    frag.id = rec.qname; frag.counter_id = counter_id;
+    frag.is_paired = (rec.flags & F_PAIRED1) || (rec.flags & F_PAIRED2);
+    frag.first_position = UINT32_MAX; frag.last_position = 0;
+    size_t leading_hardclips = 0;
+    if ((rec.flags & F_SUPP) && !rec.cigar.empty() && cig_op(rec.cigar[0]) == 5) leading_hardclips = cig_len(rec.cigar[0]);
+    frag.first_pos_base = (GnPosition)rec.pos;
+    frag.last_pos_base = (GnPosition)reference_end(rec);
+    size_t q = 0;
+    int64_t r = rec.pos;
+    // the SNPs of the contig the alignment spans: walk them together with the CIGAR (positions ascend in both)
+    auto snp_it = snp_positions.lower_bound((GnPosition)std::max<int64_t>(0, r));
+    for (uint32_t c : rec.cigar) {
+        const int op = cig_op(c);
+        const uint32_t len = cig_len(c);
+        if (op == 0 || op == 7 || op == 8) {                                   // aligned pairs (Some(q), Some(r))
+            while (snp_it != snp_positions.end() && (int64_t)snp_it->first < r) ++snp_it;
+            while (snp_it != snp_positions.end() && (int64_t)snp_it->first < r + (int64_t)len) {
+                const GnPosition genome_pos = snp_it->first;
+                const size_t seq_pos = q + (size_t)((int64_t)genome_pos - r);
+                if (seq_pos < rec.seq.size()) {
+                    const Genotype readbase = (Genotype)rec.seq[seq_pos];
+                    const auto& alleles = pos_allele_map.at(genome_pos);
+                    for (size_t i = 0; i < alleles.size(); ++i)
+                        if (readbase == alleles[i]) {
+                            const SnpPosition snp_pos = snp_it->second;
+                            frag.seq_dict[snp_pos] = (Genotype)i;                  // (a later alignment position of the same SNP overwrites, as insert does)
+                            frag.qual_dict[snp_pos] = seq_pos < rec.qual.size() ? rec.qual[seq_pos] : 255;
+                            if (snp_pos < frag.first_position) frag.first_position = snp_pos;
+                            if (snp_pos > frag.last_position) frag.last_position = snp_pos;
+                            frag.snp_pos_to_seq_pos[snp_pos] = {0, seq_pos + leading_hardclips};
+                            break;
+                        }
+                }
+                ++snp_it;
+            }
+        }
+        if (consumes_q(op)) q += len;
+        if (consumes_r(op)) r += len;                                          // D / N over a SNP: pair[0] is None -> no call
+    }
+    frag.seq_len[0] = rec.seq.size();
+    return frag;
+}
+
+struct Tagged { uint16_t flags; Frag frag; };
+
+}  // namespace
+
+BamFile read_bam(const std::string& path) {
+    const std::vector<unsigned char> raw = bgzf_inflate_all(slurp(path), path);
+    Cursor c{raw.data(), raw.size(), 0, path};
+    c.need(4);
+    if (memcmp(raw.data(), "BAM\1", 4) != 0) throw Error(FLORIA_E_INVALID, path + " is not a BAM file");
+    c.o = 4;
+    const uint32_t l_text = c.u32(); c.need(l_text); c.o += l_text;
+    const uint32_t n_ref = c.u32();
+    BamFile bam;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        const uint32_t l_name = c.u32(); c.need(l_name);
+        bam.target_names.emplace_back((const char*)raw.data() + c.o, l_name ? l_name - 1 : 0); c.o += l_name;
+        bam.target_len.push_back(c.u32());
+    }
+    static const char* SEQ16 = "=ACMGRSVTWYHKDBN";
+    while (c.o < raw.size()) {
+        const uint32_t block_size = c.u32(); c.need(block_size);
+        const size_t end = c.o + block_size;
+        BamRecord r;
+        r.tid = c.i32(); r.pos = c.i32();
+        const uint8_t l_read_name = c.u8(); r.mapq = c.u8(); (void)c.u16();
+        const uint16_t n_cigar = c.u16(); r.flags = c.u16();
+        const uint32_t l_seq = c.u32(); (void)c.i32(); (void)c.i32(); (void)c.i32();
+        c.need(l_read_name); r.qname.assign((const char*)raw.data() + c.o, l_read_name ? l_read_name - 1 : 0); c.o += l_read_name;
+        r.cigar.resize(n_cigar);
+        for (uint16_t k = 0; k < n_cigar; ++k) r.cigar[k] = c.u32();
+        c.need((l_seq + 1) / 2 + l_seq);
+        r.seq.resize(l_seq);
+        for (uint32_t k = 0; k < l_seq; ++k) { const unsigned char b = raw[c.o + k / 2]; r.seq[k] = SEQ16[(k & 1) ? (b & 15) : (b >> 4)]; }
+        c.o += (l_seq + 1) / 2;
+        r.qual.assign(raw.data() + c.o, raw.data() + c.o + l_seq);
+        if (end < c.o + l_seq) throw Error(FLORIA_E_INVALID, path + ": malformed alignment record");
+        c.o = end;                                                             // (auxiliary tags are not needed)
+        bam.records.push_back(std::move(r));
+    }
+    return bam;
+}
+
+std::vector<std::string> get_contigs_to_phase(const BamFile& bam) { return bam.target_names; }
+
+VcfProfile get_vcf_profile(const std::string& vcf_file, const std::vector<std::string>& ref_chroms) {
+    gzFile f = gzopen(vcf_file.c_str(), "rb");                                 // plain text, gzip and bgzip alike
+    if (!f) throw Error(FLORIA_E_INVALID, "cannot open VCF " + vcf_file);
+    VcfProfile vp;
+    std::string line, last_chrom;
+    bool have_last = false;
+    SnpPosition snp_counter = 1;
+    std::vector<char> buf(1 << 16);
+    auto is_acgt = [](char ch) { const char u = (char)(ch & ~0x20); return u == 'A' || u == 'C' || u == 'G' || u == 'T'; };
+    for (;;) {
+        line.clear();
+        bool got = false;
+        while (gzgets(f, buf.data(), (int)buf.size())) { got = true; line += buf.data(); if (!line.empty() && line.back() == '\n') break; }
+        if (!got) break;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (line.empty() || line[0] == '#') {
+            if (line.rfind("BCF", 0) == 0) { gzclose(f); throw Error(FLORIA_E_UNSUPPORTED, "binary BCF input is not supported; convert to VCF"); }
+            continue;
+        }
+        // CHROM POS ID REF ALT ...
+        size_t t[5], k = 0, from = 0;
+        while (k < 5) { const size_t x = line.find('\t', from); if (x == std::string::npos) break; t[k++] = x; from = x + 1; }
+        if (k < 4) continue;
+        const std::string chrom = line.substr(0, t[0]);
+        const long pos1 = strtol(line.c_str() + t[0] + 1, nullptr, 10);
+        const std::string ref = line.substr(t[2] + 1, t[3] - t[2] - 1);
+        const std::string alt = line.substr(t[3] + 1, (k == 5 ? t[4] : line.size()) - t[3] - 1);
+        std::vector<std::string> alleles{ref};
+        if (alt != ".") { size_t a = 0; for (;;) { const size_t x = alt.find(',', a); alleles.push_back(alt.substr(a, x == std::string::npos ? x : x - a)); if (x == std::string::npos) break; a = x + 1; } }
+        const bool known = std::find(ref_chroms.begin(), ref_chroms.end(), chrom) != ref_chroms.end();
+        if (known && (!have_last || last_chrom != chrom)) { snp_counter = 1; last_chrom = chrom; have_last = true; }       // :277-280
+        bool is_snp = true;
+        std::vector<Genotype> al_vec;
+        for (const std::string& a : alleles) {
+            if (a.size() != 1 || !is_acgt(a[0])) { is_snp = false; break; }                                                // :290-300 (an empty allele cannot occur)
+            al_vec.push_back((Genotype)a[0]);
+        }
+        if (!is_snp) continue;
+        const GnPosition pos0 = (GnPosition)(pos1 - 1);                          // htslib's 0-based pos()
+        vp.snp_to_genome_pos[chrom].push_back(pos0);                             // get_genotypes_from_vcf_hts: every contig of the VCF
+        if (!known) continue;
+        vp.vcf_snp_pos_to_gn_pos_map[chrom][snp_counter] = pos0;
+        vp.vcf_pos_to_snp_counter_map[chrom][pos0] = snp_counter;
+        vp.vcf_pos_allele_map[chrom][pos0] = al_vec;
+        ++snp_counter;
+    }
+    gzclose(f);
+    return vp;
+}
+
+std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file) {
+    gzFile f = gzopen(fasta_file.c_str(), "rb");
+    if (!f) throw Error(FLORIA_E_INVALID, "Could not read fasta file " + fasta_file);
+    std::map<std::string, std::string> out;
+    std::string* cur = nullptr;
+    std::vector<char> buf(1 << 16);
+    while (gzgets(f, buf.data(), (int)buf.size())) {
+        size_t n = strlen(buf.data());
+        while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) --n;
+        if (n && buf[0] == '>') {
+            size_t e = 1;
+            while (e < n && buf[e] != ' ' && buf[e] != '\t') ++e;
+            cur = &out[std::string(buf.data() + 1, e - 1)];
+        } else if (cur) cur->append(buf.data(), n);
+    }
+    gzclose(f);
+    return out;
+}
+
+std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vp, const Options& o, const std::string& contig) {
+    const bool filter_supplementary = true, use_supplementary = !o.dont_use_supp_aln;
+    const auto tid_it = std::find(bam.target_names.begin(), bam.target_names.end(), contig);
+    if (tid_it == bam.target_names.end()) return {};
+    const int32_t tid = (int32_t)(tid_it - bam.target_names.begin());
+    const auto& snp_positions = vp.vcf_pos_to_snp_counter_map.at(contig);
+    const auto& pos_allele_map = vp.vcf_pos_allele_map.at(contig);
+    const auto& snp_to_gn = vp.vcf_snp_pos_to_gn_pos_map.at(contig);
+    // read name -> its passing alignments, in record order (the reference fills the buckets from a parallel loop)
+    std::vector<std::string> names;
+    std::unordered_map<std::string, size_t> name_ix;
+    std::vector<std::vector<Tagged>> buckets;
+    size_t count = 0;
+    for (const BamRecord& rec : bam.records) {
+        if (rec.tid != tid) continue;
+        const size_t this_count = count++;
+        if (!alignment_passed_check(rec.flags, rec.mapq, use_supplementary, filter_supplementary, o.mapq_cutoff).first) continue;
+        auto ins = name_ix.emplace(rec.qname, names.size());
+        if (ins.second) { names.push_back(rec.qname); buckets.emplace_back(); }
+        buckets[ins.first->second].push_back({rec.flags, frag_from_record(rec, snp_positions, pos_allele_map, this_count)});
+    }
+    // combine_frags (:491-659)
+    std::vector<Frag> ref_frags;
+    for (auto& frags : buckets) {
+        if (frags.size() == 2 && frags[0].frag.is_paired && frags[1].frag.is_paired) {
+            std::sort(frags.begin(), frags.end(), [](const Tagged& a, const Tagged& b) { return a.flags != b.flags ? a.flags < b.flags : a.frag < b.frag; });
+            Tagged &first = frags[0], &second = frags[1];
+            Frag *ff, *sf;
+            if ((first.flags & F_PAIRED1) == F_PAIRED1) { ff = &first.frag; sf = &second.frag; }
+            else if ((first.flags & F_PAIRED2) == F_PAIRED2) { ff = &second.frag; sf = &first.frag; }
+            else continue;
+            for (auto& kv : sf->seq_dict) ff->seq_dict[kv.first] = kv.second;              // extend: the mate's call overwrites
+            for (auto& kv : sf->qual_dict) ff->qual_dict[kv.first] = kv.second;
+            ff->first_position = std::min(ff->first_position, sf->first_position);
+            ff->last_position = std::max(ff->last_position, sf->last_position);
+            ff->first_pos_base = std::min(ff->first_pos_base, sf->first_pos_base);
+            ff->last_pos_base = std::min(ff->last_pos_base, sf->last_pos_base);           // (min, as in the reference, :547)
+            ff->seq_len[1] = sf->seq_len[0];
+            for (auto& kv : sf->snp_pos_to_seq_pos) ff->snp_pos_to_seq_pos[kv.first] = {1, kv.second.second};
+            ref_frags.push_back(std::move(*ff));
+        } else if (frags.size() == 1 && (frags[0].flags & F_SUPP) == 0) {
+            ref_frags.push_back(std::move(frags[0].frag));
+        } else {
+            std::vector<std::pair<SnpPosition, SnpPosition>> supp_intervals;
+            for (auto& t : frags) if (!t.frag.seq_dict.empty()) supp_intervals.push_back({t.frag.first_position, t.frag.last_position});
+            std::sort(supp_intervals.begin(), supp_intervals.end());
+            bool take_primary_only = false;
+            for (size_t i = 0; i + 1 < supp_intervals.size(); ++i)
+                if ((int64_t)snp_to_gn.at(supp_intervals[i + 1].first) - (int64_t)snp_to_gn.at(supp_intervals[i].second) > o.supp_aln_dist_cutoff) { take_primary_only = true; break; }
+            int primary = -1;
+            for (size_t i = 0; i < frags.size(); ++i) if ((frags[i].flags & F_SUPP) != F_SUPP) primary = (int)i;   // the LAST primary wins (:606-614)
+            if (primary < 0) continue;
+            if (take_primary_only) { ref_frags.push_back(std::move(frags[primary].frag)); continue; }
+            Frag pf = std::move(frags[primary].frag);
+            for (size_t i = 0; i < frags.size(); ++i) {
+                if ((int)i == primary) continue;
+                Frag& fr = frags[i].frag;
+                for (auto& kv : fr.seq_dict) pf.seq_dict[kv.first] = kv.second;
+                for (auto& kv : fr.qual_dict) pf.qual_dict[kv.first] = kv.second;
+                pf.first_position = std::min(pf.first_position, fr.first_position);
+                pf.last_position = std::max(pf.last_position, fr.last_position);
+                pf.first_pos_base = std::min(pf.first_pos_base, fr.first_pos_base);
+                pf.last_pos_base = std::min(pf.last_pos_base, fr.last_pos_base);
+                for (auto& kv : fr.snp_pos_to_seq_pos) pf.snp_pos_to_seq_pos[kv.first] = kv.second;
+            }
+            ref_frags.push_back(std::move(pf));
+        }
+    }
+    std::pair<std::vector<Frag>, std::vector<Frag>> out;
+    for (Frag& f : ref_frags) (f.seq_dict.empty() ? out.second : out.first).push_back(std::move(f));
+    return out;
+}
+
+// file_reader.rs:749-826.  The htslib pileup engine visits every reference position covered by at least one alignment that
+// passes its default mask (unmapped | secondary | qc-fail | duplicate are dropped), contig by contig in coordinate order.
+std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam) {
+    struct Aln { const BamRecord* r; int64_t beg, end; };
+    std::vector<std::vector<Aln>> by_tid(bam.target_names.size());
+    for (const BamRecord& r : bam.records) {
+        if (r.tid < 0 || (size_t)r.tid >= by_tid.size() || (r.flags & F_ERRORS) || r.cigar.empty()) continue;
+        by_tid[r.tid].push_back({&r, r.pos, reference_end(r)});
+    }
+    size_t count = 0;
+    std::vector<double> err_vec;
+    std::vector<size_t> read_lengths;
+    const size_t stop = 1000;
+    bool done = false;
+    auto base_at = [](const BamRecord& r, int64_t pos, char* base) -> bool {          // false: deletion / refskip / not aligned here
+        size_t q = 0; int64_t ref = r.pos;
+        for (uint32_t c : r.cigar) {
+            const int op = cig_op(c); const int64_t len = cig_len(c);
+            if (consumes_r(op) && pos < ref + len) {
+                if (!(op == 0 || op == 7 || op == 8)) return false;
+                const size_t sp = q + (size_t)(pos - ref);
+                if (sp >= r.seq.size()) return false;
+                *base = r.seq[sp];
+                return true;
+            }
+            if (consumes_q(op)) q += (size_t)len;
+            if (consumes_r(op)) ref += len;
+        }
+        return false;
+    };
+    for (auto& alns : by_tid) {
+        if (done) break;
+        std::stable_sort(alns.begin(), alns.end(), [](const Aln& a, const Aln& b) { return a.beg < b.beg; });
+        size_t next = 0;
+        std::vector<Aln> active;
+        int64_t pos = 0;
+        while (!done && (next < alns.size() || !active.empty())) {
+            if (active.empty()) pos = std::max(pos, alns[next].beg);
+            while (next < alns.size() && alns[next].beg <= pos) active.push_back(alns[next++]);
+            active.erase(std::remove_if(active.begin(), active.end(), [&](const Aln& a) { return a.end <= pos; }), active.end());
+            if (active.empty()) continue;
+            // a pileup column at `pos`
+            if (count % 1000 != 0) {
+                // skip ahead: columns are consecutive while the active set is non-empty; stop where the set can change
+                int64_t lim = INT64_MAX;
+                for (const Aln& a : active) lim = std::min(lim, a.end);
+                if (next < alns.size()) lim = std::min(lim, alns[next].beg);
+                const int64_t cols = std::max<int64_t>(1, lim - pos);
+                const int64_t to_sample = 1000 - (int64_t)(count % 1000);
+                const int64_t step = std::min(cols, to_sample);
+                count += (size_t)step; pos += step;
+                continue;
+            }
+            double most_base = 0., total_c = 0.;
+            double base_cnt[256] = {0};
+            for (const Aln& a : active) {
+                char b;
+                if (!base_at(*a.r, pos, &b)) continue;
+                if ((a.r->flags & F_ERRORS) || (a.r->flags & F_SECONDARY) || a.r->seq.empty()) continue;
+                read_lengths.push_back(a.r->seq.size());
+                base_cnt[(unsigned char)b] += 1.;
+            }
+            for (double v : base_cnt) { if (v > most_base) most_base = v; total_c += v; }
+            ++pos;
+            if (total_c < 5.) continue;                                      // (count is not advanced: the next column is sampled too)
+            err_vec.push_back((total_c - most_base) / most_base);
+            if (err_vec.size() >= stop && !read_lengths.empty()) { done = true; break; }
+            ++count;
+        }
+    }
+    std::sort(read_lengths.begin(), read_lengths.end());
+    if (read_lengths.empty()) return {500, 0.01};
+    const size_t q_66 = read_lengths[read_lengths.size() * 66 / 100];
+    std::sort(err_vec.begin(), err_vec.end());
+    const double med66 = err_vec.empty() ? 0.0 : err_vec[err_vec.size() * 66 / 100];
+    return {std::max<size_t>(q_66, 500), std::max(med66, 0.01)};             // constants::MINIMUM_BLOCK_SIZE = 500
+}
+
+}  // namespace floria

@@ -1,0 +1,215 @@
+// floria-hip — command-line driver with the reference's flags (floria.rs:21-196, parse_cmd_line.rs:11-196) and its per-contig
+// flow (floria.rs:229-388): ingest -> generate_hap_graph (device) -> solve_lp_graph -> get_disjoint_paths_rewrite ->
+// process_reads_for_final_parts (device) -> get_frags_in_snpless_gaps -> write_outputs.
+//
+//   floria-hip -b reads.bam -v calls.vcf -r reference.fa -o results [-e 0.04] [-l 10000] [-n 10] [-p 5] [-d 0.0005] [-s 2] [-m 15]
+//              [-t 10] [-G contig ...] [-X] [--no-stop-heuristic] [--snp-count-filter 100] [--supp-aln-dist-cutoff 40000] [--overwrite]
+//
+// Flags of the reference that are not supported and say so: -H/--hybrid, --reassign-short, --bin-by-cov, --output-reads,
+// --gzip-reads, --extra-trimming, --ignore-monomorphic, -q (accepted and ignored by the reference too).  Extras: --device N,
+// --dump-frags FILE (the ingested Frags as text, for tests).
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+
+#include "floria_host.hpp"
+
+using namespace floria;
+
+namespace {
+
+void usage() {
+    fputs("floria-hip - strain phasing for short or long-read shotgun metagenomic sequencing (MI355X build of floria's phasing path).\n\n"
+          "Example usage :\nfloria-hip -b bamfile.bam -v vcffile.vcf -r reference.fa -o results -t 10\n", stderr);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    bool have_e = false, have_l = false;
+    std::string dump_frags;
+    bool ingest_only = false;
+    std::string stitch_graph;
+    bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
+    try {
+        for (int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error(FLORIA_E_INVALID, "missing value for " + a); return argv[++i]; };
+            if (a == "-b") o.bam_file = val();
+            else if (a == "-v") o.vcf_file = val();
+            else if (a == "-r") o.reference_fasta = val();
+            else if (a == "-o" || a == "--output-dir") o.out_dir = val();
+            else if (a == "-t" || a == "--threads") o.num_threads = (size_t)std::stoul(val());
+            else if (a == "-e" || a == "--epsilon") { o.epsilon = std::stod(val()); have_e = true; }
+            else if (a == "-n" || a == "--beam-solns") o.max_number_solns = (size_t)std::stoul(val());
+            else if (a == "-p" || a == "--max-ploidy") o.max_ploidy = (size_t)std::stoul(val());
+            else if (a == "-l" || a == "--block-length") { o.block_length = (size_t)std::stoul(val()); have_l = true; }
+            else if (a == "-d" || a == "--snp-density") o.snp_density = std::stod(val());
+            else if (a == "-s" || a == "--ploidy-sensitivity") o.ploidy_sensitivity = (uint8_t)std::stoul(val());
+            else if (a == "-m" || a == "--mapq-cutoff") o.mapq_cutoff = (uint8_t)std::stoul(val());
+            else if (a == "--snp-count-filter") o.snp_count_filter = (size_t)std::stoul(val());
+            else if (a == "--supp-aln-dist-cutoff") o.supp_aln_dist_cutoff = std::stoll(val());
+            else if (a == "-X" || a == "--no-supp") o.dont_use_supp_aln = true;
+            else if (a == "--no-stop-heuristic") o.stopping_heuristic = false;
+            else if (a == "--overwrite") o.overwrite = true;
+            else if (a == "--debug" || a == "--trace") debug = true;
+            else if (a == "-q") {}
+            else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
+            else if (a == "--device") o.device = std::stoi(val());
+            else if (a == "--dump-frags") dump_frags = val();
+            else if (a == "--ingest-only") ingest_only = true;          // (tests) stop after ingest: needs no GPU
+            else if (a == "--stitch-graph") stitch_graph = val();       // (tests) N / E lines of a hap graph -> F / P lines on stdout: needs no GPU
+            else if (a == "-h" || a == "--help") { usage(); return 0; }
+            else if (a == "-H" || a == "--hybrid" || a == "--reassign-short" || a == "--bin-by-cov" || a == "--output-reads" || a == "--gzip-reads" ||
+                     a == "--extra-trimming" || a == "--ignore-monomorphic")
+                throw Error(FLORIA_E_UNSUPPORTED, "option " + a + " of floria is not supported by floria-hip");
+            else throw Error(FLORIA_E_INVALID, "unknown option " + a);
+        }
+        if (!stitch_graph.empty()) {
+            // hap graph in the format of debug_graph.txt (N: column row id cov lo hi reads..., E: column row row2 weight)
+            std::ifstream in(stitch_graph);
+            if (!in) throw Error(FLORIA_E_INVALID, "cannot open " + stitch_graph);
+            std::vector<std::vector<HapNode>> hg;
+            std::vector<Frag> frags;
+            std::vector<std::vector<std::vector<size_t>>> node_reads;
+            std::string tag;
+            size_t max_read = 0;
+            struct EdgeIn { size_t c, r, r2; double w; };
+            std::vector<EdgeIn> edges;
+            std::string line;
+            while (std::getline(in, line)) {
+                std::istringstream ls(line);
+                ls >> tag;
+                if (tag == "N") {
+                    size_t c, r, id; double cov; SnpPosition lo, hi;
+                    ls >> c >> r >> id >> cov >> lo >> hi;
+                    if (hg.size() <= c) { hg.resize(c + 1); node_reads.resize(c + 1); }
+                    if (hg[c].size() <= r) { hg[c].resize(r + 1); node_reads[c].resize(r + 1); }
+                    HapNode& n = hg[c][r];
+                    n.column = c; n.row = r; n.id = id; n.cov = cov; n.snp_endpoints = {lo, hi};
+                    size_t x;
+                    while (ls >> x) { node_reads[c][r].push_back(x); max_read = std::max(max_read, x + 1); }
+                } else if (tag == "E") { EdgeIn e; ls >> e.c >> e.r >> e.r2 >> e.w; edges.push_back(e); }
+            }
+            frags.resize(max_read);
+            for (size_t i = 0; i < max_read; ++i) frags[i].counter_id = i;
+            for (size_t c = 0; c < hg.size(); ++c) for (size_t r = 0; r < hg[c].size(); ++r) for (size_t x : node_reads[c][r]) hg[c][r].frag_set.push_back(&frags[x]);
+            for (const EdgeIn& e : edges) { hg[e.c][e.r].out_edges.push_back({e.r2, e.w}); hg[e.c + 1][e.r2].in_edges.push_back({e.r, e.w}); }
+            const FlowUpVec fl = solve_lp_graph(hg);
+            auto paths = get_disjoint_paths_rewrite(hg, fl, o);
+            printf("%s", "");
+            for (const FlowUpdate& f : fl) printf("F\t%zu\t%zu\t%zu\t%.17g\n", f.n1.first, f.n1.second, f.n2.second, f.flow);
+            for (size_t k = 0; k < paths.first.size(); ++k) {
+                printf("P\t%u\t%u", paths.second[k].first, paths.second[k].second);
+                for (const Frag* f : paths.first[k]) printf("\t%zu", f->counter_id);
+                printf("\n");
+            }
+            return 0;
+        }
+        if (o.bam_file.empty()) throw Error(FLORIA_E_INVALID, "Must input a BAM file.");
+        if (o.vcf_file.empty() || o.reference_fasta.empty()) throw Error(FLORIA_E_INVALID, "-v and -r are required");
+        if (!(o.ploidy_sensitivity >= 1 && o.ploidy_sensitivity <= 3)) throw Error(FLORIA_E_INVALID, "Ploidy sensitivty option must be between 1 and 3");
+
+        const double t_all = now_s();
+        fprintf(stderr, "Preprocessing VCF/Reference\n");
+        const BamFile bam = read_bam(o.bam_file);
+        if (!have_e || !have_l) {                                                     // parse_cmd_line.rs:72-90
+            const auto est = l_epsilon_auto_detect(bam);
+            if (!have_l) o.block_length = est.first;
+            if (!have_e) o.epsilon = est.second;
+            fprintf(stderr, "Estimated -l %zu, -e %g (used where not given)\n", est.first, est.second);
+        }
+        if (!ingest_only) write_run_files(o, argc, argv);
+        const std::vector<std::string> contigs = get_contigs_to_phase(bam);
+        const VcfProfile vp = get_vcf_profile(o.vcf_file, contigs);
+        const std::map<std::string, std::string> fasta = get_fasta_seqs(o.reference_fasta);
+        std::unique_ptr<Session> session_holder;
+        if (!ingest_only) session_holder.reset(new Session(o.device));                // throws without a usable MI355X: no CPU fallback
+
+        std::ofstream dump;
+        if (!dump_frags.empty()) dump.open(dump_frags, std::ios::trunc);
+        bool warn_first_length = true;
+        for (const std::string& contig : contigs) {
+            if (!o.list_to_phase.empty() && std::find(o.list_to_phase.begin(), o.list_to_phase.end(), contig) == o.list_to_phase.end()) continue;
+            const auto pam = vp.vcf_pos_allele_map.find(contig);
+            if (pam == vp.vcf_pos_allele_map.end() || pam->second.size() < o.snp_count_filter) {
+                if (warn_first_length)
+                    fprintf(stderr, "A contig (%s) is not present or has < %zu variants. This warning will not be shown from now on. Make sure to change --snp-count-filter if you want to phase small contigs.\n",
+                            contig.c_str(), o.snp_count_filter);
+                warn_first_length = false;
+                continue;
+            }
+            const double t0 = now_s();
+            auto fr = get_frags_from_bamvcf_rewrite(bam, vp, o, contig);
+            std::vector<Frag>& all_frags = fr.first;
+            const std::vector<Frag>& frags_without_snps = fr.second;
+            fprintf(stderr, "Number of reads passing filtering: %zu\n", all_frags.size());
+            if (all_frags.empty()) continue;
+            const auto sgp = vp.snp_to_genome_pos.find(contig);
+            if (sgp == vp.snp_to_genome_pos.end()) continue;
+            const std::string contig_out_dir = o.out_dir + "/" + contig;
+            const std::vector<GnPosition>& snp_to_genome_pos = sgp->second;
+            std::sort(all_frags.begin(), all_frags.end());                             // floria.rs:289-293
+            for (size_t i = 0; i < all_frags.size(); ++i) all_frags[i].counter_id = i;
+            if (dump.is_open()) {
+                dump << "#CONTIG\t" << contig << "\t" << all_frags.size() << "\t" << frags_without_snps.size() << "\n";
+                for (const Frag& f : all_frags) {
+                    dump << f.id << "\t" << f.first_position << "\t" << f.last_position << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.is_paired ? 1 : 0);
+                    for (const auto& kv : f.seq_dict) dump << "\t" << kv.first << ":" << (int)kv.second << ":" << (int)f.qual_dict.at(kv.first);
+                    dump << "\n";
+                }
+                for (const Frag& f : frags_without_snps) dump << "#SNPLESS\t" << f.id << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.seq_len[0] + f.seq_len[1]) << "\n";
+            }
+            fprintf(stderr, "Reading inputs time taken %.3fs\n", now_s() - t0);
+            if (ingest_only) continue;
+            Session& session = *session_holder;
+            const double t1 = now_s();
+            std::vector<std::vector<HapNode>> hap_graph = generate_hap_graph(session, all_frags, snp_to_genome_pos, contig_out_dir, o);
+            fprintf(stderr, "Phasing time taken %.3fs\n", now_s() - t1);
+            const FlowUpVec flow_up_vec = solve_lp_graph(hap_graph);
+            auto paths = get_disjoint_paths_rewrite(hap_graph, flow_up_vec, o);
+            if (debug) {
+                struct stat st;
+                if (stat(contig_out_dir.c_str(), &st) != 0) mkdir(contig_out_dir.c_str(), 0777);
+                std::ofstream g(contig_out_dir + "/debug_graph.txt", std::ios::trunc);
+                g.precision(17);
+                for (const auto& col : hap_graph) for (const HapNode& n : col) {
+                    g << "N\t" << n.column << "\t" << n.row << "\t" << n.id << "\t" << n.cov << "\t" << n.snp_endpoints.first << "\t" << n.snp_endpoints.second;
+                    for (const Frag* f : n.frag_set) g << "\t" << f->counter_id;
+                    g << "\n";
+                }
+                for (const auto& col : hap_graph) for (const HapNode& n : col) for (const auto& e : n.out_edges) g << "E\t" << n.column << "\t" << n.row << "\t" << e.first << "\t" << e.second << "\n";
+                for (const FlowUpdate& f : flow_up_vec) g << "F\t" << f.n1.first << "\t" << f.n1.second << "\t" << f.n2.second << "\t" << f.flow << "\n";
+                for (size_t k = 0; k < paths.first.size(); ++k) {
+                    g << "P\t" << paths.second[k].first << "\t" << paths.second[k].second;
+                    for (const Frag* f : paths.first[k]) g << "\t" << f->counter_id;
+                    g << "\n";
+                }
+            }
+            const std::vector<Frag> short_frags;
+            auto fin = process_reads_for_final_parts(session, paths.first, short_frags, paths.second, o, snp_to_genome_pos);
+            const std::vector<const Frag*> snpless = get_frags_in_snpless_gaps(fin.second, snp_to_genome_pos, frags_without_snps, o.block_length, all_frags);
+            const auto fa = fasta.find(contig);
+            if (fa == fasta.end()) throw Error(FLORIA_E_INVALID, "contig " + contig + " is not in the reference fasta");
+            write_outputs(session, fin.first, fin.second, contig_out_dir, contig, contig, snp_to_genome_pos, o, snpless, fa->second.size());
+        }
+        fprintf(stderr, "Total time taken is %.3fs\n", now_s() - t_all);
+    } catch (const Error& e) {
+        fprintf(stderr, "floria-hip: error: %s\n", e.what());
+        return 1;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "floria-hip: error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,161 @@
+// writer.cpp — the on-disk formats of floria, the user-visible contract of the drop-in (file_writer.rs).
+//   {contig_dir}/{contig}.vartigs         write_haplotypes            file_writer.rs:699-917
+//   {contig_dir}/vartig_info.txt          write_fragset_haplotypes    file_writer.rs:308-369
+//   {contig_dir}/{contig}.haplosets       write_all_parts_file        file_writer.rs:919-993
+//   {contig_dir}/reads_without_snps.tsv   write_nosnp_reads_parts     file_writer.rs:151-165
+//   {out_dir}/contig_ploidy_info.tsv      (appended)                  file_writer.rs:883-914, header constants.rs:24
+//   {out_dir}/cmd.log                                                  parse_cmd_line.rs:121-126
+// COV / ERR come from floria_hip_haploset_stats (get_errors_cov_from_frags, utils_frags.rs:596-655) and HAPQ / REL_ERR from
+// floria_hip_hapq (get_hapq, part_block_manip.rs:517-616), both computed on the device; the allele strings of the vartigs are
+// counted here on the host (set_to_seq_dict(.., false), utils_frags.rs:160-175).
+#include "floria_host.hpp"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace floria {
+
+namespace {
+
+void check(int rc) { if (rc != 0) throw Error(rc, floria_hip_last_error()); }
+
+// Rust's `{:.N}` of an f64: exact decimal expansion, ties to even — what glibc's printf does — but NaN / inf spell differently
+std::string fmt_f64(double v, int prec) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.*f", prec, v);
+    return buf;
+}
+
+void mkdir_p(const std::string& path) {
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); ++i) {
+        if (i == path.size() || path[i] == '/') {
+            if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) throw Error(FLORIA_E_INVALID, "cannot create directory " + cur + ": " + strerror(errno));
+        }
+        if (i < path.size()) cur.push_back(path[i]);
+    }
+}
+
+// iteration order of the reference's inner map FxHashMap<Genotype, GenotypeCount> (fxhash 0.2.1 + hashbrown): ascending allele
+// while <= 3 distinct alleles are present (4 buckets), 0, 2, 1, 3 once all four are (8 buckets) — DESIGN.md §6
+void allele_order(const uint32_t* cnt, int* order, int* n) {
+    int present[4], np = 0;
+    for (int a = 0; a < 4; ++a) if (cnt[a]) present[np++] = a;
+    if (np == 4) { order[0] = 0; order[1] = 2; order[2] = 1; order[3] = 3; }
+    else for (int i = 0; i < np; ++i) order[i] = present[i];
+    *n = np;
+}
+
+}  // namespace
+
+void write_run_files(const Options& o, int argc, char** argv) {
+    struct stat st;
+    if (stat(o.out_dir.c_str(), &st) == 0 && !o.overwrite)
+        throw Error(FLORIA_E_INVALID, "Output directory exists; output directory must not be an existing directory. Use --overwrite to overwrite existing directory.");
+    mkdir_p(o.out_dir);
+    std::ofstream cmd(o.out_dir + "/cmd.log", std::ios::trunc);
+    for (int i = 0; i < argc; ++i) cmd << argv[i] << " ";
+    std::ofstream pl(o.out_dir + "/contig_ploidy_info.tsv", std::ios::trunc);                      // constants.rs:24
+    pl << "contig\taverage_straincount\twhole_contig_multiplicity\tapproximate_coverage_ignoring_indels\ttotal_vartig_bases_covered\t"
+          "average_straincount_min15hapq\taverage_straincount_min30hapq\taverage_straincount_min45hapq\tavg_err\n";
+}
+
+void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& ranges,
+                   const std::string& dir, const std::string& prefix, const std::string& contig, const std::vector<GnPosition>& snp_to_gn,
+                   const Options& o, const std::vector<const Frag*>& snpless_frags, size_t contig_len) {
+    mkdir_p(dir);
+    const size_t n = part.size();
+    // ---- device: get_hapq (:40-41) and get_errors_cov_from_frags per haploset ---------------------------------------------------
+    const HapqResult hq = get_hapq(s, part, snp_to_gn, ranges, o);
+    std::vector<double> st(4 * n + 4, 0.0);
+    {
+        std::vector<uint64_t> off{0};
+        std::vector<uint32_t> reads, rng;
+        for (size_t g = 0; g < n; ++g) {
+            for (const Frag* f : part[g]) reads.push_back((uint32_t)f->counter_id);
+            off.push_back(reads.size());
+            rng.push_back(ranges[g].first); rng.push_back(ranges[g].second);
+        }
+        const floria_hip_contig* one[1] = {s.contig()};
+        if (n) check(floria_hip_haploset_stats(s.ctx(), one, 1, nullptr, off.data(), reads.data(), rng.data(), (uint32_t)n, st.data()));
+    }
+    // ---- write_haplotypes (:699-917) -----------------------------------------------------------------------------------------------
+    const size_t S = snp_to_gn.size();
+    std::vector<double> cnt_all(S, 0.), cov_all(S, 0.), cnt15(S, 0.), cnt30(S, 0.), cnt45(S, 0.);
+    size_t total_bases_covered = 0;
+    FILE* vt = fopen((dir + "/" + contig + ".vartigs").c_str(), "w");
+    FILE* vi = fopen((dir + "/vartig_info.txt").c_str(), "w");
+    FILE* hs = fopen((dir + "/" + prefix + ".haplosets").c_str(), "w");
+    if (!vt || !vi || !hs) { if (vt) fclose(vt); if (vi) fclose(vi); if (hs) fclose(hs); throw Error(FLORIA_E_INVALID, "cannot create output files in " + dir); }
+    for (size_t i = 0; i < n; ++i) {
+        if (part[i].empty()) continue;
+        const SnpPosition left = ranges[i].first, right = ranges[i].second;
+        if (left > right || left == 0 || right > S) { fclose(vt); fclose(vi); fclose(hs); throw Error(FLORIA_E_INVALID, "haploset SNP range out of order (the reference panics here)"); }
+        const GnPosition lg = snp_to_gn[left - 1], rg = snp_to_gn[right - 1];
+        total_bases_covered += rg - lg;
+        const double cov = st[4 * i], err = st[4 * i + 1];
+        const unsigned hap_q = hq.hapqs[i];
+        for (SnpPosition p = left; p <= right; ++p) {
+            cnt_all[p - 1] += 1.; cov_all[p - 1] += cov;
+            if (hap_q >= 15) cnt15[p - 1] += 1.;
+            if (hap_q >= 30) cnt30[p - 1] += 1.;
+            if (hap_q >= 45) cnt45[p - 1] += 1.;
+        }
+        const std::string head = ">HAP" + std::to_string(i) + "." + dir + "\tCONTIG:" + contig + "\tSNPRANGE:" + std::to_string(left) + "-" + std::to_string(right) +
+                                 "\tBASERANGE:" + std::to_string(lg + 1) + "-" + std::to_string(rg + 1) + "\tCOV:" + fmt_f64(cov, 3) + "\tERR:" + fmt_f64(err, 4) +
+                                 "\tHAPQ:" + std::to_string(hap_q) + "\tREL_ERR:" + fmt_f64(hq.rel_err[i], 3) + "\n";
+        fputs(head.c_str(), vt);
+        // write_fragset_haplotypes (:308-369): per SNP of the range the unit-count allele histogram of the haploset's reads
+        std::vector<uint32_t> hist((size_t)(right - left + 1) * 4, 0);
+        for (const Frag* f : part[i])
+            for (auto it = f->seq_dict.lower_bound(left); it != f->seq_dict.end() && it->first <= right; ++it) hist[(size_t)(it->first - left) * 4 + (it->second & 3)]++;
+        fprintf(vi, ">HAP%zu.%s\tSNPRANGE:%u-%u\n", i, dir.c_str(), left, right);
+        std::string alleles;
+        for (SnpPosition p = left; p <= right; ++p) {
+            const uint32_t* c = &hist[(size_t)(p - left) * 4];
+            int order[4], na = 0;
+            allele_order(c, order, &na);
+            fprintf(vi, "%u:%zu\t", p, (size_t)snp_to_gn[p - 1]);
+            if (na == 0) { fputs("?\tNA\t\n", vi); alleles.push_back('?'); continue; }          // 15 + 48 = '?'
+            int best = order[0];
+            for (int k = 1; k < na; ++k) if (c[order[k]] >= c[best]) best = order[k];         // max_by_key: the LAST maximum in iteration order
+            fprintf(vi, "%d\t", best);
+            alleles.push_back((char)('0' + best));
+            for (int k = 0; k < na; ++k) fprintf(vi, "%s%d:%u", k ? "|" : "", order[k], c[order[k]]);
+            fputs("\t\n", vi);
+        }
+        fputs(alleles.c_str(), vt); fputc('\n', vt);
+        // write_all_parts_file (:919-993): the same header, then the reads sorted by Frag::cmp (ascending counter_id)
+        fputs(head.c_str(), hs);
+        std::vector<const Frag*> vec_part(part[i]);
+        std::sort(vec_part.begin(), vec_part.end(), [](const Frag* a, const Frag* b) { return *a < *b; });
+        for (const Frag* f : vec_part) fprintf(hs, "%s\t%u\t%u\n", f->id.c_str(), f->first_position, f->last_position);
+    }
+    fclose(vt); fclose(vi); fclose(hs);
+    // contig_ploidy_info.tsv (:883-914)
+    {
+        size_t num_nonzero = 0;
+        double sum_all = 0., sum15 = 0., sum30 = 0., sum45 = 0., sum_cov = 0.;
+        for (size_t p = 0; p < S; ++p) { if (cnt_all[p] > 0.) ++num_nonzero; sum_all += cnt_all[p]; sum15 += cnt15[p]; sum30 += cnt30[p]; sum45 += cnt45[p]; sum_cov += cov_all[p]; }
+        const double rough_cvg = sum_cov / (double)num_nonzero;
+        std::ofstream pl(o.out_dir + "/contig_ploidy_info.tsv", std::ios::app);
+        pl << contig << "\t" << fmt_f64(sum_all / (double)S, 3) << "\t" << fmt_f64((double)total_bases_covered / (double)contig_len, 3) << "\t" << fmt_f64(rough_cvg, 3) << "\t"
+           << total_bases_covered << "\t" << fmt_f64(sum15 / (double)S, 3) << "\t" << fmt_f64(sum30 / (double)S, 3) << "\t" << fmt_f64(sum45 / (double)S, 3) << "\t" << fmt_f64(hq.avg_err, 4) << "\n";
+    }
+    // write_nosnp_reads_parts (:151-165)
+    {
+        std::ofstream f(dir + "/reads_without_snps.tsv", std::ios::trunc);
+        f << "READ_NAME\tREAD_LENGTH_IN_BASES\n";
+        for (const Frag* fr : snpless_frags) f << fr->id << "\t" << (fr->seq_len[0] + fr->seq_len[1]) << "\n";
+    }
+}
+
+}  // namespace floria

@@ -30,6 +30,7 @@ class Contig:
     snp_pos: np.ndarray          # uint64 [S] genome position (bp) of SNP i (0-based index i <-> SNP i+1)
     ploidy_truth: int
     strain: np.ndarray = field(default=None, repr=False)   # true strain of every read (for sanity checks)
+    layout: dict = field(default=None, repr=False)         # keep_layout: genome interval(s) of every read, contig length (synth_bam.py)
 
 
 @dataclass
@@ -46,7 +47,7 @@ class Workload:
 
 
 def make_contig(seed_seq, n_snps, n_reads, ploidy, kind="long", name="ctg", snp_gap_mean=100.0,
-                flip=0.03, drop=0.02, qlo=5, qhi=40, keep_truth=False):
+                flip=0.03, drop=0.02, qlo=5, qhi=40, keep_truth=False, keep_layout=False):
     rng = np.random.Generator(np.random.PCG64(seed_seq))
     hap = rng.integers(0, 2, size=(ploidy, n_snps), dtype=np.uint8)
     if ploidy >= 2:
@@ -60,6 +61,7 @@ def make_contig(seed_seq, n_snps, n_reads, ploidy, kind="long", name="ctg", snp_
     abund = rng.dirichlet(np.ones(ploidy))
     strain = rng.choice(ploidy, size=n_reads, p=abund)
     start = rng.integers(0, contig_len, size=n_reads)
+    insert = None
     if kind == "long":
         sigma = 0.4
         length = np.clip(rng.lognormal(np.log(10000.0) - sigma * sigma / 2, sigma, size=n_reads), 1000, 50000).astype(np.int64)
@@ -103,7 +105,13 @@ def make_contig(seed_seq, n_snps, n_reads, ploidy, kind="long", name="ctg", snp_
     gather = np.repeat(off2[src] - new_off[:-1], lens) + np.arange(int(new_off[-1]))
     pile = Pileup(new_off.astype(np.uint32), (snp0[gather] + 1).astype(np.uint32), allele[gather].astype(np.uint8),
                   qual[gather].astype(np.uint8), first[order].astype(np.uint32), last[order].astype(np.uint32))
-    return Contig(name, pile, pos.astype(np.uint64), ploidy, strain[src] if keep_truth else None)
+    layout = None
+    if keep_layout:           # genome intervals [start, end) of the kept reads, in pileup order (second mate for short pairs)
+        if kind == "long":
+            layout = dict(kind=kind, contig_len=contig_len, start=start[src], end=(start + length)[src])
+        else:
+            layout = dict(kind=kind, contig_len=contig_len, start=start[src], end=(start + 150)[src], start2=(start + insert - 150)[src], end2=(start + insert)[src])
+    return Contig(name, pile, pos.astype(np.uint64), ploidy, strain[src] if keep_truth else None, layout)
 
 
 # (n_contigs, snps/contig, reads/contig, kind, ploidy spec, max_ploidy, beam, block_length)
@@ -126,14 +134,14 @@ def contig_ploidy(config, idx):
     return spec
 
 
-def make_config_contig(config, idx, scale=1.0, keep_truth=False):
+def make_config_contig(config, idx, scale=1.0, keep_truth=False, keep_layout=False):
     """Contig `idx` of BASELINE config `config`.  scale<1 shrinks SNPs and reads per contig together
     (parity-test sizes); scale=1 is the BASELINE size."""
     c = CONFIGS[config]
     snps = max(8, int(round(c["snps"] * scale)))
     reads = max(4, int(round(c["reads"] * scale)))
     ss = np.random.SeedSequence([BASE_SEED + config, idx])
-    return make_contig(ss, snps, reads, contig_ploidy(config, idx), c["kind"], name=f"cfg{config}_ctg{idx}", keep_truth=keep_truth)
+    return make_contig(ss, snps, reads, contig_ploidy(config, idx), c["kind"], name=f"cfg{config}_ctg{idx}", keep_truth=keep_truth, keep_layout=keep_layout)
 
 
 def make_workload(config, contig_ids=None, scale=1.0, epsilon=0.03125, n_contigs=None):

@@ -1,0 +1,190 @@
+"""Synthetic BAM + VCF + FASTA whose pileup is known exactly: the alignment-level counterpart of synth.py.
+
+There is no htslib / pysam in this image and the reference's quick-start BAM is missing, so the ingest path of
+`floria-hip` (floria_amd/host/ingest.cpp) is exercised with files written here: a contig of synth.make_contig(keep_layout=True)
+is turned into
+
+  * a random reference sequence, REF = its base at every SNP position, ALT = another base;
+  * one alignment per read (two for a short-read pair) whose sequence is the reference with, at every covered SNP, the base
+    the pileup cell says (allele 0 -> REF, 1 -> ALT) or a THIRD base where the synthetic read has no call;  base quality = the
+    cell's quality;  a tenth of the long reads additionally carry a soft clip, an insertion and a deletion away from SNPs
+    (the CIGAR walk must step over them) and a deletion across one SNP (that call disappears);
+  * a coordinate-sorted BAM (BGZF blocks written with zlib), a VCF and a FASTA.
+
+write_dataset returns the pileup a correct ingest must produce (reads in Frag::cmp order with the BAM record index as the
+tie-break, floria.rs:289-293) together with read names and reference spans.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+from .pileup import Pileup
+
+BASES = np.frombuffer(b"ACGT", np.uint8)
+
+
+def _bgzf_block(data: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(data) + comp.flush()
+    bsize = len(cdata) + 25                                    # total block size - 1
+    return (struct.pack("<4BI2BH", 31, 139, 8, 4, 0, 0, 255, 6) + struct.pack("<2BHH", 66, 67, 2, bsize) + cdata
+            + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+_CIG = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5}
+_NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def bam_record(tid, pos, name, flag, mapq, cigar, seq, qual, next_pos=-1, tlen=0):
+    """cigar: list of (op char, len); seq: bytes of ACGTN; qual: uint8 array."""
+    ref_len = sum(n for op, n in cigar if op in "MDN")
+    nm = name.encode() + b"\0"
+    cig = b"".join(struct.pack("<I", (n << 4) | _CIG[op]) for op, n in cigar)
+    s = seq.decode()
+    packed = bytearray((len(s) + 1) // 2)
+    for i, ch in enumerate(s):
+        packed[i // 2] |= _NT16[ch] << (4 if i % 2 == 0 else 0)
+    body = (struct.pack("<iiBBHHHIiii", tid, pos, len(nm), mapq, _reg2bin(pos, pos + max(1, ref_len)), len(cigar), flag, len(s),
+                        tid if next_pos >= 0 else -1, next_pos, tlen) + nm + cig + bytes(packed) + bytes(np.asarray(qual, np.uint8)))
+    return struct.pack("<I", len(body)) + body
+
+
+def write_bam(path, targets, records):
+    """targets: [(name, length)]; records: already coordinate-sorted list of bam_record() bytes."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{ln}\n" for n, ln in targets)
+    head = b"BAM\1" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(targets))
+    for n, ln in targets:
+        head += struct.pack("<I", len(n) + 1) + n.encode() + b"\0" + struct.pack("<I", ln)
+    raw = head + b"".join(records)
+    with open(path, "wb") as f:
+        for o in range(0, len(raw), 60000):
+            f.write(_bgzf_block(raw[o:o + 60000]))
+        f.write(_bgzf_block(b""))                               # EOF marker
+
+
+def contig_dataset(contig, rng, edit_frac=0.1, mapq=60):
+    """-> dict(ref=bytes, snps=[(pos0, REF, ALT)], records=[(pos, record bytes)], reads=[(name, [(snp, allele, qual)], span)])
+    for one synth Contig made with keep_layout=True.  `reads` follows the BAM record order of the FIRST alignment of each read."""
+    lay, p = contig.layout, contig.pileup
+    clen = int(lay["contig_len"])
+    snp_pos = contig.snp_pos.astype(np.int64)                   # 0-based genome position of SNP i (index i <-> SNP i + 1)
+    ref = BASES[rng.integers(0, 4, size=clen)].copy()
+    alt = np.array([BASES[(int(np.nonzero(BASES == ref[q])[0][0]) + 1 + int(rng.integers(0, 3))) % 4] for q in snp_pos], np.uint8)
+    other = np.zeros(len(snp_pos), np.uint8)                    # a base that is neither REF nor ALT
+    for i, q in enumerate(snp_pos):
+        other[i] = [b for b in BASES if b != ref[q] and b != alt[i]][0]
+    paired = lay["kind"] == "short"
+    out_reads, recs = [], []
+    for r in range(p.n_reads):
+        snps, als, quals = p.read(r)
+        cell = {int(s) - 1: (int(a), int(q)) for s, a, q in zip(snps, als, quals)}          # SNP index -> (allele, qual)
+        segs = [(int(lay["start"][r]), min(int(lay["end"][r]), clen))]
+        if paired:
+            segs.append((int(lay["start2"][r]), min(int(lay["end2"][r]), clen)))
+        name = f"{contig.name}_r{r}"
+        lost = set()
+        recs_r = []
+        for k, (b, e) in enumerate(segs):
+            e = max(e, b + 1)
+            seq = ref[b:e].copy()
+            qual = np.full(e - b, 30, np.uint8)
+            lo, hi = np.searchsorted(snp_pos, b, "left"), np.searchsorted(snp_pos, e, "left")
+            for i in range(lo, hi):
+                o = int(snp_pos[i]) - b
+                if i in cell:
+                    seq[o] = ref[snp_pos[i]] if cell[i][0] == 0 else alt[i]
+                    qual[o] = cell[i][1]
+                else:
+                    seq[o] = other[i]
+            cigar = [("M", e - b)]
+            pos = b
+            if not paired and rng.random() < edit_frac and e - b > 400 and hi - lo >= 3:
+                # soft clip (5 bases), a 2-base insertion and a 3-base deletion between SNPs, and a 1-base deletion ACROSS one SNP
+                mid = lo + (hi - lo) // 2
+                gaps = [i for i in range(lo, hi - 1) if snp_pos[i + 1] - snp_pos[i] > 12 and snp_pos[i] - b > 10]
+                if len(gaps) >= 2 and mid not in (lo, hi - 1):
+                    g_ins, g_del = gaps[0], gaps[-1]
+                    if g_ins < mid - 1 and g_del > mid:
+                        x_ins = int(snp_pos[g_ins]) - b + 4             # insertion after this reference offset
+                        x_snp = int(snp_pos[mid]) - b                   # deleted reference base (the SNP itself)
+                        x_del = int(snp_pos[g_del]) - b + 4             # 3-base deletion starting here
+                        ins = BASES[rng.integers(0, 4, size=2)]
+                        new_seq = np.concatenate([BASES[rng.integers(0, 4, size=5)], seq[:x_ins], ins, seq[x_ins:x_snp], seq[x_snp + 1:x_del], seq[x_del + 3:]])
+                        new_q = np.concatenate([np.full(5, 20, np.uint8), qual[:x_ins], np.full(2, 20, np.uint8), qual[x_ins:x_snp], qual[x_snp + 1:x_del], qual[x_del + 3:]])
+                        cigar = [("S", 5), ("M", x_ins), ("I", 2), ("M", x_snp - x_ins), ("D", 1), ("M", x_del - x_snp - 1), ("D", 3), ("M", (e - b) - x_del - 3)]
+                        seq, qual = new_seq, new_q
+                        lost.add(mid)
+            flag = 0
+            if paired:
+                flag = 1 | 2 | (64 | 32 if k == 0 else 128 | 16)
+            recs_r.append((pos, bam_record(0, pos, name, flag, mapq, cigar, bytes(seq), qual)))
+        cells = [(i + 1, a, q) for i, (a, q) in sorted(cell.items()) if i not in lost]
+        span = (min(b for b, _ in segs), min(max(e, b + 1) for b, e in segs)) if paired else (segs[0][0], max(segs[0][1], segs[0][0] + 1))
+        out_reads.append((name, cells, span, recs_r, sum(max(e, b + 1) - b for b, e in segs)))
+    return dict(ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
+
+
+def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True):
+    """Write {prefix}.bam / .vcf / .fa for a list of synth Contigs (keep_layout=True).  Returns, per contig name,
+    dict(pileup=Pileup in the order a correct ingest produces, names=[read name], spans=[(first_pos_base, last_pos_base)],
+         snp_pos0=[0-based genome position of every SNP], contig_len, seq_len=[bases of every read])."""
+    rng = np.random.default_rng(seed)
+    targets, all_recs, expect = [], [], {}
+    fa = open(prefix + ".fa", "w")
+    vcf = open(prefix + ".vcf", "w")
+    vcf.write("##fileformat=VCFv4.2\n")
+    datasets = []
+    for tid, c in enumerate(contigs):
+        d = contig_dataset(c, rng)
+        datasets.append(d)
+        targets.append((c.name, d["contig_len"]))
+        vcf.write(f"##contig=<ID={c.name},length={d['contig_len']}>\n")
+    vcf.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n")
+    for tid, (c, d) in enumerate(zip(contigs, datasets)):
+        fa.write(f">{c.name} synthetic\n")
+        s = d["ref"].decode()
+        for o in range(0, len(s), 60):
+            fa.write(s[o:o + 60] + "\n")
+        for k, (q, r, a) in enumerate(d["snps"]):
+            vcf.write(f"{c.name}\t{q + 1}\t.\t{r}\t{a}\t50\tPASS\t.\tGT\t0/1\n")
+            if extra_vcf_lines and k % 97 == 5 and k + 1 < len(d["snps"]) and d["snps"][k + 1][0] > q + 3:
+                # records the SNP filter must skip (file_reader.rs:290-300): an indel, a symbolic / non-ACGT allele
+                vcf.write(f"{c.name}\t{q + 2}\t.\t{s[q + 1]}{s[q + 2]}\t{s[q + 1]}\t50\tPASS\t.\tGT\t0/1\n")
+                vcf.write(f"{c.name}\t{q + 3}\t.\t{s[q + 2]}\t*\t50\tPASS\t.\tGT\t0/1\n")
+        # BAM records of this contig, coordinate-sorted (stable: ties keep read order); record index = position in this list
+        flat = []
+        for ri, (name, cells, span, recs_r, slen) in enumerate(d["reads"]):
+            for k, (pos, rec) in enumerate(recs_r):
+                flat.append((pos, ri, k, rec))
+        flat.sort(key=lambda t: (t[0], t[1], t[2]))
+        first_index = {}
+        for idx, (pos, ri, k, rec) in enumerate(flat):
+            if k == 0:
+                first_index[ri] = idx                                   # counter_id of the merged Frag = record index of the first-in-pair / only alignment
+            all_recs.append(struct.pack("<I", len(rec) - 4) + struct.pack("<i", tid) + rec[8:])   # patch refID
+        order = sorted(range(len(d["reads"])), key=lambda ri: first_index[ri])
+        reads = [d["reads"][ri] for ri in order]
+        pile_reads = [([x[0] for x in cells], [x[1] for x in cells], [x[2] for x in cells]) for _, cells, _, _, _ in reads if cells]
+        names = [nm for nm, cells, _, _, _ in reads if cells]
+        spans = [sp for _, cells, sp, _, _ in reads if cells]
+        slens = [sl for _, cells, _, _, sl in reads if cells]
+        pile = Pileup.from_reads(pile_reads)                            # Frag::cmp with the input (= record) order as the tie-break
+        # Pileup.from_reads sorted the reads: recover the permutation to carry names / spans along
+        first = np.array([r[0][0] for r in pile_reads], np.int64)
+        last = np.array([r[0][-1] for r in pile_reads], np.int64)
+        perm = np.lexsort((np.arange(len(pile_reads)), -last, first))
+        expect[c.name] = dict(pileup=pile, names=[names[i] for i in perm], spans=[spans[i] for i in perm], seq_len=[slens[i] for i in perm],
+                              snp_pos0=np.array([q for q, _, _ in d["snps"]], np.uint64), contig_len=d["contig_len"],
+                              snpless=[(nm, sp, sl) for nm, cells, sp, _, sl in reads if not cells])
+    fa.close(); vcf.close()
+    write_bam(prefix + ".bam", targets, all_recs)
+    return expect

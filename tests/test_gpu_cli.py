@@ -1,0 +1,158 @@
+"""`-m gpu`: floria-hip end to end — BAM + VCF + FASTA in, floria's output files out.
+
+Inputs are written by floria_amd/synth_bam.py (no htslib here, the reference's quick-start BAM is missing), so the pileup a
+correct ingest must produce is known exactly.  Every stage of the driver is checked against an independent restatement:
+  ingest (C++)              == the generator's pileup, read names, reference spans
+  hap graph (device)        == oracle S1 + oracle hap graph (C++ oracle)
+  LP flows (C++ min-cost flow)  feasible and optimal for the LP (scipy / HiGHS)
+  joined paths (C++)        == oracle/stitch.py: disjoint_paths on the same flows
+  final haplosets (device)  == oracle S2 on those paths
+  files (C++ writers)       == oracle/stitch.py: expected_files, byte for byte; headers parse with the regexes of the
+                               reference's scripts/haplotag_bam.py:7-10
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from floria_amd import synth, synth_bam
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "floria_amd", "host")
+EPS = 0.03125
+
+
+@pytest.fixture(scope="module")
+def floria_hip(hip_lib):
+    subprocess.check_call(["make", "-C", HOST, "floria-hip"], stdout=subprocess.DEVNULL)
+    return os.path.join(HOST, "floria-hip")
+
+
+def parse_frag_dump(path):
+    contigs, cur = {}, None
+    for line in open(path):
+        t = line.rstrip("\n").split("\t")
+        if t[0] == "#CONTIG":
+            cur = contigs.setdefault(t[1], dict(reads=[], snpless=[]))
+        elif t[0] == "#SNPLESS":
+            cur["snpless"].append((t[1], (int(t[2]), int(t[3])), int(t[4])))
+        else:
+            cells = [tuple(int(x) for x in c.split(":")) for c in t[6:]]
+            cur["reads"].append(dict(name=t[0], first=int(t[1]), last=int(t[2]), span=(int(t[3]), int(t[4])), paired=int(t[5]), cells=cells))
+    return contigs
+
+
+def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra=()):
+    from oracle import stitch
+    prefix = str(tmp_path / "data")
+    expect = synth_bam.write_dataset(prefix, contigs, seed=7)
+    out = str(tmp_path / "out")
+    dump = str(tmp_path / "frags.txt")
+    cmd = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", str(EPS), "-l", str(block_length),
+           "--debug", "--dump-frags", dump, *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(out, "cmd.log")).read().split()[1:4] == ["-b", prefix + ".bam", "-v"]
+    frags = parse_frag_dump(dump)
+    ploidy_rows = open(os.path.join(out, "contig_ploidy_info.tsv")).read().splitlines(keepends=True)
+    assert ploidy_rows[0].startswith("contig\taverage_straincount\twhole_contig_multiplicity\t")
+    cov_p, snp_p, hapq_p, index_p = re.compile(r"COV:(\d*\.?\d+)"), re.compile(r"BASERANGE:(\d+)-(\d+)"), re.compile(r"HAPQ:(\d+)"), re.compile(r"HAP(\d+)")
+    for k, c in enumerate(contigs):
+        ex = expect[c.name]
+        pile = ex["pileup"]
+        # ---- ingest ------------------------------------------------------------------------------------------------------------
+        got = frags[c.name]["reads"]
+        assert len(got) == pile.n_reads
+        assert [g["name"] for g in got] == ex["names"]
+        assert [g["first"] for g in got] == pile.first.tolist() and [g["last"] for g in got] == pile.last.tolist()
+        assert [g["span"] for g in got] == [tuple(int(x) for x in sp) for sp in ex["spans"]]
+        for i, g in enumerate(got):
+            s, a, q = pile.read(i)
+            assert g["cells"] == list(zip(s.tolist(), a.tolist(), q.tolist())), f"read {i} ({g['name']})"
+        assert sorted(x[0] for x in frags[c.name]["snpless"]) == sorted(x[0] for x in ex["snpless"])
+        # ---- hap graph == oracle -------------------------------------------------------------------------------------------------
+        cdir = os.path.join(out, c.name)
+        cols, flows, paths = stitch.parse_debug_graph(os.path.join(cdir, "debug_graph.txt"))
+        s, e = oracle_mod.block_ranges(ex["snp_pos0"], block_length)
+        ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(EPS), threads=8)
+        cov, ew = oracle_mod.hap_graph(pile, s, e, ro)
+        ocols = stitch.build_hap_graph(ro, s, e, cov, ew)
+        assert [len(x) for x in cols] == [len(x) for x in ocols]
+        for col, ocol in zip(cols, ocols):
+            for n, on in zip(col, ocol):
+                assert (n.id, n.ends, n.reads, n.out_edges) == (on.id, on.ends, on.reads, on.out_edges) and n.cov == on.cov
+        # ---- LP: feasible + optimal; paths: restated peeling on the same flows -----------------------------------------------------
+        stitch.check_flows(cols, flows)
+        assert paths == stitch.disjoint_paths(cols, flows)
+        # ---- S2 + writers ----------------------------------------------------------------------------------------------------------------
+        go = oracle_mod.reassign(pile, [p[2] for p in paths], [(p[0], p[1]) for p in paths], EPS)
+        parts = [go.group(g) for g in range(go.n_groups)]
+        ranges = [tuple(int(x) for x in go.range[g]) for g in range(go.n_groups)]
+        stats = [oracle_mod.haploset_stats(pile, parts[g], ranges[g][0], ranges[g][1]) for g in range(go.n_groups)]
+        hq, rel, avg = oracle_mod.hapq(pile, parts, ranges, ex["snp_pos0"], block_length)
+        gaps = stitch.snpless_gap_frags(ranges, ex["snp_pos0"], ex["snpless"], ex["spans"], ex["names"], block_length)
+        len_of = dict(zip(ex["names"], ex["seq_len"]))
+        rows = [(nm, sl if sl is not None else len_of[nm]) for nm, sl in gaps]
+        want = stitch.expected_files(pile, ex["names"], parts, ranges, stats, hq, rel, avg, ex["snp_pos0"], c.name, cdir, ex["contig_len"], rows)
+        for fn in (f"{c.name}.vartigs", f"{c.name}.haplosets", "vartig_info.txt", "reads_without_snps.tsv"):
+            assert open(os.path.join(cdir, fn)).read() == want[fn], fn
+        assert ploidy_rows[1 + k] == want["ploidy_row"]
+        # ---- the reference's downstream scripts can read the headers (scripts/haplotag_bam.py:7-10) ------------------------------------
+        heads = [ln for ln in open(os.path.join(cdir, f"{c.name}.haplosets")) if ln.startswith(">")]
+        assert len(heads) == sum(1 for p in parts if len(p)) > 0
+        for ln in heads:
+            assert cov_p.search(ln) and snp_p.search(ln) and hapq_p.search(ln) and index_p.search(ln)
+            lo, hi = (int(x) for x in snp_p.search(ln).groups())
+            assert 1 <= lo <= hi <= ex["contig_len"] and 0 <= int(hapq_p.search(ln).group(1)) <= 60
+        vt = open(os.path.join(cdir, f"{c.name}.vartigs")).read().splitlines()
+        assert len(vt) == 2 * len(heads) and all(set(x) <= set("0123?") for x in vt[1::2])
+    return expect
+
+
+def test_quickstart_substitute_long_reads(floria_hip, oracle_mod, tmp_path):
+    # BASELINE config 1 substitute (the quick-start BAM is missing): 954 SNPs spaced like tests/test.vcf, 3 strains,
+    # ~30x long reads; a tenth of the alignments carry soft clips, insertions and deletions (one across a SNP)
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    run_and_check(floria_hip, oracle_mod, tmp_path, [c], 10000)
+
+
+def test_two_contigs_and_a_small_one_is_skipped(floria_hip, oracle_mod, tmp_path):
+    # two config-4-shaped contigs plus one below --snp-count-filter (skipped with the reference's warning, floria.rs:233-247)
+    cs = [synth.make_config_contig(4, 3, 0.5, keep_layout=True), synth.make_config_contig(4, 8, 0.4, keep_layout=True)]
+    small = synth.make_contig(np.random.SeedSequence([9, 9]), 40, 80, 2, "long", name="tiny", keep_layout=True)
+    prefix = str(tmp_path / "d2")
+    synth_bam.write_dataset(prefix, cs + [small], seed=3)
+    out = str(tmp_path / "o2")
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", str(EPS), "-l", "10000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "has < 100 variants" in r.stderr and not os.path.exists(os.path.join(out, "tiny"))
+    assert len(open(os.path.join(out, "contig_ploidy_info.tsv")).readlines()) == 3
+    # the output directory must not exist unless --overwrite (parse_cmd_line.rs:116-119)
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", str(EPS), "-l", "10000"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Output directory exists" in r.stderr
+    run_and_check(floria_hip, oracle_mod, tmp_path, cs, 10000, extra=("--overwrite",))
+
+
+def test_paired_short_reads(floria_hip, oracle_mod, tmp_path):
+    # 2 x 150 bp pairs: mates merge into one Frag (combine_frags, file_reader.rs:505-560)
+    c = synth.make_config_contig(3, 2, 0.3, keep_layout=True)
+    run_and_check(floria_hip, oracle_mod, tmp_path, [c], 500)
+
+
+def test_auto_estimated_parameters(floria_hip, tmp_path):
+    # without -e / -l the driver estimates them from the BAM like l_epsilon_auto_detect (file_reader.rs:749-826): -l = the 66 % read
+    # length quantile (>= 500), -e = the 66 % quantile of the per-column minority / majority ratio (>= 0.01)
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    prefix = str(tmp_path / "d3")
+    ex = synth_bam.write_dataset(prefix, [c], seed=1)[c.name]
+    out = str(tmp_path / "o3")
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
+    lens = sorted(ex["seq_len"])
+    assert m and 0.01 <= float(m.group(2)) < 0.2
+    assert abs(int(m.group(1)) - lens[len(lens) * 66 // 100]) < 0.2 * lens[len(lens) * 66 // 100]
+    assert os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))

@@ -1,0 +1,117 @@
+"""CPU tests of the C++ host code above the C ABI (floria_amd/host/): ingest and global stitching need no GPU.
+
+  ingest.cpp   BAM (BGZF) / VCF / FASTA -> Frags, against the synthetic data sets of floria_amd/synth_bam.py whose pileup is known
+  stitch.cpp   solve_lp_graph (exact min-cost flow) is feasible and OPTIMAL for the reference's LP (scipy / HiGHS), and
+               get_disjoint_paths_rewrite equals the Python restatement (oracle/stitch.py) on the same flows
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from floria_amd import synth, synth_bam
+from oracle import stitch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "floria_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def floria_hip(hip_lib):
+    subprocess.check_call(["make", "-C", HOST, "floria-hip"], stdout=subprocess.DEVNULL)
+    return os.path.join(HOST, "floria-hip")
+
+
+def ingest(floria_hip, prefix, tmp_path, extra=()):
+    from tests.test_gpu_cli import parse_frag_dump
+    dump = prefix + ".frags"
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", str(tmp_path / "unused"), "-e", "0.03", "-l", "10000",
+                        "--ingest-only", "--dump-frags", dump, *extra], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return parse_frag_dump(dump), r.stderr
+
+
+@pytest.mark.parametrize("cfg,idx,scale", [(1, 0, 1.0), (4, 5, 0.5), (3, 2, 0.3)])
+def test_ingest_reproduces_the_generators_pileup(floria_hip, tmp_path, cfg, idx, scale):
+    c = synth.make_config_contig(cfg, idx, scale, keep_layout=True)
+    prefix = str(tmp_path / "d")
+    ex = synth_bam.write_dataset(prefix, [c], seed=11)[c.name]
+    got, _ = ingest(floria_hip, prefix, tmp_path)
+    reads, pile = got[c.name]["reads"], ex["pileup"]
+    assert [g["name"] for g in reads] == ex["names"]
+    assert [g["first"] for g in reads] == pile.first.tolist() and [g["last"] for g in reads] == pile.last.tolist()
+    assert [g["span"] for g in reads] == [tuple(int(x) for x in sp) for sp in ex["spans"]]
+    assert all(g["paired"] == (1 if cfg == 3 else 0) for g in reads)
+    for i, g in enumerate(reads):
+        s, a, q = pile.read(i)
+        assert g["cells"] == list(zip(s.tolist(), a.tolist(), q.tolist())), f"read {i}"
+    # the synthetic contig differs from its pileup only by the calls the deletions removed: the CIGAR walk was exercised
+    if cfg != 3:
+        assert pile.n_cells < c.pileup.n_cells
+
+
+def test_vcf_filter_mapq_and_small_contigs(floria_hip, tmp_path):
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    small = synth.make_contig(np.random.SeedSequence([9, 9]), 40, 80, 2, "long", name="tiny", keep_layout=True)
+    prefix = str(tmp_path / "d")
+    ex = synth_bam.write_dataset(prefix, [c, small], seed=5)
+    got, err = ingest(floria_hip, prefix, tmp_path)
+    assert set(got) == {c.name} and "has < 100 variants" in err                      # floria.rs:233-247
+    got, _ = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10"))
+    assert set(got) == {c.name, "tiny"} and len(got["tiny"]["reads"]) == ex["tiny"]["pileup"].n_reads
+    got, _ = ingest(floria_hip, prefix, tmp_path, extra=("-m", "61"))                 # every synthetic alignment has MAPQ 60
+    assert got == {}
+    got, _ = ingest(floria_hip, prefix, tmp_path, extra=("-G", "tiny", "--snp-count-filter", "10"))
+    assert set(got) == {"tiny"}
+    # the VCF carries indel and '*' records between the SNPs (synth_bam.write_dataset): SNP numbering must skip them
+    assert sum(1 for ln in open(prefix + ".vcf") if not ln.startswith("#")) > len(ex[c.name]["snp_pos0"]) + len(ex["tiny"]["snp_pos0"])
+
+
+def random_graph(rng, n_cols, max_rows, n_reads=400):
+    """a layered hap graph with integer edge weights >= 2, as update_hap_graph produces"""
+    lines, rows, reads = [], [], iter(range(10 ** 6))
+    nid = 0
+    for c in range(n_cols):
+        r = int(rng.integers(1, max_rows + 1))
+        rows.append(r)
+        for k in range(r):
+            ids = sorted(set(int(x) for x in rng.integers(0, n_reads, size=int(rng.integers(1, 8)))))
+            lines.append("N\t%d\t%d\t%d\t%.3f\t%d\t%d\t%s" % (c, k, nid, float(rng.random() * 30), 1 + 10 * c, 14 + 10 * c, "\t".join(map(str, ids))))
+            nid += 1
+    for c in range(n_cols - 1):
+        for j in range(rows[c]):
+            for l in range(rows[c + 1]):
+                if rng.random() < 0.6:
+                    lines.append("E\t%d\t%d\t%d\t%d" % (c, j, l, int(rng.integers(2, 60))))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_lp_flows_are_optimal_and_paths_match_the_restatement(floria_hip, tmp_path, seed):
+    rng = np.random.default_rng(300 + seed)
+    path = str(tmp_path / "g.txt")
+    open(path, "w").write(random_graph(rng, int(rng.integers(2, 12)), int(rng.integers(1, 5))))
+    r = subprocess.run([floria_hip, "--stitch-graph", path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    open(path, "a").write(r.stdout)
+    cols, flows, paths = stitch.parse_debug_graph(path)
+    stitch.check_flows(cols, flows)
+    assert all(abs(f[2] - round(f[2])) == 0 for f in flows)                      # a vertex of a network LP with integer data
+    assert paths == stitch.disjoint_paths(cols, flows)
+    # every node lies on exactly one path, so every read of the graph is in some haplogroup
+    assert set(x for p in paths for x in p[2]) == set(x for col in cols for n in col for x in n.reads)
+
+
+def test_lp_hand_case_with_a_unique_optimum(floria_hip, tmp_path):
+    # a chain 0 -(7)-> 1 -(7)-> 2 -(4)-> 3: node 1 is balanced, node 2 needs inflow == outflow.  Lowering edges (0,1) and (1,2) to 4
+    # costs 6, raising (2,3) to 7 costs 3 and any mix costs in between: the unique optimum is x = (7, 7, 7).
+    g = "N\t0\t0\t0\t1\t1\t4\t0\nN\t1\t0\t1\t1\t5\t8\t1\nN\t2\t0\t2\t1\t9\t12\t2\nN\t3\t0\t3\t1\t13\t16\t3\nE\t0\t0\t0\t7\nE\t1\t0\t0\t7\nE\t2\t0\t0\t4\n"
+    path = str(tmp_path / "h.txt")
+    open(path, "w").write(g)
+    r = subprocess.run([floria_hip, "--stitch-graph", path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fl = [ln.split("\t") for ln in r.stdout.splitlines() if ln.startswith("F")]
+    assert [float(x[4]) for x in fl] == [7.0, 7.0, 7.0]
+    ps = [ln.split("\t") for ln in r.stdout.splitlines() if ln.startswith("P")]
+    assert ps == [["P", "1", "16", "0", "1", "2", "3"]]                          # one path through all four nodes
