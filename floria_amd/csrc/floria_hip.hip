@@ -1786,7 +1786,8 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
     }
     std::vector<uint64_t> r2g_off_base(n_contigs), r2g_base(n_contigs), grp_base(n_contigs), assign_base(n_contigs);
     std::vector<uint64_t> r2g_off_all, hist_off_all;
-    std::vector<uint32_t> r2g_all, gpos0_all;
+    std::vector<uint32_t> r2g_all, gpos0_all, multi_all;
+    std::vector<uint64_t> multi_off_all;
     std::vector<fl::ContigDev> cdev(n_contigs);
     uint64_t hist_cells = 0, n_assign = 0;
     for (uint32_t ci = 0; ci < n_contigs; ++ci) {
@@ -1835,6 +1836,11 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
             }
             for (uint32_t r = 0; r < N; ++r) if (off[r + 1] > off[r] && !seen[r]) return fail(FLORIA_E_INVALID, "read_order misses a read that sits in a group");
         }
+        multi_off_all.push_back(multi_all.size());
+        {                                                   // visiting indices of the reads that have a choice (more than one candidate group)
+            const uint64_t nv = read_order ? order_off[ci + 1] - order_off[ci] : N;
+            for (uint64_t v = 0; v < nv; ++v) { const uint32_t r = read_order ? read_order[order_off[ci] + v] : (uint32_t)v; if (off[r + 1] - off[r] > 1) multi_all.push_back((uint32_t)v); }
+        }
         r2g_off_all.insert(r2g_off_all.end(), off.begin(), off.end());
         for (uint32_t lg = 0; lg < cg[ci].size(); ++lg) {
             hist_off_all.push_back(hist_cells);
@@ -1852,7 +1858,8 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
                   s_ab = seg(8ull * n_contigs), s_ro = seg(8ull * r2g_off_all.size() + 8), s_r2g = seg(4ull * r2g_all.size() + 4),
                   s_ho = seg(8ull * hist_off_all.size() + 8), s_p0 = seg(4ull * gpos0_all.size() + 4), s_hist = seg(8ull * hist_cells + 8),
                   s_as = seg(4ull * n_assign + 4), s_q = seg(16), s_ord = seg(read_order ? 4ull * order_off[n_contigs] + 4 : 4),
-                  s_oo = seg(8ull * (n_contigs + 1));
+                  s_oo = seg(8ull * (n_contigs + 1)), s_mu = seg(4ull * multi_all.size() + 4), s_mo = seg(8ull * (n_contigs + 1));
+        multi_off_all.push_back(multi_all.size());
         int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
         char* M = ctx->misc.as<char>();
         EventTimer T(ctx->stream);
@@ -1867,6 +1874,7 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         HIPCHK(hipMemsetAsync(M + s_q.off, 0, 16, ctx->stream));
         HIPCHK(hipMemsetAsync(M + s_as.off, 0xff, s_as.bytes, ctx->stream));            // -1 = not assigned
         if (read_order) { HIPCHK(h2d(s_ord, read_order, 4ull * order_off[n_contigs])); HIPCHK(h2d(s_oo, order_off, 8ull * (n_contigs + 1))); }
+        HIPCHK(h2d(s_mu, multi_all.data(), 4ull * multi_all.size())); HIPCHK(h2d(s_mo, multi_off_all.data(), 8ull * (n_contigs + 1)));
         T.end(th);
         fl::ReassignArgs a{};
         a.contigs = (const fl::ContigDev*)(M + s_cd.off); a.n_contigs = n_contigs;
@@ -1876,10 +1884,12 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         a.hist = (uint64_t*)(M + s_hist.off); a.assign = (int32_t*)(M + s_as.off); a.assign_base = (const uint64_t*)(M + s_ab.off);
         a.eps = epsilon; a.queue_head = (uint32_t*)(M + s_q.off);
         a.order = read_order ? (const uint32_t*)(M + s_ord.off) : nullptr; a.order_off = (const uint64_t*)(M + s_oo.off);
-        const uint32_t grid = std::min<uint32_t>(n_contigs, (uint32_t)ctx->n_cu * 16);
+        a.multi = (const uint32_t*)(M + s_mu.off); a.multi_off = (const uint64_t*)(M + s_mo.off);
+        const uint32_t grid = std::min<uint32_t>(n_contigs, (uint32_t)ctx->n_cu * 8);
         int tk = T.begin(K_REASSIGN);
-        if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+        ctx->timing.jobs = multi_all.size();                        // reads that had a choice (the sequential part of S2)
         T.end(tk);
         HIPCHK(hipGetLastError());
         int td = T.begin(K_D2H);
