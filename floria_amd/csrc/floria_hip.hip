@@ -144,6 +144,7 @@ struct Knobs {
     uint32_t upload_chunks = 0;   // floria_hip_phase_pileups_batch: chunks the cell arrays travel in (0 = auto by size, <= 8)
     uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
+    uint32_t spec_desc = 0;       // speculative stage: launch the highest ploidy first
 };
 
 struct Arena;
@@ -477,7 +478,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                 HIPCHK(hipEventRecord(ctx->ev_fork[g * W], s0));
                 for (uint32_t j = 1; j < stage.size(); ++j) HIPCHK(hipStreamWaitEvent(ls[g * W + j], ctx->ev_fork[g * W], 0));
             }
-            for (uint32_t j = 0; j < stage.size(); ++j) {
+            for (uint32_t jj = 0; jj < stage.size(); ++jj) {
+                const uint32_t j = K.spec_desc ? (uint32_t)stage.size() - 1 - jj : jj;     // launch order inside a stage (the lane of ploidy stage[j] stays j)
                 const uint32_t p = stage[j], lane = g * W + j;
                 const PloidyPlan& q = plan[p];
                 hipStream_t st = ls[lane];
@@ -635,6 +637,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(2, atoi(v)));
         if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(3, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
+        K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
         else c->stage_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     }
@@ -1215,7 +1218,8 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     {
         int spec = ctx->knobs.speculate;
         const bool slab_path = P * prm->beam <= 63 && !ctx->knobs.beam_path;          // the wide-beam kernels own whole CUs: nothing to gain there
-        if (spec < 0) spec = (slab_path && G == 1 && P >= 3 && jobs.size() * 3 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
+        // (measured on config-4 shards: all ploidies at once wins below ~2k blocks — 250 contigs: 33 vs 40 ms — and loses above — 500 contigs: 64 vs 47 ms)
+        if (spec < 0) spec = (slab_path && G == 1 && P >= 3 && jobs.size() * 2 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
         if (chunked) spec = 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
@@ -1858,7 +1862,7 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
                   s_ab = seg(8ull * n_contigs), s_ro = seg(8ull * r2g_off_all.size() + 8), s_r2g = seg(4ull * r2g_all.size() + 4),
                   s_ho = seg(8ull * hist_off_all.size() + 8), s_p0 = seg(4ull * gpos0_all.size() + 4), s_hist = seg(8ull * hist_cells + 8),
                   s_as = seg(4ull * n_assign + 4), s_q = seg(16), s_ord = seg(read_order ? 4ull * order_off[n_contigs] + 4 : 4),
-                  s_oo = seg(8ull * (n_contigs + 1)), s_mu = seg(4ull * multi_all.size() + 4), s_mo = seg(8ull * (n_contigs + 1));
+                  s_oo = seg(8ull * (n_contigs + 1)), s_mu = seg(4ull * multi_all.size() + 4), s_mo = seg(8ull * (n_contigs + 1)), s_ls = seg(4ull * n_contigs + 4);
         multi_off_all.push_back(multi_all.size());
         int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
         char* M = ctx->misc.as<char>();
@@ -1885,10 +1889,29 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         a.eps = epsilon; a.queue_head = (uint32_t*)(M + s_q.off);
         a.order = read_order ? (const uint32_t*)(M + s_ord.off) : nullptr; a.order_off = (const uint64_t*)(M + s_oo.off);
         a.multi = (const uint32_t*)(M + s_mu.off); a.multi_off = (const uint64_t*)(M + s_mo.off);
-        const uint32_t grid = std::min<uint32_t>(n_contigs, (uint32_t)ctx->n_cu * 8);
+        // contigs where at least 1 read in 8 has a choice take the latency-optimised chain kernel, the others the parallel one
+        std::vector<uint32_t> list_par, list_chain;
+        for (uint32_t ci = 0; ci < n_contigs; ++ci) {
+            const uint64_t nm = multi_off_all[ci + 1] - multi_off_all[ci];
+            const uint64_t nv = read_order ? order_off[ci + 1] - order_off[ci] : contigs[ci]->n_reads;
+            (nm * 8 >= nv && nm > 0 ? list_chain : list_par).push_back(ci);
+        }
+        std::vector<uint32_t> lists(list_par);
+        lists.insert(lists.end(), list_chain.begin(), list_chain.end());
+        HIPCHK(hipMemcpyAsync(M + s_ls.off, lists.data(), 4ull * lists.size(), hipMemcpyHostToDevice, ctx->stream));
         int tk = T.begin(K_REASSIGN);
-        if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+        if (!list_par.empty()) {
+            a.list = (const uint32_t*)(M + s_ls.off); a.n_list = (uint32_t)list_par.size(); a.queue_head = (uint32_t*)(M + s_q.off);
+            const uint32_t grid = std::min<uint32_t>(a.n_list, (uint32_t)ctx->n_cu * 8);
+            if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+        }
+        if (!list_chain.empty()) {
+            a.list = (const uint32_t*)(M + s_ls.off) + list_par.size(); a.n_list = (uint32_t)list_chain.size(); a.queue_head = (uint32_t*)(M + s_q.off) + 1;
+            const uint32_t grid = std::min<uint32_t>(a.n_list, (uint32_t)ctx->n_cu * 16);
+            if (A == 2) hipLaunchKernelGGL(fl::reassign_chain_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(fl::reassign_chain_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        }
         ctx->timing.jobs = multi_all.size();                        // reads that had a choice (the sequential part of S2)
         T.end(tk);
         HIPCHK(hipGetLastError());

@@ -523,3 +523,33 @@ def test_random_pileups_default_beam_width(gpu_ctx, hip_lib, oracle_mod, seed):
     ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, s, e, eps=eps, P=P, B=10)
     assert_block_results_equal(ro, rg, f"seed {seed}")
     assert rg.min_prune_margin == ro.min_prune_margin
+
+
+def test_reassign_sparse_choices_parallel_kernel(gpu_ctx, hip_lib, oracle_mod):
+    # haplogroups as they come out of stitching: almost every read sits in ONE group, a few in two or three.  Such contigs run the
+    # workgroup-parallel S2 kernel (single-candidate reads are added in bulk between the reads that have a choice); dense contigs
+    # (test_reassign_parity) run the one-wavefront chain.  Both must equal the oracle for the canonical and for arbitrary orders.
+    rng = np.random.default_rng(21)
+    for cfg, idx, scale, n_groups in ((4, 6, 1.0, 4), (2, 0, 0.1, 3), (5, 0, 0.02, 8)):
+        c = synth.make_config_contig(cfg, idx, scale, keep_truth=True)
+        p = c.pileup
+        S = int(p.last.max())
+        groups = [np.nonzero(c.strain % n_groups == k)[0].astype(np.uint32) for k in range(n_groups)]
+        ranges = [(1, S)] * n_groups
+        extra = rng.choice(p.n_reads, size=max(4, p.n_reads // 40), replace=False)          # 2.5 % of the reads get a second / third candidate
+        for r in extra:
+            for k in rng.choice(n_groups, size=int(rng.integers(1, 3)), replace=False):
+                if r not in groups[k]:
+                    groups[k] = np.sort(np.append(groups[k], np.uint32(r)))
+        for order in (None, rng.permutation(p.n_reads).astype(np.uint32)):
+            go = oracle_mod.reassign(p, groups, ranges, EPS, read_order=order)
+            gg = gpu_ctx.reassign(p, groups, ranges, EPS, read_order=order)
+            assert np.array_equal(go.grp_off, gg.grp_off) and np.array_equal(go.grp_read, gg.grp_read) and np.array_equal(go.range, gg.range), (cfg, order is None)
+            assert 0 < gpu_ctx.timing()["jobs"] < p.n_reads // 8                           # sparse: the parallel kernel took it
+    # no read with a choice at all: no histogram work, assignment = the only candidate
+    c = synth.make_config_contig(4, 9, 0.5, keep_truth=True)
+    groups = [np.nonzero(c.strain == k)[0].astype(np.uint32) for k in range(int(c.strain.max()) + 1)]
+    ranges = [(1, int(c.pileup.last.max()))] * len(groups)
+    go = oracle_mod.reassign(c.pileup, groups, ranges, EPS)
+    gg = gpu_ctx.reassign(c.pileup, groups, ranges, EPS)
+    assert np.array_equal(go.grp_read, gg.grp_read) and np.array_equal(go.range, gg.range) and gpu_ctx.timing()["jobs"] == 0
