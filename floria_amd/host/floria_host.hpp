@@ -164,8 +164,10 @@ BamFile read_bam(const std::string& path);                                      
 std::vector<std::string> get_contigs_to_phase(const BamFile& bam);                     // file_reader.rs:738-746
 VcfProfile get_vcf_profile(const std::string& vcf_file, const std::vector<std::string>& ref_chroms);       // :239-314 (+ :113-175); text VCF, optionally gzipped
 std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file);      // :462-489 (whole sequences)
-// :343-460 + combine_frags :491-659 + frag_from_record :661-736; no realignment yet (alignment.rs)
-std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vcf_profile, const Options& options, const std::string& contig);
+// :343-460 + combine_frags :491-659 + frag_from_record :661-736; with `ref_seq` (the contig's reference sequence) every call is
+// realigned (alignment.rs:7-64, exact affine-gap DP in place of block-aligner)
+std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vcf_profile, const Options& options, const std::string& contig,
+                                                                               const std::string* ref_seq = nullptr);
 std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam);                   // :749-826
 
 // part_block_manip.rs:517-616: (hapqs, rel_err per haploset, avg_err) — the HAPQ / REL_ERR header fields and the contig table's avg_err.

@@ -9,8 +9,12 @@
 //   get_frags_from_bamvcf_rewrite  :343-460   (frags with SNPs, frags without)
 //   get_fasta_seqs                 :462-489   whole sequences (the writers need the contig length)
 //   l_epsilon_auto_detect          :749-826   every 1000th pileup column: minority / majority base ratio, read-length quantile
-// Not restated yet: alignment::realign (alignment.rs:7-64, block-aligner, third-party SIMD arithmetic): alleles are taken as
-// called.  For alignments without indels next to a SNP the realignment returns the called allele anyway.
+//   alignment::realign             alignment.rs:7-64   around every called SNP the read's 32 bases are globally aligned to the reference's 32
+//                                  bases with each allele in turn (match +1, mismatch -1, gap open -2, extend -1) and the best-scoring
+//                                  allele replaces the call.  The reference computes the scores with block-aligner 0.4.0 (a third-party
+//                                  adaptive banded SIMD aligner, fixed 8-wide blocks); here they come from the exact affine-gap DP, which
+//                                  the banded heuristic approximates — identical wherever its band contains an optimal path (parity of this
+//                                  step is unpinned: third-party arithmetic).  Only runs when a reference FASTA is given, as in the reference.
 // The whole BAM is read once and records are bucketed by contig in file order, so no .bai is needed; `count` (the enumerate
 // index frag_from_record stores in counter_id, which breaks ties of Frag::cmp in all_frags.sort(), floria.rs:289) is the
 // record's index among the contig's records, as with the reference's fetch().
@@ -19,6 +23,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -154,6 +159,57 @@ Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPositi
 
 struct Tagged { uint16_t flags; Frag frag; };
 
+// global alignment score of two byte strings, affine gaps: a gap of length n costs open + (n - 1) * extend
+int nw_affine_score(const unsigned char* q, int nq, const unsigned char* r, int nr) {
+    constexpr int MATCH = 1, MISMATCH = -1, OPEN = -2, EXTEND = -1, NEG = -(1 << 28);
+    static thread_local std::vector<int> Mv, Iv, Dv;             // (M: ends in a pair, I: gap in r, D: gap in q), rolling rows
+    Mv.assign(nr + 1, NEG); Iv.assign(nr + 1, NEG); Dv.assign(nr + 1, NEG);
+    Mv[0] = 0;
+    for (int j = 1; j <= nr; ++j) Dv[j] = OPEN + (j - 1) * EXTEND;
+    for (int i = 1; i <= nq; ++i) {
+        int m_diag = Mv[0], i_diag = Iv[0], d_diag = Dv[0];
+        Mv[0] = NEG; Dv[0] = NEG; Iv[0] = OPEN + (i - 1) * EXTEND;
+        for (int j = 1; j <= nr; ++j) {
+            const int m_up = Mv[j], i_up = Iv[j], d_up = Dv[j];
+            const int best_diag = std::max(m_diag, std::max(i_diag, d_diag));
+            const auto up = [](unsigned char c) { return (unsigned char)(c >= 'a' && c <= 'z' ? c - 32 : c); };
+            const int sub = up(q[i - 1]) == up(r[j - 1]) ? MATCH : MISMATCH;
+            const int m_new = best_diag + sub;
+            const int i_new = std::max(std::max(m_up, d_up) + OPEN, i_up + EXTEND);               // consume q[i-1] against a gap
+            const int d_new = std::max(std::max(Mv[j - 1], Iv[j - 1]) + OPEN, Dv[j - 1] + EXTEND);   // consume r[j-1] against a gap
+            m_diag = m_up; i_diag = i_up; d_diag = d_up;
+            Mv[j] = m_new; Iv[j] = i_new; Dv[j] = d_new;
+        }
+    }
+    return std::max(Mv[nr], std::max(Iv[nr], Dv[nr]));
+}
+
+// alignment::realign (alignment.rs:7-64)
+void realign(const std::string& ref_gn, Frag& frag, const std::string& read_seq, const std::map<SnpPosition, GnPosition>& var_to_gn_pos,
+             const std::map<GnPosition, std::vector<Genotype>>& gn_pos_to_allele) {
+    constexpr size_t flank = 16;
+    for (auto& kv : frag.seq_dict) {
+        const size_t snp_gn_pos = var_to_gn_pos.at(kv.first);
+        const size_t snp_q_pos = frag.snp_pos_to_seq_pos.at(kv.first).second;
+        if (flank > snp_gn_pos || flank + snp_gn_pos >= ref_gn.size() || flank > snp_q_pos || flank + snp_q_pos >= read_seq.size()) continue;
+        unsigned char q[2 * flank], r[2 * flank];
+        for (size_t i = 0; i < 2 * flank; ++i) {
+            const char c = read_seq[snp_q_pos - flank + i];                      // DnaString::from_acgt_bytes: anything but ACGT becomes A
+            q[i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? (unsigned char)c : ((c == 'a' || c == 'c' || c == 'g' || c == 't') ? (unsigned char)(c - 32) : 'A');
+            r[i] = (unsigned char)ref_gn[snp_gn_pos - flank + i];
+        }
+        const auto& alleles = gn_pos_to_allele.at(snp_gn_pos);
+        int best_score = INT32_MIN;
+        Genotype best_geno = 0;
+        for (size_t a = 0; a < alleles.size(); ++a) {
+            r[flank] = alleles[a];
+            const int score = nw_affine_score(q, 2 * flank, r, 2 * flank);
+            if (score > best_score) { best_score = score; best_geno = (Genotype)a; }
+        }
+        kv.second = best_geno;
+    }
+}
+
 }  // namespace
 
 BamFile read_bam(const std::string& path) {
@@ -265,7 +321,8 @@ std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file)
     return out;
 }
 
-std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vp, const Options& o, const std::string& contig) {
+std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vp, const Options& o, const std::string& contig,
+                                                                               const std::string* ref_seq) {
     const bool filter_supplementary = true, use_supplementary = !o.dont_use_supp_aln;
     const auto tid_it = std::find(bam.target_names.begin(), bam.target_names.end(), contig);
     if (tid_it == bam.target_names.end()) return {};
@@ -284,7 +341,9 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
         if (!alignment_passed_check(rec.flags, rec.mapq, use_supplementary, filter_supplementary, o.mapq_cutoff).first) continue;
         auto ins = name_ix.emplace(rec.qname, names.size());
         if (ins.second) { names.push_back(rec.qname); buckets.emplace_back(); }
-        buckets[ins.first->second].push_back({rec.flags, frag_from_record(rec, snp_positions, pos_allele_map, this_count)});
+        Frag fr = frag_from_record(rec, snp_positions, pos_allele_map, this_count);
+        if (ref_seq) realign(*ref_seq, fr, rec.seq, snp_to_gn, pos_allele_map);                    // :416-423
+        buckets[ins.first->second].push_back({rec.flags, std::move(fr)});
     }
     // combine_frags (:491-659)
     std::vector<Frag> ref_frags;

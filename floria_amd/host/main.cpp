@@ -7,7 +7,7 @@
 //
 // Flags of the reference that are not supported and say so: -H/--hybrid, --reassign-short, --bin-by-cov, --output-reads,
 // --gzip-reads, --extra-trimming, --ignore-monomorphic, -q (accepted and ignored by the reference too).  Extras: --device N,
-// --dump-frags FILE (the ingested Frags as text, for tests).
+// --debug (debug_graph.txt per contig), and for tests --dump-frags FILE, --ingest-only, --no-realign, --stitch-graph FILE.
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     Options o;
     bool have_e = false, have_l = false;
     std::string dump_frags;
-    bool ingest_only = false;
+    bool ingest_only = false, no_realign = false;
     std::string stitch_graph;
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
     try {
@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
             else if (a == "--dump-frags") dump_frags = val();
+            else if (a == "--no-realign") no_realign = true;                   // (tests) keep the alleles as called
             else if (a == "--ingest-only") ingest_only = true;          // (tests) stop after ingest: needs no GPU
             else if (a == "--stitch-graph") stitch_graph = val();       // (tests) N / E lines of a hap graph -> F / P lines on stdout: needs no GPU
             else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -150,7 +151,8 @@ int main(int argc, char** argv) {
                 continue;
             }
             const double t0 = now_s();
-            auto fr = get_frags_from_bamvcf_rewrite(bam, vp, o, contig);
+            const auto fa0 = fasta.find(contig);
+            auto fr = get_frags_from_bamvcf_rewrite(bam, vp, o, contig, (fa0 != fasta.end() && !no_realign) ? &fa0->second : nullptr);
             std::vector<Frag>& all_frags = fr.first;
             const std::vector<Frag>& frags_without_snps = fr.second;
             fprintf(stderr, "Number of reads passing filtering: %zu\n", all_frags.size());

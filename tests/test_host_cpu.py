@@ -158,3 +158,73 @@ def test_auto_detect_matches_the_restatement(floria_hip, tmp_path):
     m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
     l, e = l_epsilon_restated(ex["alignments"])
     assert m and int(m.group(1)) == l and abs(float(m.group(2)) - e) < 1e-5 * e, (m.group(0), l, e)
+
+
+def nw_affine(q, r, match=1, mismatch=-1, gap_open=-2, gap_extend=-1):
+    """global alignment score, gap of length n costs open + (n - 1) * extend (Gotoh, plain Python: independent of ingest.cpp)"""
+    NEG = -10 ** 9
+    n, m = len(q), len(r)
+    M = [[NEG] * (m + 1) for _ in range(n + 1)]; X = [[NEG] * (m + 1) for _ in range(n + 1)]; Y = [[NEG] * (m + 1) for _ in range(n + 1)]
+    M[0][0] = 0
+    for i in range(1, n + 1): X[i][0] = gap_open + (i - 1) * gap_extend
+    for j in range(1, m + 1): Y[0][j] = gap_open + (j - 1) * gap_extend
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            s = match if q[i - 1].upper() == r[j - 1].upper() else mismatch
+            M[i][j] = max(M[i - 1][j - 1], X[i - 1][j - 1], Y[i - 1][j - 1]) + s
+            X[i][j] = max(max(M[i - 1][j], Y[i - 1][j]) + gap_open, X[i - 1][j] + gap_extend)
+            Y[i][j] = max(max(M[i][j - 1], X[i][j - 1]) + gap_open, Y[i][j - 1] + gap_extend)
+    return max(M[n][m], X[n][m], Y[n][m])
+
+
+def test_realign_changes_calls_next_to_unreported_indels(floria_hip, tmp_path):
+    # alignment::realign (alignment.rs:7-64): a read that lost one base shortly before a SNP but was aligned without a gap shows the
+    # NEXT reference base in the SNP column; re-aligning its 32 bases against the reference with each allele in turn recovers the allele
+    # (or keeps the call).  Expected alleles come from a plain-Python Gotoh DP with the same scores.
+    rng = np.random.default_rng(12)
+    L = 4000
+    ref = "".join("ACGT"[i] for i in rng.integers(0, 4, size=L))
+    snps = list(range(200, 3800, 60))
+    alt = {p: "ACGT"[("ACGT".index(ref[p]) + 1 + int(rng.integers(0, 3))) % 4] for p in snps}
+    recs, truth = [], []
+    for k in range(60):
+        b = int(rng.integers(0, 1500)); e = b + 2000
+        hap = k % 2
+        seq = list(ref[b:e])
+        for p in snps:
+            if b <= p < e and hap:
+                seq[p - b] = alt[p]
+        cut = None
+        if k % 3 == 0:                                  # drop one base 2..6 bases before some SNP, keep the all-match CIGAR
+            p = [x for x in snps if b + 100 <= x < e - 100][k % 7]
+            cut = p - b - int(rng.integers(2, 7))
+            del seq[cut]
+        seq = "".join(seq)
+        recs.append((b, synth_bam.bam_record(0, b, f"r{k}", 0, 60, [("M", len(seq))], seq.encode(), np.full(len(seq), 30, np.uint8))))
+        truth.append((b, seq))
+    recs.sort(key=lambda t: t[0])
+    prefix = str(tmp_path / "ra")
+    synth_bam.write_bam(prefix + ".bam", [("ctg", L)], [r for _, r in recs])
+    open(prefix + ".fa", "w").write(">ctg\n" + ref + "\n")
+    with open(prefix + ".vcf", "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for p in snps:
+            f.write(f"ctg\t{p + 1}\t.\t{ref[p]}\t{alt[p]}\t50\tPASS\t.\n")
+    called, _ = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10", "--no-realign"))
+    realigned, _ = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10"))
+    seq_of = {f"r{k}": truth[k] for k in range(60)}
+    changed = 0
+    for rc, rr in zip(called["ctg"]["reads"], realigned["ctg"]["reads"]):
+        assert rc["name"] == rr["name"] and [c[0] for c in rc["cells"]] == [c[0] for c in rr["cells"]]
+        b, seq = seq_of[rc["name"]]
+        for (snp, a_called, _), (_, a_re, _) in zip(rc["cells"], rr["cells"]):
+            p = snps[snp - 1]
+            qpos = p - b
+            if qpos < 16 or qpos + 16 >= len(seq) or p < 16 or p + 16 >= L:
+                assert a_re == a_called
+                continue
+            q = "".join(c if c in "ACGT" else "A" for c in seq[qpos - 16:qpos + 16])
+            scores = [nw_affine(q, ref[p - 16:p] + al + ref[p + 1:p + 16]) for al in (ref[p], alt[p])]
+            assert a_re == (0 if scores[0] >= scores[1] else 1), (rc["name"], snp)
+            changed += a_re != a_called
+    assert changed > 0
