@@ -7,9 +7,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --check 0 --pipeline 0 > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_write.log 2>&1
 cd $R
 python - <<PY
 import csv, json, collections, glob
@@ -22,7 +22,7 @@ def agg(path, name):
             k=r["Kernel_Name"].split("(")[0]; tot[k]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     return {k:(v,len(n[k])) for k,v in tot.items()}
 f=agg(O+"/pmc_fetch","FETCH_SIZE"); w=agg(O+"/pmc_write","WRITE_SIZE")
-out={"workload":"config4","contigs_per_rank":2000,"note":"rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 0); FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 FETCH_SIZE under-reports wide coalesced streams by 2x (MI355X_MICROARCH.md §HBM), so the read side is doubled (upper bound for this scattered 16-B access pattern)","kernels":{}}
+out={"workload":"config4","contigs_per_rank":2000,"note":"rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 0 --resident-only: one warm-up and one timed S1 call over the resident batch); FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 FETCH_SIZE under-reports wide coalesced streams by 2x (MI355X_MICROARCH.md §HBM), so the read side is doubled (upper bound for this scattered 16-B access pattern)","kernels":{}}
 for k in f:
     if "beam" in k or "optimize" in k:
         fk,nl=f[k]; wk,_=w.get(k,(0,nl))
@@ -49,8 +49,8 @@ PY
 grep '^{' $O/bench_stats.log | tail -1 > $O/bench.json
 # ---- SQ counters (two more passes): VALU / SALU / LDS / VMEM instruction counts, busy and wait cycles per kernel --------------------
 cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq1 -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/bench_sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU --output-format csv -d $O/pmc_sq2 -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/bench_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq1 -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU --output-format csv -d $O/pmc_sq2 -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_sq2.log 2>&1
 cd $R
 python - <<PY
 import csv, json, collections, glob
@@ -87,6 +87,9 @@ if kt:
         if a and dur.get(k):
             out["kernels"][k]["kernel_seconds_in_counter_pass"]=round(dur[k],5)
             out["kernels"][k]["valu_busy_frac"]=round(a*4/(dur[k]*2.37e9*1024),3)      # 4 cycles per wave instruction, 1024 SIMDs, 2.37 GHz measured core clock
+        tc=raw[k].get("SQ_THREAD_CYCLES_VALU")
+        if a and tc:
+            out["kernels"][k]["lane_utilisation"]=round(tc/(64.0*a),3)                 # active lanes per VALU instruction cycle / 64
 json.dump(out, open(O+"/sq_counters.json","w"), indent=1)
 print(json.dumps(out["kernels"])[:900])
 PY
