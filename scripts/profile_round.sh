@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --check 0 --pipeline 0 > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o $TAG -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only > $O/bench_write.log 2>&1
 cd $R
@@ -43,7 +43,7 @@ for key in ("beam_slab_kernel","optimize_kernel"):
     calls=sum(int(r["Calls"]) for r in rs); tot=sum(float(r["TotalDurationNs"]) for r in rs)
     fam[key]={"instances":[{"name":r["Name"].split("(")[0],"calls":int(r["Calls"]),"avg_ms":float(r["AverageNs"])/1e6} for r in rs],
               "calls":calls,"avg_launch_ms":tot/calls/1e6 if calls else None,"total_ms":tot/1e6}
-json.dump({"note":"per-family aggregate of rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1): the ploidy-specialised instances of one kernel are separate rows in kernel_stats.csv; bench.py's roofline.avg_launch_ms is the calls-weighted mean over the beam_slab_kernel family","families":fam}, open("$O/kernel_family_stats.json","w"), indent=1)
+json.dump({"note":"per-family aggregate of rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1 --resident-only: the resident pass the roofline block is measured in): the ploidy-specialised instances of one kernel are separate rows in kernel_stats.csv; bench.py's roofline.avg_launch_ms is the calls-weighted mean over the beam_slab_kernel family","families":fam}, open("$O/kernel_family_stats.json","w"), indent=1)
 print(json.dumps({k:(v["calls"],round(v["avg_launch_ms"],3)) for k,v in fam.items()}))
 PY
 grep '^{' $O/bench_stats.log | tail -1 > $O/bench.json
