@@ -145,6 +145,7 @@ struct Knobs {
     uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
     uint32_t spec_desc = 0;       // speculative stage: launch the highest ploidy first
+    uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
 };
 
 struct Arena;
@@ -686,6 +687,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 3));
     else if (k == "trace") K.trace = value != 0;
+    else if (k == "reassign_path") { if (value < 0 || value > 2) return fail(FLORIA_E_INVALID, "reassign_path: 0 auto | 1 parallel | 2 chain"); K.reassign_path = (uint32_t)value; }
     else if (k == "slots") ctx->user_slots = (uint32_t)std::max<int64_t>(0, value);
     else if (k == "stage_threads") ctx->stage_threads = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else return fail(FLORIA_E_INVALID, "unknown option '" + k + "'");
@@ -1894,7 +1896,8 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         for (uint32_t ci = 0; ci < n_contigs; ++ci) {
             const uint64_t nm = multi_off_all[ci + 1] - multi_off_all[ci];
             const uint64_t nv = read_order ? order_off[ci + 1] - order_off[ci] : contigs[ci]->n_reads;
-            (nm * 8 >= nv && nm > 0 ? list_chain : list_par).push_back(ci);
+            const bool chain = ctx->knobs.reassign_path == 2 || (ctx->knobs.reassign_path == 0 && nm * 8 >= nv && nm > 0);
+            (chain ? list_chain : list_par).push_back(ci);
         }
         std::vector<uint32_t> lists(list_par);
         lists.insert(lists.end(), list_chain.begin(), list_chain.end());
