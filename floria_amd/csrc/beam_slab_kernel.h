@@ -18,7 +18,7 @@
 // Slab layout: [pos][allele] u64 (16 B per SNP for biallelic data): consecutive cells of a read are consecutive
 // 16-B pieces, so four cells share a 64-B line.
 #pragma once
-#include "beam_fast_kernel.h"
+#include "wave_util.h"
 
 namespace fl {
 

@@ -29,7 +29,7 @@
 
 #include "../../include/floria_hip.h"
 #include "beam_kernel.h"
-#include "beam_fast_kernel.h"
+#include "wave_util.h"
 #include "beam_slab_kernel.h"
 #include "beam_wide_kernel.h"
 #include "optimize_kernel.h"
@@ -131,11 +131,11 @@ BigCache g_big;
 }  // namespace
 
 // Tuning / test knobs of a context (floria_hip_set_option); the defaults are what bench.py measures.  Read from the environment
-// ONCE, at floria_hip_create (FLORIA_HIP_GROUPS, FLORIA_HIP_BEAM, FLORIA_HIP_NO_SPECIALIZED, FLORIA_HIP_NO_P1_SHORTCUT,
+// ONCE, at floria_hip_create (FLORIA_HIP_GROUPS, FLORIA_HIP_BEAM=generic|slab|wide, FLORIA_HIP_NO_SPECIALIZED, FLORIA_HIP_NO_P1_SHORTCUT,
 // FLORIA_HIP_OPT_THREADS, FLORIA_HIP_OPT_GLOBAL, FLORIA_HIP_SPECULATE); none of them changes results.
 struct Knobs {
     uint32_t groups = 0;          // job groups (0 = auto: 2 when the batch has >= 2048 non-empty blocks)
-    uint32_t beam_path = 0;       // 0 auto | 1 generic | 2 fast | 3 slab | 4 wide
+    uint32_t beam_path = 0;       // 0 auto | 1 generic | 2 slab | 3 wide
     uint32_t no_specialized = 0;  // runtime ploidy / beam width instead of the template instances
     uint32_t no_p1_shortcut = 0;  // run the beam kernel for ploidy 1 too
     uint32_t opt_threads = 0;     // 0 auto | 128 | 512 | 1024
@@ -328,7 +328,7 @@ double mec_threshold(const floria_params* prm, uint32_t p) {
 
 struct PloidyPlan {
     uint32_t p = 0, LM = 0;
-    bool shortcut = false, wide = false, slab = false, fast = false, beam_spec = false;
+    bool shortcut = false, wide = false, slab = false, beam_spec = false;
     uint64_t state_bytes = 0, hist_stride = 0;
     fl::SlabLds SL{}; fl::WideLds WL{}; fl::BeamLds LY{};
     uint32_t beam_slots = 0;
@@ -383,16 +383,15 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * waves_per_simd, by_lds);
         q.beam_slots = std::min(q.beam_slots, nj_max);
         const bool fits32 = q.state_bytes < 0xf0000000ull;
-        const bool small = LM <= 63 && fits32;
+        // shared-slab kernels: register heap for ploidy*beam <= 63 (the CLI defaults give <= 50), LDS heap beyond; the generic kernel
+        // (per-state slabs, any size) remains for beams whose slab tables fit neither
         const bool wide_ok = fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && q.WL.total <= 150 * 1024;
-        q.wide = !small && wide_ok;
-        q.slab = small && LM * p <= (uint32_t)fl::SLAB_NS_MAX && q.SL.total <= 60 * 1024;
-        q.fast = small;
+        q.slab = LM <= 63 && fits32 && LM * p <= (uint32_t)fl::SLAB_NS_MAX && q.SL.total <= 60 * 1024;
+        q.wide = !q.slab && wide_ok;
         switch (K.beam_path) {                               // dev/test knob
-            case 1: q.wide = false; q.slab = false; q.fast = false; break;     // generic
-            case 2: q.wide = false; q.slab = false; break;                     // fast (where it applies)
-            case 3: q.wide = false; break;                                     // slab (where it applies)
-            case 4: q.wide = wide_ok; break;                                   // wide (where it applies)
+            case 1: q.wide = false; q.slab = false; break;                     // generic
+            case 2: q.wide = false; break;                                     // slab (where it applies, else generic)
+            case 3: q.wide = wide_ok; q.slab = q.slab && !wide_ok; break;      // wide (where it applies)
             default: break;
         }
         if (!q.shortcut) {
@@ -514,10 +513,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         else if (q.beam_spec && p == 4) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
                         else if (q.beam_spec && p == 5) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
                         else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), q.SL.total, st, a);
-                    } else if (q.fast) {
-                        const fl::FastLds FL = fl::fast_lds_layout(q.LM, any_q0);
-                        if (any_q0) hipLaunchKernelGGL((fl::beam_fast_kernel<A, true>), dim3(slots), dim3(64), FL.total, st, a);
-                        else hipLaunchKernelGGL((fl::beam_fast_kernel<A, false>), dim3(slots), dim3(64), FL.total, st, a);
                     } else {
                         HIPCHK(big_lds((const void*)fl::beam_kernel<A>, q.LY.total));
                         hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), q.LY.total, st, a);
@@ -630,7 +625,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
     {   // development knobs: environment defaults, read once (floria_hip_set_option overrides them)
         Knobs& K = c->knobs;
         if (const char* v = getenv("FLORIA_HIP_GROUPS")) K.groups = (uint32_t)std::max(0, std::min<int>(atoi(v), floria_hip_ctx::MAX_GROUPS));
-        if (const char* v = getenv("FLORIA_HIP_BEAM")) K.beam_path = !strcmp(v, "generic") ? 1 : !strcmp(v, "fast") ? 2 : !strcmp(v, "slab") ? 3 : !strcmp(v, "wide") ? 4 : 0;
+        if (const char* v = getenv("FLORIA_HIP_BEAM")) K.beam_path = !strcmp(v, "generic") ? 1 : !strcmp(v, "slab") ? 2 : !strcmp(v, "wide") ? 3 : 0;
         K.no_specialized = getenv("FLORIA_HIP_NO_SPECIALIZED") != nullptr;
         K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
@@ -678,7 +673,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     const std::string k(key);
     Knobs& K = ctx->knobs;
     if (k == "groups") K.groups = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
-    else if (k == "beam_path") { if (value < 0 || value > 4) return fail(FLORIA_E_INVALID, "beam_path: 0 auto | 1 generic | 2 fast | 3 slab | 4 wide"); K.beam_path = (uint32_t)value; }
+    else if (k == "beam_path") { if (value < 0 || value > 3) return fail(FLORIA_E_INVALID, "beam_path: 0 auto | 1 generic | 2 slab | 3 wide"); K.beam_path = (uint32_t)value; }
     else if (k == "no_specialized") K.no_specialized = value != 0;
     else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }

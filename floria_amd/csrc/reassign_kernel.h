@@ -9,7 +9,7 @@
 // ascending counter_id when none is given.
 // separate_broken_haplogroups / sort_parts (:27-98, :276-288) are integer bookkeeping done by the host.
 #pragma once
-#include "beam_fast_kernel.h"     // rl32 / rl64 / uni
+#include "wave_util.h"     // rl32 / rl64 / uni
 
 namespace fl {
 

@@ -239,8 +239,8 @@ def test_hap_graph_nodes_and_edges(gpu_ctx, hip_lib, oracle_mod, cfg, n_contigs,
 
 @pytest.mark.parametrize("seed", range(24))
 def test_random_medium_pileups_all_beam_paths(gpu_ctx, hip_lib, oracle_mod, seed):
-    # medium blocks (hundreds of reads, deeper coverage, ties from identical reads) through the three beam kernels:
-    # shared-slab (default), per-state-slab (fast), the generic LDS-heap kernel and the wide-beam shared-slab kernel must all equal the oracle
+    # medium blocks (hundreds of reads, deeper coverage, ties from identical reads) through the three beam kernels: shared-slab with the
+    # register heap (default), the generic per-state-slab LDS-heap kernel and the wide-beam shared-slab kernel must all equal the oracle
     rng = np.random.default_rng(5000 + seed)
     ploidy = int(rng.integers(1, 6))
     pile = random_pileup(rng, int(rng.integers(150, 600)), int(rng.integers(20, 120)), ploidy, max_len=int(rng.integers(3, 60)),
@@ -252,7 +252,7 @@ def test_random_medium_pileups_all_beam_paths(gpu_ctx, hip_lib, oracle_mod, seed
     eps = [EPS, 0.04][seed % 2]
     ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, B), threads=4)
     try:
-        for code, path in ((3, "slab"), (2, "fast"), (1, "generic"), (4, "wide")):
+        for code, path in ((2, "slab"), (1, "generic"), (3, "wide")):
             gpu_ctx.set_option("beam_path", code)
             for spec in (0, 1):                      # one ploidy per stage / all ploidies of a block at once
                 gpu_ctx.set_option("speculate", spec)
@@ -553,3 +553,14 @@ def test_reassign_sparse_choices_parallel_kernel(gpu_ctx, hip_lib, oracle_mod):
     go = oracle_mod.reassign(c.pileup, groups, ranges, EPS)
     gg = gpu_ctx.reassign(c.pileup, groups, ranges, EPS)
     assert np.array_equal(go.grp_read, gg.grp_read) and np.array_equal(go.range, gg.range) and gpu_ctx.timing()["jobs"] == 0
+
+
+def test_narrow_beam_with_many_slabs_takes_the_wide_kernel(gpu_ctx, hip_lib, oracle_mod):
+    # -p 9 -n 7: ploidy*beam = 63 fits the register heap, but ploidy^2*beam = 567 slabs exceed the slab kernel's table (512): the wide-beam kernel
+    # takes the job (round 1 kept a third kernel for this corner)
+    rng = np.random.default_rng(909)
+    pile = random_pileup(rng, 160, 50, 4, max_len=30)
+    S = int(pile.last.max())
+    ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1, S // 2], [S // 2 + 4, S], P=9, B=7)
+    assert_block_results_equal(ro, rg, "p9 n7")
+    assert rg.min_prune_margin == ro.min_prune_margin
