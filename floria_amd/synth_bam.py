@@ -133,8 +133,73 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60):
     return dict(ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
 
 
-def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1):
-    """Write {prefix}.bam / .vcf / .fa for a list of synth Contigs (keep_layout=True).  Returns, per contig name,
+def nw_affine_batch(Q, R, match=1, mismatch=-1, gap_open=-2, gap_extend=-1):
+    """Global alignment scores of N sequence pairs at once (Q, R: uint8 [N, n] / [N, m]); a gap of length k costs open + (k - 1) * extend
+    (Gotoh).  The scoring of alignment::realign (alignment.rs:15-18: NW1, Gaps { open: -2, extend: -1 })."""
+    N, n = Q.shape
+    m = R.shape[1]
+    NEG = -10 ** 6
+    M = np.full((N, m + 1), NEG, np.int32); X = np.full((N, m + 1), NEG, np.int32); Y = np.full((N, m + 1), NEG, np.int32)
+    M[:, 0] = 0
+    Y[:, 1:] = gap_open + gap_extend * np.arange(m)
+    for i in range(1, n + 1):
+        Mn = np.full((N, m + 1), NEG, np.int32); Xn = np.full((N, m + 1), NEG, np.int32); Yn = np.full((N, m + 1), NEG, np.int32)
+        Xn[:, 0] = gap_open + (i - 1) * gap_extend
+        sub = np.where(Q[:, i - 1:i] == R, match, mismatch).astype(np.int32)
+        Mn[:, 1:] = np.maximum(np.maximum(M[:, :-1], X[:, :-1]), Y[:, :-1]) + sub
+        Xn[:, 1:] = np.maximum(np.maximum(M[:, 1:], Y[:, 1:]) + gap_open, X[:, 1:] + gap_extend)
+        for j in range(1, m + 1):
+            Yn[:, j] = np.maximum(np.maximum(Mn[:, j - 1], Xn[:, j - 1]) + gap_open, Yn[:, j - 1] + gap_extend)
+        M, X, Y = Mn, Xn, Yn
+    return np.maximum(np.maximum(M[:, m], X[:, m]), Y[:, m])
+
+
+def realign_dataset(d, flank=16):
+    """What alignment::realign (alignment.rs:7-64) makes of the calls of contig_dataset `d`: every call whose 2 x 16-base windows fit is
+    replaced by the allele whose reference window aligns best to the read's window (first best).  Updates d["reads"][...] cells in place."""
+    ref = np.frombuffer(d["ref"], np.uint8)
+    snp_pos = np.array([q for q, _, _ in d["snps"]], np.int64)
+    alleles = [(ord(r), ord(a)) for _, r, a in d["snps"]]
+    wq, wr0, wr1, where = [], [], [], []
+    for ri, (name, cells, span, recs_r, slen) in enumerate(d["reads"]):
+        cell_ix = {c[0] - 1: k for k, c in enumerate(cells)}
+        for pos, _rec, seq, cigar in recs_r:                      # a later alignment of the read overwrites an earlier call (extend)
+            sq = np.frombuffer(seq, np.uint8)
+            q, r = 0, pos
+            for op, ln in cigar:
+                if op == "M":
+                    lo, hi = np.searchsorted(snp_pos, r, "left"), np.searchsorted(snp_pos, r + ln, "left")
+                    for i in range(lo, hi):
+                        if i not in cell_ix:
+                            continue
+                        gp = int(snp_pos[i]); qp = q + (gp - r)
+                        if flank > gp or flank + gp >= len(ref) or flank > qp or flank + qp >= len(sq):
+                            continue
+                        w = ref[gp - flank:gp + flank].copy()
+                        w0 = w.copy(); w0[flank] = alleles[i][0]
+                        w1 = w.copy(); w1[flank] = alleles[i][1]
+                        wq.append(sq[qp - flank:qp + flank]); wr0.append(w0); wr1.append(w1); where.append((ri, cell_ix[i]))
+                if op in "MIS":
+                    q += ln
+                if op in "MDN":
+                    r += ln
+    if not wq:
+        return 0
+    Q = np.array(wq, np.uint8)
+    s0 = nw_affine_batch(Q, np.array(wr0, np.uint8)); s1 = nw_affine_batch(Q, np.array(wr1, np.uint8))
+    changed = 0
+    for (ri, k), a0, a1 in zip(where, s0, s1):
+        new = 0 if a0 >= a1 else 1
+        name, cells, span, recs_r, slen = d["reads"][ri]
+        if cells[k][1] != new:
+            changed += 1
+        cells[k] = (cells[k][0], new, cells[k][2])
+    return changed
+
+
+def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, realign=True):
+    """Write {prefix}.bam / .vcf / .fa for a list of synth Contigs (keep_layout=True).  With realign=False the returned pileups hold the
+    calls as sequenced (floria-hip --no-realign).  Returns, per contig name,
     dict(pileup=Pileup in the order a correct ingest produces, names=[read name], spans=[(first_pos_base, last_pos_base)],
          snp_pos0=[0-based genome position of every SNP], contig_len, seq_len=[bases of every read])."""
     rng = np.random.default_rng(seed)
@@ -145,6 +210,8 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1):
     datasets = []
     for tid, c in enumerate(contigs):
         d = contig_dataset(c, rng, edit_frac=edit_frac)
+        if realign:                # the pileup floria makes of these files when a reference FASTA is given (it always is): calls realigned
+            d["realigned_calls"] = realign_dataset(d)
         datasets.append(d)
         targets.append((c.name, d["contig_len"]))
         vcf.write(f"##contig=<ID={c.name},length={d['contig_len']}>\n")
