@@ -140,7 +140,7 @@ struct Knobs {
     uint32_t no_p1_shortcut = 0;  // run the beam kernel for ploidy 1 too
     uint32_t opt_threads = 0;     // 0 auto | 128 | 512 | 1024
     uint32_t opt_global = 0;      // optimise histogram in HBM
-    int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P}
+    int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P} | 3 {1..P-1} then {P}
     uint32_t upload_chunks = 0;   // floria_hip_phase_pileups_batch: chunks the cell arrays travel in (0 = auto by size, <= 8)
     uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
@@ -630,7 +630,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
-        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(2, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(3, atoi(v)));
         if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(3, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
@@ -678,7 +678,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
     else if (k == "opt_global") K.opt_global = value != 0;
-    else if (k == "speculate") { if (value < -1 || value > 2) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2"); K.speculate = (int32_t)value; }
+    else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 3));
     else if (k == "trace") K.trace = value != 0;
@@ -1222,6 +1222,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
                               if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
+        else if (spec == 3) { stages.emplace_back(); for (uint32_t p = 1; p < P; ++p) stages.back().push_back(p); stages.push_back({P}); }
         else for (uint32_t p = 1; p <= P; ++p) stages.push_back({p});
     }
     uint32_t stage_w = 1;
