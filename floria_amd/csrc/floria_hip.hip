@@ -1216,8 +1216,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         int spec = ctx->knobs.speculate;
         const bool slab_path = P * prm->beam <= 63 && !ctx->knobs.beam_path;          // the wide-beam kernels own whole CUs: nothing to gain there
         // (measured on config-4 shards: all ploidies at once wins below ~2k blocks — 250 contigs: 33 vs 40 ms — and loses above — 500 contigs: 64 vs 47 ms)
-        if (spec < 0) spec = (slab_path && G == 1 && P >= 3 && jobs.size() * 2 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
-        if (chunked) spec = 0;
+        if (spec < 0) spec = (slab_path && (G == 1 || chunked) && P >= 3 && jobs.size() * 2 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
@@ -1396,7 +1395,7 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     uint64_t cells = 0;
     for (uint32_t i = 0; i < n_contigs; ++i) if (pileups[i].n_reads && pileups[i].read_off) cells += pileups[i].read_off[pileups[i].n_reads];
     // auto: ~0.5 GB of host pileup per chunk, at most 5 (measured on BASELINE config 4, 2.65 GB: 5 chunks, the first one half-size, are best)
-    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(5, cells * 6 / (448ull << 20)));
+    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (448ull << 20)));
     UploadPlan UP;
     int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(want_chunks, floria_hip_ctx::MAX_GROUPS), UP);
     if (rc) return rc;
