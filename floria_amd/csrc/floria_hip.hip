@@ -631,7 +631,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(3, atoi(v)));
-        if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(3, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(4, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
@@ -680,7 +680,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "opt_global") K.opt_global = value != 0;
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
-    else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 3));
+    else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 4));
     else if (k == "trace") K.trace = value != 0;
     else if (k == "reassign_path") { if (value < 0 || value > 2) return fail(FLORIA_E_INVALID, "reassign_path: 0 auto | 1 parallel | 2 chain"); K.reassign_path = (uint32_t)value; }
     else if (k == "slots") ctx->user_slots = (uint32_t)std::max<int64_t>(0, value);
@@ -825,6 +825,7 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, u
         for (uint32_t g = 0; g < n_chunks; ++g) {
             double w = 1.0;
             if (ctx->knobs.upload_split == 1 && n_chunks >= 3) w = (g == 0 || g + 1 == n_chunks) ? 0.5 : 1.0;
+            else if (ctx->knobs.upload_split == 4 && n_chunks >= 3) w = g == 0 ? 0.25 : (g == 1 ? 0.75 : 1.0);
             else if (ctx->knobs.upload_split == 2 && n_chunks >= 2) w = g == 0 ? 0.5 : 1.0;
             else if (ctx->knobs.upload_split == 3 && n_chunks >= 2) w = 1.0 + g;
             cum[g + 1] = cum[g] + w;
@@ -1418,7 +1419,6 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
         rc = issue_copies(ctx, UP.small_runs, &pinned_b, &staged_b);                       // main stream: read_off / first / last + tables
         hipError_t e = rc ? hipSuccess : issue_tables(ctx, UP, ctx->stream);
         if (!rc && e == hipSuccess) e = hipEventRecord(ctx->ev_chunk[UP.n_chunks], ctx->stream);
-        if (!rc && e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_chunk[UP.n_chunks], 0);
         if (!rc && e == hipSuccess) e = hipStreamWaitEvent(ctx->flat_stream, ctx->ev_chunk[UP.n_chunks], 0);
         for (uint32_t g = 0; g < UP.n_chunks && !rc && e == hipSuccess; ++g) {             // copy stream: the cells of chunk g, back to back with chunk g+1;
             for (const CopyRun& r : UP.chunk_runs[g]) { pinned_b += r.bytes; if (e == hipSuccess) e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyHostToDevice, ctx->copy_stream); }
