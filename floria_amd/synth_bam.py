@@ -42,6 +42,9 @@ def _reg2bin(beg, end):
 
 _CIG = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5}
 _NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_NT16_LUT = np.full(256, 15, np.uint8)
+for _c, _i in _NT16.items():
+    _NT16_LUT[ord(_c)] = _i
 
 
 def bam_record(tid, pos, name, flag, mapq, cigar, seq, qual, next_pos=-1, tlen=0):
@@ -49,12 +52,12 @@ def bam_record(tid, pos, name, flag, mapq, cigar, seq, qual, next_pos=-1, tlen=0
     ref_len = sum(n for op, n in cigar if op in "MDN")
     nm = name.encode() + b"\0"
     cig = b"".join(struct.pack("<I", (n << 4) | _CIG[op]) for op, n in cigar)
-    s = seq.decode()
-    packed = bytearray((len(s) + 1) // 2)
-    for i, ch in enumerate(s):
-        packed[i // 2] |= _NT16[ch] << (4 if i % 2 == 0 else 0)
-    body = (struct.pack("<iiBBHHHIiii", tid, pos, len(nm), mapq, _reg2bin(pos, pos + max(1, ref_len)), len(cigar), flag, len(s),
-                        tid if next_pos >= 0 else -1, next_pos, tlen) + nm + cig + bytes(packed) + bytes(np.asarray(qual, np.uint8)))
+    codes = _NT16_LUT[np.frombuffer(seq, np.uint8)]
+    if len(codes) % 2:
+        codes = np.append(codes, np.uint8(0))
+    packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)
+    body = (struct.pack("<iiBBHHHIiii", tid, pos, len(nm), mapq, _reg2bin(pos, pos + max(1, ref_len)), len(cigar), flag, len(seq),
+                        tid if next_pos >= 0 else -1, next_pos, tlen) + nm + cig + packed.tobytes() + bytes(np.asarray(qual, np.uint8)))
     return struct.pack("<I", len(body)) + body
 
 

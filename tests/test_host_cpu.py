@@ -152,7 +152,7 @@ def test_auto_detect_matches_the_restatement(floria_hip, tmp_path):
     import re
     c = synth.make_config_contig(4, 1, keep_layout=True)
     prefix = str(tmp_path / "d")
-    ex = synth_bam.write_dataset(prefix, [c], seed=2, edit_frac=0.0)[c.name]
+    ex = synth_bam.write_dataset(prefix, [c], seed=2, edit_frac=0.0, realign=False)[c.name]
     r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", str(tmp_path / "u"), "--ingest-only"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
