@@ -42,6 +42,42 @@ std::vector<std::pair<SnpPosition, SnpPosition>> get_range_with_lengths(const st
     return out;
 }
 
+namespace {
+// process_chunks (graph_processing.rs:306-323) + update_hap_graph's edge lists (:22-100) for the blocks [b0, b1) of one contig out of a batch
+// result: columns = blocks that returned Some, in block order; ids run over the contig's nodes; edges with weight >= MIN_SHARED_READS_UNAMBIG (:51)
+std::vector<std::vector<HapNode>> build_columns(const floria_block_result* res, const floria_hap_graph* hg, uint32_t b0, uint32_t b1, const std::vector<Frag>& all_frags,
+                                                const std::vector<std::pair<SnpPosition, SnpPosition>>& iter_vec) {
+    std::vector<std::vector<HapNode>> cols;
+    std::vector<size_t> col_of_block(b1 - b0, SIZE_MAX);
+    size_t id_counter = 0;
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t p = res->best_ploidy[b];
+        if (p == 0) continue;
+        std::vector<HapNode> col(p);
+        for (uint64_t i = res->read_off[b]; i < res->read_off[b + 1]; ++i) col[res->part[i]].frag_set.push_back(&all_frags[res->read_id[i]]);
+        for (uint32_t k = 0; k < p; ++k) {
+            col[k].row = k; col[k].column = cols.size(); col[k].id = id_counter++;
+            col[k].snp_endpoints = iter_vec[b - b0];
+            col[k].cov = hg->node_cov[hg->node_off[b] + k];
+        }
+        col_of_block[b - b0] = cols.size();
+        cols.push_back(std::move(col));
+    }
+    for (uint32_t b = b0; b < b1; ++b) {
+        const int32_t pb = hg->pred[b];
+        if (pb < 0 || res->best_ploidy[b] == 0) continue;
+        auto& c1 = cols[col_of_block[(uint32_t)pb - b0]]; auto& c2 = cols[col_of_block[b - b0]];
+        const uint32_t p1 = res->best_ploidy[pb], p2 = res->best_ploidy[b];
+        for (uint32_t j = 0; j < p1; ++j)
+            for (uint32_t l = 0; l < p2; ++l) {
+                const double w = (double)hg->edge_w[hg->edge_off[b] + (uint64_t)j * p2 + l];
+                if (w >= MIN_SHARED_READS_UNAMBIG) { c1[j].out_edges.push_back({l, w}); c2[l].in_edges.push_back({j, w}); }
+            }
+    }
+    return cols;
+}
+}  // namespace
+
 std::vector<std::vector<HapNode>> generate_hap_graph(Session& s, const std::vector<Frag>& all_frags, const std::vector<GnPosition>& snp_to_genome_pos,
                                                      const std::string&, const Options& o) {
     if (s.frags() != &all_frags) s.load_contig(all_frags);
@@ -54,38 +90,125 @@ std::vector<std::vector<HapNode>> generate_hap_graph(Session& s, const std::vect
     floria_hap_graph* hg = nullptr;
     int rc = floria_hip_hap_graph(s.ctx(), res, &hg);                                                                       // :369 update_hap_graph
     if (rc) { floria_hip_block_result_free(res); check(rc); }
-    // process_chunks (:306-323): columns = blocks that returned Some, in block order; ids run over all nodes
-    std::vector<std::vector<HapNode>> cols;
-    std::vector<size_t> col_of_block(res->n_blocks, SIZE_MAX);
-    size_t id_counter = 0;
-    for (uint32_t b = 0; b < res->n_blocks; ++b) {
-        const uint32_t p = res->best_ploidy[b];
-        if (p == 0) continue;
-        std::vector<HapNode> col(p);
-        for (uint64_t i = res->read_off[b]; i < res->read_off[b + 1]; ++i) col[res->part[i]].frag_set.push_back(&all_frags[res->read_id[i]]);
-        for (uint32_t k = 0; k < p; ++k) {
-            col[k].row = k; col[k].column = cols.size(); col[k].id = id_counter++;
-            col[k].snp_endpoints = iter_vec[b];
-            col[k].cov = hg->node_cov[hg->node_off[b] + k];
-        }
-        col_of_block[b] = cols.size();
-        cols.push_back(std::move(col));
-    }
-    // update_hap_graph (:22-100): edges with weight >= MIN_SHARED_READS_UNAMBIG (:51), mirrored into in_edges (:87-96)
-    for (uint32_t b = 0; b < res->n_blocks; ++b) {
-        const int32_t pb = hg->pred[b];
-        if (pb < 0 || res->best_ploidy[b] == 0) continue;
-        auto& c1 = cols[col_of_block[pb]]; auto& c2 = cols[col_of_block[b]];
-        const uint32_t p1 = res->best_ploidy[pb], p2 = res->best_ploidy[b];
-        for (uint32_t j = 0; j < p1; ++j)
-            for (uint32_t l = 0; l < p2; ++l) {
-                const double w = (double)hg->edge_w[hg->edge_off[b] + (uint64_t)j * p2 + l];
-                if (w >= MIN_SHARED_READS_UNAMBIG) { c1[j].out_edges.push_back({l, w}); c2[l].in_edges.push_back({j, w}); }
-            }
-    }
+    auto cols = build_columns(res, hg, 0, res->n_blocks, all_frags, iter_vec);
     floria_hip_hap_graph_free(hg);
     floria_hip_block_result_free(res);
     return cols;
+}
+
+// ---- Batch: every device stage once for MANY contigs ----------------------------------------------------------------------------------
+Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
+    const size_t n = work.size();
+    uint64_t R = 0, C = 0;
+    for (const ContigWork& w : work) { R += w.all_frags.size(); for (const Frag& f : w.all_frags) C += f.seq_dict.size(); }
+    // CSR of all contigs in ONE pinned buffer, field by field, so that every field of a chunk of contigs is one DMA
+    const size_t bytes = 4 * (R + n) + 8 * R + 6 * C + 64;
+    pinned_ = floria_hip_host_alloc(bytes);
+    if (!pinned_) throw Error(FLORIA_E_NOMEM, floria_hip_last_error());
+    char* p = (char*)pinned_;
+    uint32_t* off = (uint32_t*)p; p += 4 * (R + n);
+    uint32_t* first = (uint32_t*)p; p += 4 * R;
+    uint32_t* last = (uint32_t*)p; p += 4 * R;
+    uint32_t* snp = (uint32_t*)p; p += 4 * C;
+    uint8_t* al = (uint8_t*)p; p += C;
+    uint8_t* q = (uint8_t*)p;
+    piles_.resize(n);
+    uint64_t ro = 0, rr = 0, cc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const std::vector<Frag>& fr = work[i].all_frags;
+        floria_pileup& pl = piles_[i];
+        pl.read_off = off + ro; pl.first = first + rr; pl.last = last + rr; pl.snp = snp + cc; pl.allele = al + cc; pl.qual = q + cc; pl.n_reads = (uint32_t)fr.size();
+        uint32_t local = 0;
+        off[ro] = 0;
+        for (size_t k = 0; k < fr.size(); ++k) {
+            if (fr[k].counter_id != k) throw Error(FLORIA_E_INVALID, "all_frags must be sorted with counter_id == index (floria.rs:289-293)");
+            for (const auto& kv : fr[k].seq_dict) { snp[cc + local] = kv.first; al[cc + local] = kv.second; q[cc + local] = fr[k].qual_dict.at(kv.first); ++local; }
+            off[ro + k + 1] = local; first[rr + k] = fr[k].first_position; last[rr + k] = fr[k].last_position;
+        }
+        ro += fr.size() + 1; rr += fr.size(); cc += local;
+    }
+    handles_.assign(n, nullptr);
+}
+Batch::~Batch() {
+    for (floria_hip_contig* h : handles_) if (h) floria_hip_contig_free(h);
+    if (pinned_) floria_hip_host_free(pinned_);
+}
+
+void Batch::generate_hap_graphs(const Options& o) {
+    std::vector<uint32_t> bc, bs, be, b0;
+    for (size_t i = 0; i < work_.size(); ++i) {
+        ContigWork& w = work_[i];
+        w.iter_vec = get_range_with_lengths(*w.snp_to_genome_pos, o.block_length, o.block_length / 3, o.snp_density);
+        b0.push_back((uint32_t)bs.size());
+        for (auto& r : w.iter_vec) { bc.push_back((uint32_t)i); bs.push_back(r.first); be.push_back(r.second); }
+    }
+    b0.push_back((uint32_t)bs.size());
+    floria_params prm{o.epsilon, (uint32_t)o.max_ploidy, (uint32_t)o.max_number_solns, o.ploidy_sensitivity, o.stopping_heuristic ? 1 : 0};
+    floria_block_result* res = nullptr;
+    check(floria_hip_phase_pileups_batch(s_.ctx(), piles_.data(), (uint32_t)piles_.size(), bc.data(), bs.data(), be.data(), (uint32_t)bs.size(), &prm, &res, handles_.data()));
+    floria_hap_graph* hg = nullptr;
+    int rc = floria_hip_hap_graph(s_.ctx(), res, &hg);
+    if (rc) { floria_hip_block_result_free(res); check(rc); }
+    for (size_t i = 0; i < work_.size(); ++i) work_[i].hap_graph = build_columns(res, hg, b0[i], b0[i + 1], work_[i].all_frags, work_[i].iter_vec);
+    floria_hip_hap_graph_free(hg);
+    floria_hip_block_result_free(res);
+}
+
+namespace {
+struct GroupCsr { std::vector<uint32_t> gc, reads, rng; std::vector<uint64_t> off{0}; };
+GroupCsr groups_of(const std::vector<ContigWork>& work, bool final_parts) {
+    GroupCsr g;
+    for (size_t i = 0; i < work.size(); ++i) {
+        const auto& parts = final_parts ? work[i].final_parts : work[i].path_parts;
+        const auto& ranges = final_parts ? work[i].final_ranges : work[i].path_ranges;
+        for (size_t k = 0; k < parts.size(); ++k) {
+            for (const Frag* f : parts[k]) g.reads.push_back((uint32_t)f->counter_id);
+            g.off.push_back(g.reads.size()); g.gc.push_back((uint32_t)i);
+            g.rng.push_back(ranges[k].first); g.rng.push_back(ranges[k].second);
+        }
+    }
+    return g;
+}
+}  // namespace
+
+void Batch::process_reads_for_final_parts(const Options& o) {
+    if (o.reassign_short) throw Error(FLORIA_E_UNSUPPORTED, "--reassign-short (hidden flag) is not supported");
+    const GroupCsr g = groups_of(work_, false);
+    floria_groups** out = nullptr;
+    check(floria_hip_reassign_batch(s_.ctx(), handles_.data(), (uint32_t)handles_.size(), g.gc.data(), g.off.data(), g.reads.data(), g.rng.data(), (uint32_t)g.gc.size(),
+                                    nullptr, nullptr, o.epsilon, &out));
+    for (size_t i = 0; i < work_.size(); ++i) {
+        ContigWork& w = work_[i];
+        const floria_groups* G = out[i];
+        w.final_parts.assign(G->n_groups, {}); w.final_ranges.assign(G->n_groups, {});
+        for (uint32_t k = 0; k < G->n_groups; ++k) {
+            for (uint64_t x = G->grp_off[k]; x < G->grp_off[k + 1]; ++x) w.final_parts[k].push_back(&w.all_frags[G->grp_read[x]]);
+            w.final_ranges[k] = {G->range[2 * k], G->range[2 * k + 1]};
+        }
+    }
+    floria_hip_groups_array_free(out, (uint32_t)handles_.size());
+}
+
+void Batch::stats_and_hapq(const Options& o) {
+    const GroupCsr g = groups_of(work_, true);
+    const uint32_t ng = (uint32_t)g.gc.size();
+    std::vector<double> st(4 * (size_t)ng + 4, 0.0), rel(ng + 1, 0.0), avg(work_.size() + 1, 0.0);
+    std::vector<uint8_t> hq(ng + 1, 0);
+    std::vector<std::vector<uint64_t>> pos(work_.size());
+    std::vector<const uint64_t*> pp(work_.size());
+    std::vector<uint32_t> ns(work_.size());
+    for (size_t i = 0; i < work_.size(); ++i) { pos[i].assign(work_[i].snp_to_genome_pos->begin(), work_[i].snp_to_genome_pos->end()); pp[i] = pos[i].data(); ns[i] = (uint32_t)pos[i].size(); }
+    if (ng) check(floria_hip_haploset_stats(s_.ctx(), handles_.data(), (uint32_t)handles_.size(), g.gc.data(), g.off.data(), g.reads.data(), g.rng.data(), ng, st.data()));
+    check(floria_hip_hapq_batch(s_.ctx(), handles_.data(), (uint32_t)handles_.size(), g.gc.data(), g.off.data(), g.reads.data(), g.rng.data(), ng, pp.data(), ns.data(),
+                                (uint64_t)o.block_length, hq.data(), rel.data(), avg.data()));
+    size_t k = 0;
+    for (size_t i = 0; i < work_.size(); ++i) {
+        ContigWork& w = work_[i];
+        const size_t m = w.final_parts.size();
+        w.stats.assign(st.begin() + 4 * k, st.begin() + 4 * (k + m));
+        w.hq.hapqs.assign(hq.begin() + k, hq.begin() + k + m); w.hq.rel_err.assign(rel.begin() + k, rel.begin() + k + m); w.hq.avg_err = avg[i];
+        k += m;
+    }
 }
 
 std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPosition, SnpPosition>>> process_reads_for_final_parts(

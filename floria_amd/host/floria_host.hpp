@@ -159,8 +159,9 @@ struct BamFile {
     std::vector<std::string> target_names;
     std::vector<uint64_t> target_len;
     std::vector<BamRecord> records;    // file order
+    std::vector<std::vector<uint32_t>> by_tid;     // record indices per target, file order (what an indexed fetch() of the contig yields)
 };
-BamFile read_bam(const std::string& path);                                             // BGZF + BAM, whole file (no index needed)
+BamFile read_bam(const std::string& path, size_t threads = 1);                         // BGZF + BAM, whole file (no index needed); members and records decode in parallel
 std::vector<std::string> get_contigs_to_phase(const BamFile& bam);                     // file_reader.rs:738-746
 VcfProfile get_vcf_profile(const std::string& vcf_file, const std::vector<std::string>& ref_chroms);       // :239-314 (+ :113-175); text VCF, optionally gzipped
 std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file);      // :462-489 (whole sequences)
@@ -171,7 +172,51 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
 std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam);                   // :749-826
 
 // part_block_manip.rs:517-616: (hapqs, rel_err per haploset, avg_err) — the HAPQ / REL_ERR header fields and the contig table's avg_err.
-struct HapqResult { std::vector<uint8_t> hapqs; std::vector<double> rel_err; double avg_err; };
+struct HapqResult { std::vector<uint8_t> hapqs; std::vector<double> rel_err; double avg_err = 0.0; };
+
+// ---- many contigs at once ---------------------------------------------------------------------------------------------------------------
+// The reference walks its contigs serially (floria.rs:229) because its parallelism is inside a contig (rayon over blocks).  On the
+// GPU the throughput comes from thousands of blocks in flight, and a metagenome has thousands of small contigs: a host takes a batch
+// of contigs through every stage together — one pipelined upload + S1 call, one hap-graph call, the LP / path peeling per contig
+// on host threads, one S2 call, one COV/ERR and one HAPQ call — and writes the files contig by contig.  Results per contig are
+// exactly those of the per-contig functions above.
+struct ContigWork {
+    std::string name, out_dir;
+    std::vector<Frag> all_frags, frags_without_snps;                   // all_frags sorted, counter_id == index (floria.rs:289-293)
+    const std::vector<GnPosition>* snp_to_genome_pos = nullptr;
+    size_t contig_len = 0;
+    // filled stage by stage
+    std::vector<std::pair<SnpPosition, SnpPosition>> iter_vec;         // get_range_with_lengths
+    std::vector<std::vector<HapNode>> hap_graph;                       // generate_hap_graph
+    FlowUpVec flows;                                                   // solve_lp_graph
+    std::vector<std::vector<const Frag*>> path_parts, final_parts;     // get_disjoint_paths_rewrite / process_reads_for_final_parts
+    std::vector<std::pair<SnpPosition, SnpPosition>> path_ranges, final_ranges;
+    std::vector<const Frag*> snpless;                                  // get_frags_in_snpless_gaps
+    std::vector<double> stats;                                         // 4 per final haploset: cov, err, total_err, total_cov
+    HapqResult hq;
+};
+class Batch {
+public:
+    Batch(Session& s, std::vector<ContigWork>& work);                  // marshals the Frags into pinned CSR buffers
+    ~Batch();
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
+    void generate_hap_graphs(const Options& options);                  // upload + S1 + hap graph for every contig (graph_processing.rs:325-372)
+    void process_reads_for_final_parts(const Options& options);        // S2 for every contig, from path_parts / path_ranges
+    void stats_and_hapq(const Options& options);                       // get_errors_cov_from_frags + get_hapq for every final haploset
+private:
+    Session& s_;
+    std::vector<ContigWork>& work_;
+    void* pinned_ = nullptr;
+    std::vector<floria_pileup> piles_;
+    std::vector<floria_hip_contig*> handles_;
+};
+// write_outputs for a contig whose statistics were computed by Batch::stats_and_hapq
+void write_outputs(const ContigWork& w, const Options& options);
+// the same in two halves, for hosts that write the contigs of a batch from several threads: the files of the contig (returns its
+// contig_ploidy_info.tsv row), and the append of the rows in contig order
+std::string write_contig_files(const ContigWork& w, const Options& options);
+void append_contig_ploidy_row(const Options& options, const std::string& row);
 HapqResult get_hapq(Session& s, const std::vector<std::vector<const Frag*>>& parts, const std::vector<GnPosition>& snp_to_genome_pos,
                     const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec, const Options& options);
 

@@ -23,11 +23,15 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 namespace floria {
@@ -35,14 +39,84 @@ namespace floria {
 namespace {
 
 std::vector<unsigned char> slurp(const std::string& path) {
-    std::ifstream f(path, std::ios::binary);
+    FILE* f = fopen(path.c_str(), "rb");
     if (!f) throw Error(FLORIA_E_INVALID, "cannot open " + path);
-    return std::vector<unsigned char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<unsigned char> buf;
+    if (fseek(f, 0, SEEK_END) == 0) { const long n = ftell(f); if (n > 0) buf.reserve((size_t)n); }
+    rewind(f);
+    unsigned char chunk[1 << 16];
+    for (size_t k; (k = fread(chunk, 1, sizeof chunk, f)) > 0;) buf.insert(buf.end(), chunk, chunk + k);
+    fclose(f);
+    return buf;
+}
+
+// one task per index on up to `threads` threads (first exception rethrown on the caller)
+template <class F> void parallel_tasks(size_t n, size_t threads, F&& f) {
+    threads = std::min(threads, n);
+    if (threads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) return;
+                try { f(i); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); next = n; return; }
+            }
+        });
+    for (std::thread& t : pool) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// BGZF members carry their compressed size (extra subfield 'B','C') and end with ISIZE, so their places in the output are known
+// before any is inflated: -> false if `in` is not made of BGZF members only (plain gzip: the serial path takes it)
+struct BgzfBlock { size_t in_off, in_len, out_off, out_len; };
+bool bgzf_index(const std::vector<unsigned char>& in, std::vector<BgzfBlock>& blocks) {
+    size_t o = 0, out = 0;
+    while (o < in.size()) {
+        if (o + 18 > in.size() || in[o] != 0x1f || in[o + 1] != 0x8b || in[o + 2] != 8 || !(in[o + 3] & 4)) return false;
+        const size_t xlen = in[o + 10] | (in[o + 11] << 8);
+        if (o + 12 + xlen > in.size()) return false;
+        size_t x = o + 12, bsize = 0;
+        while (x + 4 <= o + 12 + xlen) {
+            const size_t slen = in[x + 2] | (in[x + 3] << 8);
+            if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= o + 12 + xlen) bsize = (size_t)(in[x + 4] | (in[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || o + bsize > in.size()) return false;
+        uint32_t isize; memcpy(&isize, &in[o + bsize - 4], 4);
+        blocks.push_back({o, bsize, out, isize});
+        o += bsize; out += isize;
+    }
+    return true;
 }
 
 // BGZF = concatenated gzip members; inflate them all
-std::vector<unsigned char> bgzf_inflate_all(const std::vector<unsigned char>& in, const std::string& what) {
+std::vector<unsigned char> bgzf_inflate_all(const std::vector<unsigned char>& in, const std::string& what, size_t threads) {
     std::vector<unsigned char> out;
+    std::vector<BgzfBlock> blocks;
+    if (threads > 1 && bgzf_index(in, blocks)) {
+        out.resize(blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_len);
+        const size_t per = 64;                                                     // members per task
+        parallel_tasks((blocks.size() + per - 1) / per, threads, [&](size_t t) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) throw Error(FLORIA_E_NOMEM, "inflateInit2 failed");
+            for (size_t b = t * per; b < std::min(blocks.size(), (t + 1) * per); ++b) {
+                const BgzfBlock& k = blocks[b];
+                zs.next_in = const_cast<unsigned char*>(in.data()) + k.in_off; zs.avail_in = (uInt)k.in_len;
+                unsigned char dummy;
+                zs.next_out = k.out_len ? out.data() + k.out_off : &dummy; zs.avail_out = (uInt)k.out_len;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw Error(FLORIA_E_INVALID, what + " is not a valid BGZF/gzip file"); }
+                inflateReset(&zs);
+            }
+            inflateEnd(&zs);
+        });
+        return out;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) throw Error(FLORIA_E_NOMEM, "inflateInit2 failed");
@@ -199,6 +273,22 @@ void realign(const std::string& ref_gn, Frag& frag, const std::string& read_seq,
             r[i] = (unsigned char)ref_gn[snp_gn_pos - flank + i];
         }
         const auto& alleles = gn_pos_to_allele.at(snp_gn_pos);
+        // Exact shortcut.  Both windows have 2 * flank = 32 bytes, so an alignment with gaps has g >= 1 gap columns on EACH side and
+        // scores at most (32 - g) + 2 * (OPEN + (g - 1) * EXTEND) = 30 - 3g <= 27.  With h mismatches outside the SNP column the
+        // ungapped alignment scores 32 - 2h for an allele equal to the read's base and 30 - 2h for any other.  So for h <= 2 the
+        // first allele equal to the read's base wins strictly (28 > 27); with no such allele and h <= 1 every allele scores
+        // 30 - 2h >= 28 and the first one is kept (`score > best_score`).  Everything else takes the DP.
+        {
+            const auto up = [](unsigned char c) { return (unsigned char)(c >= 'a' && c <= 'z' ? c - 32 : c); };
+            int h = 0;
+            for (size_t i = 0; i < 2 * flank && h <= 2; ++i) h += (i != flank && q[i] != up(r[i]));
+            if (h <= 2) {
+                size_t a = 0;
+                while (a < alleles.size() && up(alleles[a]) != q[flank]) ++a;
+                if (a < alleles.size()) { kv.second = (Genotype)a; continue; }
+                if (h <= 1) { kv.second = 0; continue; }
+            }
+        }
         int best_score = INT32_MIN;
         Genotype best_geno = 0;
         for (size_t a = 0; a < alleles.size(); ++a) {
@@ -212,8 +302,16 @@ void realign(const std::string& ref_gn, Frag& frag, const std::string& read_seq,
 
 }  // namespace
 
-BamFile read_bam(const std::string& path) {
-    const std::vector<unsigned char> raw = bgzf_inflate_all(slurp(path), path);
+BamFile read_bam(const std::string& path, size_t threads) {
+    const bool trace = getenv("FLORIA_HOST_TRACE") != nullptr;
+    const auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    const std::vector<unsigned char> packed = slurp(path);
+    if (trace) fprintf(stderr, "[read_bam] file %.3fs (%zu MiB)\n", now() - t0, packed.size() >> 20);
+    t0 = now();
+    const std::vector<unsigned char> raw = bgzf_inflate_all(packed, path, threads);
+    if (trace) fprintf(stderr, "[read_bam] inflate %.3fs (%zu MiB)\n", now() - t0, raw.size() >> 20);
+    t0 = now();
     Cursor c{raw.data(), raw.size(), 0, path};
     c.need(4);
     if (memcmp(raw.data(), "BAM\1", 4) != 0) throw Error(FLORIA_E_INVALID, path + " is not a BAM file");
@@ -226,27 +324,42 @@ BamFile read_bam(const std::string& path) {
         bam.target_names.emplace_back((const char*)raw.data() + c.o, l_name ? l_name - 1 : 0); c.o += l_name;
         bam.target_len.push_back(c.u32());
     }
-    static const char* SEQ16 = "=ACMGRSVTWYHKDBN";
+    bam.by_tid.resize(bam.target_names.size());
+    // record boundaries first (a walk over the block_size fields), then the records are decoded independently
+    std::vector<size_t> rec_off;
     while (c.o < raw.size()) {
         const uint32_t block_size = c.u32(); c.need(block_size);
-        const size_t end = c.o + block_size;
-        BamRecord r;
-        r.tid = c.i32(); r.pos = c.i32();
-        const uint8_t l_read_name = c.u8(); r.mapq = c.u8(); (void)c.u16();
-        const uint16_t n_cigar = c.u16(); r.flags = c.u16();
-        const uint32_t l_seq = c.u32(); (void)c.i32(); (void)c.i32(); (void)c.i32();
-        c.need(l_read_name); r.qname.assign((const char*)raw.data() + c.o, l_read_name ? l_read_name - 1 : 0); c.o += l_read_name;
-        r.cigar.resize(n_cigar);
-        for (uint16_t k = 0; k < n_cigar; ++k) r.cigar[k] = c.u32();
-        c.need((l_seq + 1) / 2 + l_seq);
-        r.seq.resize(l_seq);
-        for (uint32_t k = 0; k < l_seq; ++k) { const unsigned char b = raw[c.o + k / 2]; r.seq[k] = SEQ16[(k & 1) ? (b & 15) : (b >> 4)]; }
-        c.o += (l_seq + 1) / 2;
-        r.qual.assign(raw.data() + c.o, raw.data() + c.o + l_seq);
-        if (end < c.o + l_seq) throw Error(FLORIA_E_INVALID, path + ": malformed alignment record");
-        c.o = end;                                                             // (auxiliary tags are not needed)
-        bam.records.push_back(std::move(r));
+        rec_off.push_back(c.o);
+        c.o += block_size;
     }
+    rec_off.push_back(raw.size() + 4);
+    bam.records.resize(rec_off.size() - 1);
+    const size_t per = 256;
+    parallel_tasks((bam.records.size() + per - 1) / per, threads, [&](size_t t) {
+        static const char* SEQ16 = "=ACMGRSVTWYHKDBN";
+        for (size_t i = t * per; i < std::min(bam.records.size(), (t + 1) * per); ++i) {
+            Cursor d{raw.data(), rec_off[i + 1] - 4, rec_off[i], path};             // (bounded by the record's own end)
+            BamRecord& r = bam.records[i];
+            r.tid = d.i32(); r.pos = d.i32();
+            const uint8_t l_read_name = d.u8(); r.mapq = d.u8(); (void)d.u16();
+            const uint16_t n_cigar = d.u16(); r.flags = d.u16();
+            const uint32_t l_seq = d.u32(); (void)d.i32(); (void)d.i32(); (void)d.i32();
+            d.need(l_read_name); r.qname.assign((const char*)raw.data() + d.o, l_read_name ? l_read_name - 1 : 0); d.o += l_read_name;
+            r.cigar.resize(n_cigar);
+            for (uint16_t k = 0; k < n_cigar; ++k) r.cigar[k] = d.u32();
+            d.need((size_t)(l_seq + 1) / 2 + l_seq);
+            r.seq.resize(l_seq);
+            for (uint32_t k = 0; k + 1 < l_seq; k += 2) { const unsigned char b = raw[d.o + k / 2]; r.seq[k] = SEQ16[b >> 4]; r.seq[k + 1] = SEQ16[b & 15]; }
+            if (l_seq & 1) r.seq[l_seq - 1] = SEQ16[raw[d.o + l_seq / 2] >> 4];
+            d.o += (l_seq + 1) / 2;
+            r.qual.assign(raw.data() + d.o, raw.data() + d.o + l_seq);              // (auxiliary tags are not needed)
+        }
+    });
+    for (size_t i = 0; i < bam.records.size(); ++i) {
+        const int32_t tid = bam.records[i].tid;
+        if (tid >= 0 && (size_t)tid < bam.by_tid.size()) bam.by_tid[tid].push_back((uint32_t)i);
+    }
+    if (trace) fprintf(stderr, "[read_bam] records %.3fs\n", now() - t0);
     return bam;
 }
 
@@ -335,8 +448,8 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
     std::unordered_map<std::string, size_t> name_ix;
     std::vector<std::vector<Tagged>> buckets;
     size_t count = 0;
-    for (const BamRecord& rec : bam.records) {
-        if (rec.tid != tid) continue;
+    for (const uint32_t rec_ix : bam.by_tid[tid]) {                           // the contig's records in file order, as fetch() yields them
+        const BamRecord& rec = bam.records[rec_ix];
         const size_t this_count = count++;
         if (!alignment_passed_check(rec.flags, rec.mapq, use_supplementary, filter_supplementary, o.mapq_cutoff).first) continue;
         auto ins = name_ix.emplace(rec.qname, names.size());

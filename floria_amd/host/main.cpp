@@ -1,23 +1,30 @@
 // floria-hip — command-line driver with the reference's flags (floria.rs:21-196, parse_cmd_line.rs:11-196) and its per-contig
 // flow (floria.rs:229-388): ingest -> generate_hap_graph (device) -> solve_lp_graph -> get_disjoint_paths_rewrite ->
-// process_reads_for_final_parts (device) -> get_frags_in_snpless_gaps -> write_outputs.
+// process_reads_for_final_parts (device) -> get_frags_in_snpless_gaps -> write_outputs.  The contigs take that flow in BATCHES:
+// the host stages of a batch run one contig per task on -t threads, every device stage runs once per batch (a metagenome is
+// thousands of small contigs; one device call per contig and stage would be launch-latency-bound).  Files are those of the
+// per-contig flow, byte for byte.
 //
 //   floria-hip -b reads.bam -v calls.vcf -r reference.fa -o results [-e 0.04] [-l 10000] [-n 10] [-p 5] [-d 0.0005] [-s 2] [-m 15]
 //              [-t 10] [-G contig ...] [-X] [--no-stop-heuristic] [--snp-count-filter 100] [--supp-aln-dist-cutoff 40000] [--overwrite]
 //
 // Flags of the reference that are not supported and say so: -H/--hybrid, --reassign-short, --bin-by-cov, --output-reads,
 // --gzip-reads, --extra-trimming, --ignore-monomorphic, -q (accepted and ignored by the reference too).  Extras: --device N,
-// --debug (debug_graph.txt per contig), and for tests --dump-frags FILE, --ingest-only, --no-realign, --stitch-graph FILE.
+// --batch-contigs N / --batch-cells N (size of a device batch), --debug (debug_graph.txt per contig), and for tests --dump-frags FILE,
+// --ingest-only, --no-realign, --stitch-graph FILE.
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "floria_host.hpp"
 
@@ -34,10 +41,52 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 }  // namespace
 
+// one task per index on up to `threads` std::threads; the first exception is rethrown on the caller
+template <class F> static void parallel_for(size_t n, size_t threads, F&& f) {
+    threads = std::min(threads, n);
+    if (threads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) return;
+                try { f(i); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); next = n; return; }
+            }
+        });
+    for (std::thread& t : pool) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// hap graph, flows and paths of a contig in the N / E / F / P line format (--debug; tests/test_gpu_cli.py reads it back)
+static void write_debug_graph(const ContigWork& w) {
+    struct stat st;
+    if (stat(w.out_dir.c_str(), &st) != 0) mkdir(w.out_dir.c_str(), 0777);
+    std::ofstream g(w.out_dir + "/debug_graph.txt", std::ios::trunc);
+    g.precision(17);
+    for (const auto& col : w.hap_graph) for (const HapNode& n : col) {
+        g << "N\t" << n.column << "\t" << n.row << "\t" << n.id << "\t" << n.cov << "\t" << n.snp_endpoints.first << "\t" << n.snp_endpoints.second;
+        for (const Frag* f : n.frag_set) g << "\t" << f->counter_id;
+        g << "\n";
+    }
+    for (const auto& col : w.hap_graph) for (const HapNode& n : col) for (const auto& e : n.out_edges) g << "E\t" << n.column << "\t" << n.row << "\t" << e.first << "\t" << e.second << "\n";
+    for (const FlowUpdate& f : w.flows) g << "F\t" << f.n1.first << "\t" << f.n1.second << "\t" << f.n2.second << "\t" << f.flow << "\n";
+    for (size_t k = 0; k < w.path_parts.size(); ++k) {
+        g << "P\t" << w.path_ranges[k].first << "\t" << w.path_ranges[k].second;
+        for (const Frag* f : w.path_parts[k]) g << "\t" << f->counter_id;
+        g << "\n";
+    }
+}
+
 int main(int argc, char** argv) {
     Options o;
     bool have_e = false, have_l = false;
     std::string dump_frags;
+    size_t batch_contigs = 4096;         // --batch-contigs
+    uint64_t batch_cells = 256ull << 20; // --batch-cells (1.5 GB of pinned staging)
     bool ingest_only = false, no_realign = false;
     std::string stitch_graph;
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
@@ -66,6 +115,8 @@ int main(int argc, char** argv) {
             else if (a == "-q") {}
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
+            else if (a == "--batch-contigs") batch_contigs = std::max<size_t>(1, std::stoul(val()));       // contigs per device batch
+            else if (a == "--batch-cells") batch_cells = std::max<uint64_t>(1, std::stoull(val()));        // SNP calls per device batch
             else if (a == "--dump-frags") dump_frags = val();
             else if (a == "--no-realign") no_realign = true;                   // (tests) keep the alleles as called
             else if (a == "--ingest-only") ingest_only = true;          // (tests) stop after ingest: needs no GPU
@@ -123,7 +174,9 @@ int main(int argc, char** argv) {
 
         const double t_all = now_s();
         fprintf(stderr, "Preprocessing VCF/Reference\n");
-        const BamFile bam = read_bam(o.bam_file);
+        double tp = now_s();
+        const BamFile bam = read_bam(o.bam_file, std::max<size_t>(1, o.num_threads));
+        const double t_bam = now_s() - tp;
         if (!have_e || !have_l) {                                                     // parse_cmd_line.rs:72-90
             const auto est = l_epsilon_auto_detect(bam);
             if (!have_l) o.block_length = est.first;
@@ -132,14 +185,20 @@ int main(int argc, char** argv) {
         }
         if (!ingest_only) write_run_files(o, argc, argv);
         const std::vector<std::string> contigs = get_contigs_to_phase(bam);
+        tp = now_s();
         const VcfProfile vp = get_vcf_profile(o.vcf_file, contigs);
         const std::map<std::string, std::string> fasta = get_fasta_seqs(o.reference_fasta);
+        const double t_vcf = now_s() - tp;
+        tp = now_s();
         std::unique_ptr<Session> session_holder;
         if (!ingest_only) session_holder.reset(new Session(o.device));                // throws without a usable MI355X: no CPU fallback
+        fprintf(stderr, "Preprocessing: BAM %.3fs (%zu records), VCF + FASTA %.3fs, device %.3fs\n", t_bam, bam.records.size(), t_vcf, now_s() - tp);
 
         std::ofstream dump;
         if (!dump_frags.empty()) dump.open(dump_frags, std::ios::trunc);
+        // ---- which contigs (floria.rs:229-262) -------------------------------------------------------------------------------------
         bool warn_first_length = true;
+        std::vector<std::string> todo;
         for (const std::string& contig : contigs) {
             if (!o.list_to_phase.empty() && std::find(o.list_to_phase.begin(), o.list_to_phase.end(), contig) == o.list_to_phase.end()) continue;
             const auto pam = vp.vcf_pos_allele_map.find(contig);
@@ -150,62 +209,93 @@ int main(int argc, char** argv) {
                 warn_first_length = false;
                 continue;
             }
-            const double t0 = now_s();
-            const auto fa0 = fasta.find(contig);
-            auto fr = get_frags_from_bamvcf_rewrite(bam, vp, o, contig, (fa0 != fasta.end() && !no_realign) ? &fa0->second : nullptr);
-            std::vector<Frag>& all_frags = fr.first;
-            const std::vector<Frag>& frags_without_snps = fr.second;
-            fprintf(stderr, "Number of reads passing filtering: %zu\n", all_frags.size());
-            if (all_frags.empty()) continue;
-            const auto sgp = vp.snp_to_genome_pos.find(contig);
-            if (sgp == vp.snp_to_genome_pos.end()) continue;
-            const std::string contig_out_dir = o.out_dir + "/" + contig;
-            const std::vector<GnPosition>& snp_to_genome_pos = sgp->second;
-            std::sort(all_frags.begin(), all_frags.end());                             // floria.rs:289-293
-            for (size_t i = 0; i < all_frags.size(); ++i) all_frags[i].counter_id = i;
-            if (dump.is_open()) {
-                dump << "#CONTIG\t" << contig << "\t" << all_frags.size() << "\t" << frags_without_snps.size() << "\n";
-                for (const Frag& f : all_frags) {
-                    dump << f.id << "\t" << f.first_position << "\t" << f.last_position << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.is_paired ? 1 : 0);
-                    for (const auto& kv : f.seq_dict) dump << "\t" << kv.first << ":" << (int)kv.second << ":" << (int)f.qual_dict.at(kv.first);
-                    dump << "\n";
-                }
-                for (const Frag& f : frags_without_snps) dump << "#SNPLESS\t" << f.id << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.seq_len[0] + f.seq_len[1]) << "\n";
-            }
-            fprintf(stderr, "Reading inputs time taken %.3fs\n", now_s() - t0);
-            if (ingest_only) continue;
-            Session& session = *session_holder;
-            const double t1 = now_s();
-            session.load_contig(all_frags);                                            // (explicit: the vector's address repeats from contig to contig)
-            std::vector<std::vector<HapNode>> hap_graph = generate_hap_graph(session, all_frags, snp_to_genome_pos, contig_out_dir, o);
-            fprintf(stderr, "Phasing time taken %.3fs\n", now_s() - t1);
-            const FlowUpVec flow_up_vec = solve_lp_graph(hap_graph);
-            auto paths = get_disjoint_paths_rewrite(hap_graph, flow_up_vec, o);
-            if (debug) {
-                struct stat st;
-                if (stat(contig_out_dir.c_str(), &st) != 0) mkdir(contig_out_dir.c_str(), 0777);
-                std::ofstream g(contig_out_dir + "/debug_graph.txt", std::ios::trunc);
-                g.precision(17);
-                for (const auto& col : hap_graph) for (const HapNode& n : col) {
-                    g << "N\t" << n.column << "\t" << n.row << "\t" << n.id << "\t" << n.cov << "\t" << n.snp_endpoints.first << "\t" << n.snp_endpoints.second;
-                    for (const Frag* f : n.frag_set) g << "\t" << f->counter_id;
-                    g << "\n";
-                }
-                for (const auto& col : hap_graph) for (const HapNode& n : col) for (const auto& e : n.out_edges) g << "E\t" << n.column << "\t" << n.row << "\t" << e.first << "\t" << e.second << "\n";
-                for (const FlowUpdate& f : flow_up_vec) g << "F\t" << f.n1.first << "\t" << f.n1.second << "\t" << f.n2.second << "\t" << f.flow << "\n";
-                for (size_t k = 0; k < paths.first.size(); ++k) {
-                    g << "P\t" << paths.second[k].first << "\t" << paths.second[k].second;
-                    for (const Frag* f : paths.first[k]) g << "\t" << f->counter_id;
-                    g << "\n";
-                }
-            }
-            const std::vector<Frag> short_frags;
-            auto fin = process_reads_for_final_parts(session, paths.first, short_frags, paths.second, o, snp_to_genome_pos);
-            const std::vector<const Frag*> snpless = get_frags_in_snpless_gaps(fin.second, snp_to_genome_pos, frags_without_snps, o.block_length, all_frags);
-            const auto fa = fasta.find(contig);
-            if (fa == fasta.end()) throw Error(FLORIA_E_INVALID, "contig " + contig + " is not in the reference fasta");
-            write_outputs(session, fin.first, fin.second, contig_out_dir, contig, contig, snp_to_genome_pos, o, snpless, fa->second.size());
+            todo.push_back(contig);
         }
+        const size_t n_threads = std::max<size_t>(1, o.num_threads);
+        // The contigs go through the stages in batches (floria_host.hpp, "many contigs at once"): the host stages of a batch run on -t
+        // threads, one contig per task; the device stages once per batch.  A batch is closed at batch_contigs contigs or batch_cells
+        // SNP calls, whichever comes first (the pinned staging buffer holds 6 bytes per call).
+        double t_ingest = 0., t_s1 = 0., t_stitch = 0., t_s2 = 0., t_stats = 0., t_write = 0.;
+        size_t done = 0, n_batches = 0;
+        while (done < todo.size()) {
+            // ---- ingest (floria.rs:264-293), one contig per task ----------------------------------------------------------------------
+            double t0 = now_s();
+            std::vector<ContigWork> work;
+            uint64_t cells = 0;
+            while (done < todo.size() && work.size() < batch_contigs && cells < batch_cells) {
+                const size_t take = std::min({todo.size() - done, batch_contigs - work.size(), std::max<size_t>(n_threads * 2, 2)});
+                std::vector<ContigWork> got(take);
+                parallel_for(take, n_threads, [&](size_t i) {
+                    const std::string& contig = todo[done + i];
+                    ContigWork& w = got[i];
+                    w.name = contig; w.out_dir = o.out_dir + "/" + contig;
+                    const auto fa = fasta.find(contig);
+                    auto fr = get_frags_from_bamvcf_rewrite(bam, vp, o, contig, (fa != fasta.end() && !no_realign) ? &fa->second : nullptr);
+                    w.all_frags = std::move(fr.first); w.frags_without_snps = std::move(fr.second);
+                    const auto sgp = vp.snp_to_genome_pos.find(contig);
+                    w.snp_to_genome_pos = sgp == vp.snp_to_genome_pos.end() ? nullptr : &sgp->second;
+                    w.contig_len = fa == fasta.end() ? 0 : fa->second.size();
+                    std::sort(w.all_frags.begin(), w.all_frags.end());                     // floria.rs:289-293
+                    for (size_t k = 0; k < w.all_frags.size(); ++k) w.all_frags[k].counter_id = k;
+                });
+                done += take;
+                for (ContigWork& w : got) {
+                    fprintf(stderr, "Number of reads passing filtering: %zu (%s)\n", w.all_frags.size(), w.name.c_str());
+                    if (w.all_frags.empty() || !w.snp_to_genome_pos) continue;
+                    if (!ingest_only && w.contig_len == 0) throw Error(FLORIA_E_INVALID, "contig " + w.name + " is not in the reference fasta");
+                    for (const Frag& f : w.all_frags) cells += f.seq_dict.size();
+                    work.push_back(std::move(w));
+                }
+            }
+            if (dump.is_open())
+                for (const ContigWork& w : work) {
+                    dump << "#CONTIG\t" << w.name << "\t" << w.all_frags.size() << "\t" << w.frags_without_snps.size() << "\n";
+                    for (const Frag& f : w.all_frags) {
+                        dump << f.id << "\t" << f.first_position << "\t" << f.last_position << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.is_paired ? 1 : 0);
+                        for (const auto& kv : f.seq_dict) dump << "\t" << kv.first << ":" << (int)kv.second << ":" << (int)f.qual_dict.at(kv.first);
+                        dump << "\n";
+                    }
+                    for (const Frag& f : w.frags_without_snps) dump << "#SNPLESS\t" << f.id << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.seq_len[0] + f.seq_len[1]) << "\n";
+                }
+            t_ingest += now_s() - t0;
+            if (ingest_only || work.empty()) continue;
+            ++n_batches;
+            Session& session = *session_holder;
+            // ---- S1 + hap graph, every contig of the batch in one pipelined device call ----------------------------------------------
+            t0 = now_s();
+            Batch batch(session, work);
+            batch.generate_hap_graphs(o);
+            t_s1 += now_s() - t0;
+            // ---- LP + path peeling (host), one contig per task -------------------------------------------------------------------------
+            t0 = now_s();
+            parallel_for(work.size(), n_threads, [&](size_t i) {
+                ContigWork& w = work[i];
+                w.flows = solve_lp_graph(w.hap_graph);
+                auto paths = get_disjoint_paths_rewrite(w.hap_graph, w.flows, o);
+                w.path_parts = std::move(paths.first); w.path_ranges = std::move(paths.second);
+                if (debug) write_debug_graph(w);
+            });
+            t_stitch += now_s() - t0;
+            // ---- S2, then COV / ERR / HAPQ of the final haplosets -------------------------------------------------------------------
+            t0 = now_s();
+            batch.process_reads_for_final_parts(o);
+            t_s2 += now_s() - t0;
+            t0 = now_s();
+            batch.stats_and_hapq(o);
+            t_stats += now_s() - t0;
+            // ---- writers, one contig per task; the contig table in contig order ----------------------------------------------------
+            t0 = now_s();
+            std::vector<std::string> rows(work.size());
+            parallel_for(work.size(), n_threads, [&](size_t i) {
+                ContigWork& w = work[i];
+                w.snpless = get_frags_in_snpless_gaps(w.final_ranges, *w.snp_to_genome_pos, w.frags_without_snps, o.block_length, w.all_frags);
+                rows[i] = write_contig_files(w, o);
+            });
+            for (const std::string& r : rows) append_contig_ploidy_row(o, r);
+            t_write += now_s() - t0;
+        }
+        fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
+                t_stitch, t_s2, t_stats, t_write);
         fprintf(stderr, "Total time taken is %.3fs\n", now_s() - t_all);
     } catch (const Error& e) {
         fprintf(stderr, "floria-hip: error: %s\n", e.what());

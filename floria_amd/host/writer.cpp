@@ -68,25 +68,14 @@ void write_run_files(const Options& o, int argc, char** argv) {
           "average_straincount_min15hapq\taverage_straincount_min30hapq\taverage_straincount_min45hapq\tavg_err\n";
 }
 
-void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& ranges,
-                   const std::string& dir, const std::string& prefix, const std::string& contig, const std::vector<GnPosition>& snp_to_gn,
-                   const Options& o, const std::vector<const Frag*>& snpless_frags, size_t contig_len) {
+namespace {
+// the files of one contig; returns its contig_ploidy_info.tsv row (appended by the caller, so that rows keep the contig order when the
+// contigs of a batch are written by several threads)
+std::string write_contig_files(const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& ranges,
+                               const std::string& dir, const std::string& prefix, const std::string& contig, const std::vector<GnPosition>& snp_to_gn,
+                               const std::vector<const Frag*>& snpless_frags, size_t contig_len, const HapqResult& hq, const std::vector<double>& st) {
     mkdir_p(dir);
     const size_t n = part.size();
-    // ---- device: get_hapq (:40-41) and get_errors_cov_from_frags per haploset ---------------------------------------------------
-    const HapqResult hq = get_hapq(s, part, snp_to_gn, ranges, o);
-    std::vector<double> st(4 * n + 4, 0.0);
-    {
-        std::vector<uint64_t> off{0};
-        std::vector<uint32_t> reads, rng;
-        for (size_t g = 0; g < n; ++g) {
-            for (const Frag* f : part[g]) reads.push_back((uint32_t)f->counter_id);
-            off.push_back(reads.size());
-            rng.push_back(ranges[g].first); rng.push_back(ranges[g].second);
-        }
-        const floria_hip_contig* one[1] = {s.contig()};
-        if (n) check(floria_hip_haploset_stats(s.ctx(), one, 1, nullptr, off.data(), reads.data(), rng.data(), (uint32_t)n, st.data()));
-    }
     // ---- write_haplotypes (:699-917) -----------------------------------------------------------------------------------------------
     const size_t S = snp_to_gn.size();
     std::vector<double> cnt_all(S, 0.), cov_all(S, 0.), cnt15(S, 0.), cnt30(S, 0.), cnt45(S, 0.);
@@ -141,14 +130,15 @@ void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part
     }
     fclose(vt); fclose(vi); fclose(hs);
     // contig_ploidy_info.tsv (:883-914)
+    std::string row;
     {
         size_t num_nonzero = 0;
         double sum_all = 0., sum15 = 0., sum30 = 0., sum45 = 0., sum_cov = 0.;
         for (size_t p = 0; p < S; ++p) { if (cnt_all[p] > 0.) ++num_nonzero; sum_all += cnt_all[p]; sum15 += cnt15[p]; sum30 += cnt30[p]; sum45 += cnt45[p]; sum_cov += cov_all[p]; }
         const double rough_cvg = sum_cov / (double)num_nonzero;
-        std::ofstream pl(o.out_dir + "/contig_ploidy_info.tsv", std::ios::app);
-        pl << contig << "\t" << fmt_f64(sum_all / (double)S, 3) << "\t" << fmt_f64((double)total_bases_covered / (double)contig_len, 3) << "\t" << fmt_f64(rough_cvg, 3) << "\t"
-           << total_bases_covered << "\t" << fmt_f64(sum15 / (double)S, 3) << "\t" << fmt_f64(sum30 / (double)S, 3) << "\t" << fmt_f64(sum45 / (double)S, 3) << "\t" << fmt_f64(hq.avg_err, 4) << "\n";
+        row = contig + "\t" + fmt_f64(sum_all / (double)S, 3) + "\t" + fmt_f64((double)total_bases_covered / (double)contig_len, 3) + "\t" + fmt_f64(rough_cvg, 3) + "\t" +
+              std::to_string(total_bases_covered) + "\t" + fmt_f64(sum15 / (double)S, 3) + "\t" + fmt_f64(sum30 / (double)S, 3) + "\t" + fmt_f64(sum45 / (double)S, 3) + "\t" +
+              fmt_f64(hq.avg_err, 4) + "\n";
     }
     // write_nosnp_reads_parts (:151-165)
     {
@@ -156,6 +146,39 @@ void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part
         f << "READ_NAME\tREAD_LENGTH_IN_BASES\n";
         for (const Frag* fr : snpless_frags) f << fr->id << "\t" << (fr->seq_len[0] + fr->seq_len[1]) << "\n";
     }
+    return row;
 }
+void append_ploidy_row(const Options& o, const std::string& row) {
+    std::ofstream pl(o.out_dir + "/contig_ploidy_info.tsv", std::ios::app);
+    pl << row;
+}
+}  // namespace
+
+void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& ranges,
+                   const std::string& dir, const std::string& prefix, const std::string& contig, const std::vector<GnPosition>& snp_to_gn,
+                   const Options& o, const std::vector<const Frag*>& snpless_frags, size_t contig_len) {
+    const size_t n = part.size();
+    // ---- device: get_hapq (:40-41) and get_errors_cov_from_frags per haploset ---------------------------------------------------
+    const HapqResult hq = get_hapq(s, part, snp_to_gn, ranges, o);
+    std::vector<double> st(4 * n + 4, 0.0);
+    {
+        std::vector<uint64_t> off{0};
+        std::vector<uint32_t> reads, rng;
+        for (size_t g = 0; g < n; ++g) {
+            for (const Frag* f : part[g]) reads.push_back((uint32_t)f->counter_id);
+            off.push_back(reads.size());
+            rng.push_back(ranges[g].first); rng.push_back(ranges[g].second);
+        }
+        const floria_hip_contig* one[1] = {s.contig()};
+        if (n) check(floria_hip_haploset_stats(s.ctx(), one, 1, nullptr, off.data(), reads.data(), rng.data(), (uint32_t)n, st.data()));
+    }
+    append_ploidy_row(o, write_contig_files(part, ranges, dir, prefix, contig, snp_to_gn, snpless_frags, contig_len, hq, st));
+}
+
+std::string write_contig_files(const ContigWork& w, const Options&) {
+    return write_contig_files(w.final_parts, w.final_ranges, w.out_dir, w.name, w.name, *w.snp_to_genome_pos, w.snpless, w.contig_len, w.hq, w.stats);
+}
+void write_outputs(const ContigWork& w, const Options& o) { append_ploidy_row(o, write_contig_files(w, o)); }
+void append_contig_ploidy_row(const Options& o, const std::string& row) { append_ploidy_row(o, row); }
 
 }  // namespace floria

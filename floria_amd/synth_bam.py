@@ -74,7 +74,7 @@ def write_bam(path, targets, records):
         f.write(_bgzf_block(b""))                               # EOF marker
 
 
-def contig_dataset(contig, rng, edit_frac=0.1, mapq=60):
+def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
     """-> dict(ref=bytes, snps=[(pos0, REF, ALT)], records=[(pos, record bytes)], reads=[(name, [(snp, allele, qual)], span)])
     for one synth Contig made with keep_layout=True.  `reads` follows the BAM record order of the FIRST alignment of each read."""
     lay, p = contig.layout, contig.pileup
@@ -108,6 +108,10 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60):
                     qual[o] = cell[i][1]
                 else:
                     seq[o] = other[i]
+            if sub_rate > 0:                                    # sequencing errors between the SNPs: what realign's windows have to absorb
+                hit = np.nonzero(rng.random(e - b) < sub_rate)[0]
+                hit = hit[~np.isin(hit + b, snp_pos[lo:hi])]
+                seq[hit] = BASES[(np.searchsorted(BASES, seq[hit]) + rng.integers(1, 4, size=len(hit))) % 4]
             cigar = [("M", e - b)]
             pos = b
             if not paired and rng.random() < edit_frac and e - b > 400 and hi - lo >= 3:
@@ -200,7 +204,7 @@ def realign_dataset(d, flank=16):
     return changed
 
 
-def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, realign=True):
+def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, realign=True, sub_rate=0.0):
     """Write {prefix}.bam / .vcf / .fa for a list of synth Contigs (keep_layout=True).  With realign=False the returned pileups hold the
     calls as sequenced (floria-hip --no-realign).  Returns, per contig name,
     dict(pileup=Pileup in the order a correct ingest produces, names=[read name], spans=[(first_pos_base, last_pos_base)],
@@ -212,7 +216,7 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, 
     vcf.write("##fileformat=VCFv4.2\n")
     datasets = []
     for tid, c in enumerate(contigs):
-        d = contig_dataset(c, rng, edit_frac=edit_frac)
+        d = contig_dataset(c, rng, edit_frac=edit_frac, sub_rate=sub_rate)
         if realign:                # the pileup floria makes of these files when a reference FASTA is given (it always is): calls realigned
             d["realigned_calls"] = realign_dataset(d)
         datasets.append(d)

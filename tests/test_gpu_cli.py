@@ -154,3 +154,39 @@ def test_auto_estimated_parameters(floria_hip, tmp_path):
     m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
     assert m and 0.01 <= float(m.group(2)) < 0.2 and int(m.group(1)) >= 500
     assert os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))
+
+
+def tree_bytes(root):
+    files = {}
+    for d, _, fs in os.walk(root):
+        for f in fs:
+            if f != "cmd.log":
+                files[os.path.relpath(os.path.join(d, f), root)] = open(os.path.join(d, f), "rb").read().replace(root.encode(), b"OUT")      # (headers name the output directory)
+    return files
+
+
+def test_batches_of_contigs_write_the_files_of_the_per_contig_flow(floria_hip, oracle_mod, tmp_path):
+    # a metagenome-shaped input: 12 small contigs of different shapes.  One device batch for all of them, batches of 5, and one
+    # contig per batch (the reference's serial flow, floria.rs:229) must write identical trees, with 1 or 8 host threads; the
+    # first two contigs are also checked against the oracle chain like every other CLI test.
+    cs = [synth.make_config_contig(4, 20 + i, 0.25 + 0.02 * i, keep_layout=True) for i in range(10)]
+    cs += [synth.make_config_contig(3, 5, 0.2, keep_layout=True), synth.make_config_contig(1, 1, 0.5, keep_layout=True)]
+    prefix = str(tmp_path / "data")
+    synth_bam.write_dataset(prefix, cs, seed=7)
+    base = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-e", str(EPS), "-l", "5000", "--debug", "--snp-count-filter", "50"]
+    trees = []
+    for k, extra in enumerate((["-t", "8"], ["-t", "1", "--batch-contigs", "5"], ["-t", "3", "--batch-contigs", "1"], ["-t", "2", "--batch-cells", "20000"])):
+        out = str(tmp_path / f"o{k}")
+        r = subprocess.run(base + ["-o", out] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert re.search(r"Batches (\d+);", r.stderr)
+        trees.append((int(re.search(r"Batches (\d+);", r.stderr).group(1)), tree_bytes(out)))
+    assert [t[0] for t in trees[:3]] == [1, 3, 12] and 1 < trees[3][0] < 12
+    names = sorted(trees[0][1])
+    assert len([n for n in names if n.endswith(".vartigs")]) == 12
+    rows = trees[0][1]["contig_ploidy_info.tsv"].decode().splitlines()
+    assert [r.split("\t")[0] for r in rows[1:]] == [c.name for c in cs]                     # contig order of the BAM header
+    for n_b, tree in trees[1:]:
+        assert sorted(tree) == names
+        for n in names:
+            assert tree[n] == trees[0][1][n], (n_b, n)

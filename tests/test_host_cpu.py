@@ -228,3 +228,22 @@ def test_realign_changes_calls_next_to_unreported_indels(floria_hip, tmp_path):
             assert a_re == (0 if scores[0] >= scores[1] else 1), (rc["name"], snp)
             changed += a_re != a_called
     assert changed > 0
+
+
+@pytest.mark.parametrize("sub_rate", [0.03, 0.12])
+def test_realign_shortcut_is_exact_under_sequencing_errors(floria_hip, tmp_path, sub_rate):
+    # realign decides most calls from the mismatch count of the two 32-base windows without running the DP (ingest.cpp, "Exact
+    # shortcut"); with substitution errors at 3 % and 12 % the windows carry 0..8 mismatches, so both the shortcut and the DP
+    # are taken, on either side of the bound.  Expected calls: the numpy Gotoh DP on every window (synth_bam.realign_dataset).
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    prefix = str(tmp_path / "d")
+    ex = synth_bam.write_dataset(prefix, [c], seed=4, sub_rate=sub_rate)[c.name]
+    got, _ = ingest(floria_hip, prefix, tmp_path)
+    raw, _ = ingest(floria_hip, prefix, tmp_path, extra=("--no-realign",))
+    pile = ex["pileup"]
+    n_changed = 0
+    for i, (g, g0) in enumerate(zip(got[c.name]["reads"], raw[c.name]["reads"])):
+        s, a, q = pile.read(i)
+        assert g["cells"] == list(zip(s.tolist(), a.tolist(), q.tolist())), f"read {i}"
+        n_changed += sum(1 for x, y in zip(g["cells"], g0["cells"]) if x != y)
+    assert n_changed > 0 if sub_rate > 0.1 else True                              # noise flips some calls, the same ones in both
