@@ -22,7 +22,10 @@
 
 namespace fl {
 
-constexpr int SLAB_TILE = 256;
+#ifndef FLORIA_SLAB_TILE
+#define FLORIA_SLAB_TILE 256
+#endif
+constexpr int SLAB_TILE = FLORIA_SLAB_TILE;      // cells of a read staged per pass (x2 arrays x2 buffers x4 B of LDS)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 

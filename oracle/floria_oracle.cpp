@@ -51,6 +51,13 @@ thread_local std::string g_err;
 // Sensitivity knob (tests only): 0 = canonical ascending counter_id at the order-dependent sites, 1 = DEscending.
 // The reference's FxHash order is some third permutation; comparing 0 vs 1 measures how often the order matters at all.
 std::atomic<int> g_order_mode{0};
+// Arithmetic mode.  0 (canonical, what the HIP path computes): every weighted sum is carried as (Q24 integer, #epsilon) and turned
+// into f64 once, value = Q * 2^-24 + m * eps.  1 (the reference's own arithmetic): running f64 sums in the order the
+// reference adds the terms, i.e. the iteration order of its hash containers (emulated with FxSet below) — `diff += epsilon`
+// interleaved with `diff += w` over a read's positions (utils_frags.rs:32-75), error_vec per partition summed over the partitions
+// (global_clustering.rs:181-208), `errors +=` over a haplotype's positions (local_clustering.rs:218-260).  The two agree bit for bit
+// when eps is dyadic; mode 1 exists to COUNT how often they part at the reference's non-dyadic operating points.
+std::atomic<int> g_arith_mode{0};
 
 // ---- mode 2: FxHashSet<&Frag> as the reference's binary lays it out -------------------------------------------------------------
 // The three order-dependent sites iterate hash sets / maps keyed by &Frag, whose Hash is `counter_id.hash()` (types_structs.rs:
@@ -193,6 +200,7 @@ inline double qm_to_f64(uint64_t q, uint64_t m, double eps) {
 // ---- Frag (types_structs.rs:68-112) as a view into the CSR pileup -----------------------------------
 struct Pile {
     const floria_pileup* p;
+    const uint32_t* order = nullptr;      // arithmetic mode 1: order[beg(r) .. end(r)) = the read's cells in the iteration order of Frag.positions
     uint32_t n() const { return p->n_reads; }
     uint32_t beg(uint32_t r) const { return p->read_off[r]; }
     uint32_t end(uint32_t r) const { return p->read_off[r + 1]; }
@@ -307,21 +315,40 @@ HapBlock hap_block_from_partition(const Pile& P, const std::vector<std::vector<u
 }
 
 // ---- distance_read_haplo_epsilon_empty (utils_frags.rs:32-75) ------------------------------------------
-struct SD { uint64_t same, diff, m; };   // same = Q24, diff = Q24 + m*eps
-inline SD distance_read_haplo_epsilon_empty(const Pile& P, uint32_t r, const Hap& hap) {
-    SD d{0, 0, 0};
-    for (uint32_t c = P.beg(r); c < P.end(r); ++c) {
+struct SD { uint64_t same, diff, m; double same_f, diff_f; };   // same = Q24, diff = Q24 + m*eps; *_f: the running f64 sums (arithmetic mode 1)
+inline SD distance_read_haplo_epsilon_empty(const Pile& P, uint32_t r, const Hap& hap, double epsilon = 0.0) {
+    SD d{0, 0, 0, 0.0, 0.0};
+    const bool running = P.order != nullptr;
+    for (uint32_t cc = P.beg(r); cc < P.end(r); ++cc) {
+        const uint32_t c = running ? P.order[cc] : cc;       // `for pos in r.positions.iter()` (:35): an FxHashSet
         const Site* s = hap.find(P.p->snp[c]);
         uint64_t mx = 0;                                   // :36-44 empty_pos <=> no non-zero count
         if (s) for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) mx = std::max(mx, s->q[a]);
-        if (mx == 0) { d.m += 1; continue; }               // :45-48 diff += epsilon
+        if (mx == 0) { d.m += 1; d.diff_f += epsilon; continue; }               // :45-48 diff += epsilon
         uint8_t a = P.p->allele[c];
         uint64_t w = g_w.q24[P.p->qual[c]];
         // :52-71  same if the read's allele is (tied for) the consensus, else diff
         bool has = (s->present >> a) & 1;
-        if (has && s->q[a] == mx) d.same += w; else d.diff += w;
+        if (has && s->q[a] == mx) { d.same += w; d.same_f += (double)w * 0x1p-24; } else { d.diff += w; d.diff_f += (double)w * 0x1p-24; }
     }
     return d;
+}
+// the two f64 values the reference goes on with
+inline double sd_same(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) == 1 ? d.same_f : qm_to_f64(d.same, 0, eps); }
+inline double sd_diff(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) == 1 ? d.diff_f : qm_to_f64(d.diff, d.m, eps); }
+
+// Frag.positions: FxHashSet<SnpPosition>, filled in ascending order by the CIGAR walk (file_reader.rs:661-736); its iteration order
+// is the table's bucket order.  -> for every read the permutation of its cells in that order.
+inline std::vector<uint32_t> build_cell_order(const floria_pileup* p) {
+    std::vector<uint32_t> ord(p->read_off[p->n_reads]);
+    for (uint32_t r = 0; r < p->n_reads; ++r) {
+        const uint32_t b = p->read_off[r], e = p->read_off[r + 1];
+        FxSet fs;
+        for (uint32_t c = b; c < e; ++c) fs.insert(p->snp[c]);
+        uint32_t k = b;
+        fs.for_each([&](uint64_t pos) { ord[k++] = (uint32_t)(std::lower_bound(p->snp + b, p->snp + e, (uint32_t)pos) - p->snp); });
+    }
+    return ord;
 }
 
 // ---- stable_binom_cdf_p_rev / log_sum_exp (utils_frags.rs:211-258) ---------------------------------------
@@ -421,6 +448,7 @@ struct SearchNode {
     uint32_t read; int part; int parent;
     uint64_t diff_q, diff_m;       // sum over partitions of error_vec[k].1 ("mec", global_clustering.rs:202)
     double   score;
+    double   errv[FLORIA_MAX_PLOIDY];      // arithmetic mode 1: error_vec[k].1 as running f64 sums (:196-200)
 };
 
 // ---- build_truncated_hap_block (types_structs.rs:326-376); broken_blocks bookkeeping (:340-366) is dead
@@ -441,7 +469,7 @@ void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, 
     partition.assign(ploidy, {});
     if (all_reads.empty()) return;                                                    // :24-26
     std::vector<SearchNode> arena;
-    arena.push_back(SearchNode{all_reads[0], -1, -1, 0, 0, 0.0});                     // first_node :34-44
+    { SearchNode root{}; root.read = all_reads[0]; root.part = -1; root.parent = -1; arena.push_back(root); }                     // first_node :34-44
     BinaryHeap heap;
     { HeapItem it; it.score = 0.0; it.node = 0; it.block.blocks.assign(ploidy, Hap()); heap.push(std::move(it)); }
     std::vector<double> p_value_list(ploidy);
@@ -455,9 +483,9 @@ void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, 
         for (size_t h = 0; h < heap.data.size(); ++h) {                                // heap.iter() = Vec order :71
             const HeapItem& cur = heap.data[h];
             for (int k = 0; k < ploidy; ++k) {                                         // :74-91
-                sd[k] = distance_read_haplo_epsilon_empty(P, frag, cur.block.blocks[k]);
-                double same = qm_to_f64(sd[k].same, 0, epsilon);
-                double diff = qm_to_f64(sd[k].diff, sd[k].m, epsilon);
+                sd[k] = distance_read_haplo_epsilon_empty(P, frag, cur.block.blocks[k], epsilon);
+                double same = sd_same(sd[k], epsilon);
+                double diff = sd_diff(sd[k], epsilon);
                 p_value_list[k] = 1.0 * stable_binom_cdf_p_rev(f64_as_usize(same + diff), f64_as_usize(diff), epsilon, div_factor);
             }
             double lse = log_sum_exp(p_value_list);                                    // :93
@@ -467,11 +495,17 @@ void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, 
                 if (p_value_list[j] - lse > cutoff_value) {                            // :98
                     // read_to_node_value :181-208 (recomputes the same distance :193)
                     const SearchNode& pn = arena[cur.node];
-                    SearchNode nn;
+                    SearchNode nn = pn;
                     nn.read = frag; nn.part = j; nn.parent = cur.node;
                     nn.diff_q = pn.diff_q + sd[j].diff;
                     nn.diff_m = pn.diff_m + sd[j].m;
                     nn.score  = qm_to_f64(nn.diff_q, nn.diff_m, epsilon);               // new_node_score = -(-mec) :105
+                    if (g_arith_mode.load(std::memory_order_relaxed) == 1) {
+                        nn.errv[j] = pn.errv[j] + sd[j].diff_f;                         // node.error_vec[i].1 + diff :198
+                        double mec = 0.0;                                               // new_error_vec.iter().map(|x| x.1).sum() :202
+                        for (int k = 0; k < ploidy; ++k) mec += nn.errv[k];
+                        nn.score = mec;
+                    }
                     HapBlock new_block = build_truncated_hap_block(P, cur.block, frag, j, current_startpos);   // :118
                     bool project_exists = false;                                       // :122-127
                     for (const HeapItem& e : next.data)
@@ -499,22 +533,49 @@ void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, 
 }
 
 // ---- get_mec_stats_epsilon (local_clustering.rs:218-260, use_gaps=true) and _no_phred (:187-215) ---------
-struct QM { uint64_t bases, errors, m; };
-std::vector<QM> mec_stats_of_block(const HapBlock& hb, uint64_t one) {
+struct QM { uint64_t bases, errors, m; double errors_f; };       // errors_f: the running f64 sum (arithmetic mode 1)
+// part_order (arithmetic mode 1): the reads of every partition in the iteration order of its FxHashSet.  set_to_seq_dict
+// (utils_frags.rs:160-176) fills the haplotype's FxHashMap position by position in that order (reads x their own position order), and
+// `for seq_dict in hap.values()` (:227) walks the map's buckets: the order in which `errors` receives its terms.
+std::vector<QM> mec_stats_of_block(const HapBlock& hb, uint64_t one, const Pile* P = nullptr,
+                                   const std::vector<std::vector<uint32_t>>* part_order = nullptr, double epsilon = 0.0) {
     std::vector<QM> v;
-    for (const Hap& hap : hb.blocks) {
-        QM s{0, 0, 0};
-        hap.for_each([&](uint32_t, const Site& site) {
+    const double scale = one == 1 ? 1.0 : 0x1p-24;
+    for (size_t pi = 0; pi < hb.blocks.size(); ++pi) {
+        const Hap& hap = hb.blocks[pi];
+        QM s{0, 0, 0, 0.0};
+        auto site_terms = [&](const Site& site, bool running) {
             if (!site.present) return;                           // allele_counts.is_empty() -> continue
             uint64_t mx = 0, tot = 0;
             for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((site.present >> a) & 1) { mx = std::max(mx, site.q[a]); tot += site.q[a]; }
-            s.bases += mx;                                       // cons_bases = last after sort
-            s.errors += tot - mx;                                // all but the last
-            if (mx <= one) s.m += 1;                             // cons_bases <= 1. -> errors += epsilon
-        });
+            if (!running) {
+                s.bases += mx;                                       // cons_bases = last after sort
+                s.errors += tot - mx;                                // all but the last
+                if (mx <= one) s.m += 1;                             // cons_bases <= 1. -> errors += epsilon
+            } else {
+                uint64_t vals[FLORIA_MAX_ALLELES]; int nv = 0;
+                for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((site.present >> a) & 1) vals[nv++] = site.q[a];
+                std::sort(vals, vals + nv);                          // allele_counts.sort_by(count) (:244); equal counts add equal terms
+                for (int i = 0; i + 1 < nv; ++i) s.errors_f += (double)vals[i] * scale;      // :248-250
+                if (mx <= one) s.errors_f += epsilon;                // :251-253
+            }
+        };
+        hap.for_each([&](uint32_t, const Site& site) { site_terms(site, false); });
+        if (P && P->order && part_order) {
+            FxSet pos_map;
+            for (uint32_t r : (*part_order)[pi])
+                for (uint32_t cc = P->beg(r); cc < P->end(r); ++cc) pos_map.insert(P->p->snp[P->order[cc]]);
+            pos_map.for_each([&](uint64_t pos) { const Site* site = hap.find((uint32_t)pos); if (site) site_terms(*site, true); });
+        }
         v.push_back(s);
     }
     return v;
+}
+inline std::vector<std::vector<uint32_t>> set_orders(const std::vector<std::vector<uint32_t>>& partition, const std::vector<FxSet>* shadow) {
+    if (!shadow) return partition;
+    std::vector<std::vector<uint32_t>> o;
+    for (const FxSet& f : *shadow) o.push_back(f.order());
+    return o;
 }
 
 // ---- opt_iterate (local_clustering.rs:292-358) -------------------------------------------------------------
@@ -530,12 +591,12 @@ std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<
         if (shadow) order_i = (*shadow)[i].order();                                      // mode 2: the emulated FxHashSet's bucket order (:304)
         else if (g_order_mode.load() == 1) std::reverse(order_i.begin(), order_i.end());
         for (uint32_t read : order_i) {                                                  // canonical: ascending id (2)
-            SD own = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[i]);
-            double errors_read = qm_to_f64(own.diff, own.m, epsilon);
+            SD own = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[i], epsilon);
+            double errors_read = sd_diff(own, epsilon);
             for (int j = 0; j < ploidy; ++j) {
                 if (j == i) continue;
-                SD oth = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[j]);
-                double read_errors_movej = qm_to_f64(oth.diff, oth.m, epsilon);
+                SD oth = distance_read_haplo_epsilon_empty(P, read, hap_block.blocks[j], epsilon);
+                double read_errors_movej = sd_diff(oth, epsilon);
                 double diff_score = errors_read - read_errors_movej;                     // :320
                 if (diff_score > 0.0) best_moves.push_back(Move{diff_score, i, read, j});
             }
@@ -574,7 +635,8 @@ std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<
 // ---- optimize_clustering (local_clustering.rs:71-130) -------------------------------------------------------
 double mec_score_of(const std::vector<QM>& v, double epsilon) {
     double s = 0.0;                                   // binom_vec.iter().map(|x| x.1).sum()
-    for (const QM& x : v) s += qm_to_f64(x.errors, x.m, epsilon);
+    const bool running = g_arith_mode.load(std::memory_order_relaxed) == 1;
+    for (const QM& x : v) s += running ? x.errors_f : qm_to_f64(x.errors, x.m, epsilon);
     return s * -1.0;
 }
 std::vector<std::vector<uint32_t>> optimize_clustering(const Pile& P, std::vector<std::vector<uint32_t>> partition,
@@ -584,13 +646,19 @@ std::vector<std::vector<uint32_t>> optimize_clustering(const Pile& P, std::vecto
     if (iters_done) *iters_done = 0;
     if (!not_empty) return partition;                                                    // :82-85
     HapBlock prev_hap_block = hap_block_from_partition(P, partition, true);
-    double prev_score = mec_score_of(mec_stats_of_block(prev_hap_block, 1u << 24), epsilon);   // :97-99
+    const bool running = g_arith_mode.load(std::memory_order_relaxed) == 1 && P.order;
+    auto stats_of = [&](const HapBlock& hb, const std::vector<std::vector<uint32_t>>& part, const std::vector<FxSet>* sh) {
+        if (!running) return mec_stats_of_block(hb, 1u << 24);
+        const auto ord = set_orders(part, sh);
+        return mec_stats_of_block(hb, 1u << 24, &P, &ord, epsilon);
+    };
+    double prev_score = mec_score_of(stats_of(prev_hap_block, partition, shadow), epsilon);   // :97-99
     std::vector<std::vector<uint32_t>> best_part = std::move(partition);
     for (int i = 0; i < max_iters; ++i) {                                                // :105-127
         std::vector<FxSet> new_shadow;
         auto new_part = opt_iterate(P, best_part, prev_hap_block, epsilon, shadow, shadow ? &new_shadow : nullptr);
         HapBlock new_block = hap_block_from_partition(P, new_part, true);
-        double new_score = mec_score_of(mec_stats_of_block(new_block, 1u << 24), epsilon);
+        double new_score = mec_score_of(stats_of(new_block, new_part, shadow ? &new_shadow : nullptr), epsilon);
         if (iters_done) *iters_done = i + 1;
         if (new_score > prev_score) { prev_score = new_score; best_part = std::move(new_part); prev_hap_block = std::move(new_block); if (shadow) *shadow = std::move(new_shadow); }
         else return best_part;
@@ -638,9 +706,11 @@ void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const flo
         auto optimized_part = optimize_clustering(P, std::move(part), epsilon, NUM_ITER_OPTIMIZE, nullptr, emu ? &shadow : nullptr);  // :153-154
         if (emu) shadow_vector.push_back(shadow);
         HapBlock np = hap_block_from_partition(P, optimized_part, false);                   // :156 (_no_phred)
-        for (const QM& s : mec_stats_of_block(np, 1)) {                                     // :158-162
+        const bool running = g_arith_mode.load(std::memory_order_relaxed) == 1 && P.order;
+        const auto final_orders = running ? set_orders(optimized_part, emu ? &shadow : nullptr) : std::vector<std::vector<uint32_t>>();
+        for (const QM& s : (running ? mec_stats_of_block(np, 1, &P, &final_orders, epsilon) : mec_stats_of_block(np, 1))) {   // :158-162
             double good = (double)s.bases;
-            double bad  = (double)s.errors + (double)s.m * epsilon;
+            double bad  = running ? s.errors_f : (double)s.errors + (double)s.m * epsilon;
             out.mec[ploidy - 1] += bad;
             num_alleles += good;
             num_alleles += bad;
@@ -777,9 +847,9 @@ void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32
         if (read_to_parts[r].empty()) continue;
         bool have = false; double bd = 0, bs = 0; uint32_t bid = 0;
         for (uint32_t id : read_to_parts[r]) {
-            SD d = distance_read_haplo_epsilon_empty(P, r, block.blocks[id]);
-            double key_d = qm_to_f64(d.diff, d.m, epsilon) + 1.;                             // (diff + 1., id, same)
-            double key_s = qm_to_f64(d.same, 0, epsilon);
+            SD d = distance_read_haplo_epsilon_empty(P, r, block.blocks[id], epsilon);
+            double key_d = sd_diff(d, epsilon) + 1.;                                         // (diff + 1., id, same)
+            double key_s = sd_same(d, epsilon);
             bool less = !have || key_d < bd || (key_d == bd && (id < bid || (id == bid && key_s < bs)));
             if (less) { have = true; bd = key_d; bs = key_s; bid = id; }
         }
@@ -856,6 +926,8 @@ extern "C" {
 
 const char* floria_oracle_last_error(void) { return g_err.c_str(); }
 void floria_oracle_set_order_mode(int m) { g_order_mode.store(m); }
+void floria_oracle_set_arith_mode(int m) { g_arith_mode.store(m); }
+int floria_oracle_get_arith_mode(void) { return g_arith_mode.load(); }
 
 // The FxHashSet<&Frag> emulator on its own (tests; building the later sets of the chain from Python): ops[i] > 0 inserts key
 // ops[i] - 1, ops[i] < 0 removes key -ops[i] - 1; out receives the iteration order of the final set.
@@ -902,6 +974,8 @@ int floria_oracle_phase_blocks(const floria_pileup* pileup, const uint32_t* blk_
     if (rc) return rc;
     if (!params || params->max_ploidy < 1 || params->max_ploidy > FLORIA_MAX_PLOIDY || params->beam < 1) { g_err = "bad params"; return FLORIA_E_INVALID; }
     Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<BlockOut> outs(n_blocks);
     std::atomic<uint32_t> next{0};
     auto worker = [&]() {
@@ -954,6 +1028,8 @@ int floria_oracle_one_ploidy(const floria_pileup* pileup, uint32_t start, uint32
     int rc = validate(pileup);
     if (rc) return rc;
     Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<uint32_t> reads = find_reads_in_interval(P, start, end);
     *n_out = (uint32_t)reads.size();
     if (reads.empty()) return 0;
@@ -988,6 +1064,8 @@ int floria_oracle_reassign_ordered(const floria_pileup* pileup, const uint64_t* 
     int rc = validate(pileup);
     if (rc) return rc;
     Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<uint32_t>> parts(n_groups);
     std::vector<std::pair<uint32_t, uint32_t>> ranges(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) {
@@ -1042,6 +1120,8 @@ int floria_oracle_hap_graph(const floria_pileup* pileup, const uint32_t* blk_sta
     int rc = validate(pileup);
     if (rc) return rc;
     Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<NodeO>> cols;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         if (best_ploidy[b] == 0) continue;                               // None -> no column (graph_processing.rs:355-361)
@@ -1101,6 +1181,8 @@ int floria_oracle_haploset_stats(const floria_pileup* pileup, const uint32_t* re
     int rc = validate(pileup);
     if (rc) return rc;
     Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<uint32_t> fs(reads, reads + n);
     Hap hap_map = set_to_seq_dict(P, fs, false);                                   // :606
     double errors = 0., total_support = 0., sum_support = 0.;
@@ -1140,6 +1222,8 @@ int floria_oracle_hapq(const floria_pileup* pileup, const uint64_t* grp_off, con
     int rc = validate(pileup);
     if (rc) return rc;
     Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<uint32_t>> parts(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) parts[g].assign(grp_read + grp_off[g], grp_read + grp_off[g + 1]);
     double weight = 0., error = 0.;

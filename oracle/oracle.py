@@ -155,6 +155,13 @@ def set_order_mode(mode):
     lib().floria_oracle_set_order_mode(C.c_int(mode))
 
 
+def set_arith_mode(mode):
+    """0 = canonical arithmetic (every weighted sum an exact (Q24, #epsilon) pair turned into f64 once: what the HIP path computes),
+    1 = the reference's running f64 sums, terms added in the iteration order of its (emulated) hash containers.  Identical for
+    dyadic epsilon; mode 1 is for counting how often they part elsewhere (scripts/arith_sensitivity.py)."""
+    lib().floria_oracle_set_arith_mode(C.c_int(mode))
+
+
 def fxset_order(ops):
     """Iteration order of the emulated FxHashSet<&Frag> after `ops`: +k+1 inserts counter_id k, -(k+1) removes it."""
     ops = np.ascontiguousarray(ops, np.int64)

@@ -37,13 +37,22 @@ def test_s1_against_the_captured_reference(gpu_ctx, hip_lib, oracle_mod, tmp_pat
         for c in cs:
             ex = expect[c.name]
             s, e = hip_lib.get_range_with_lengths(ex["snp_pos0"], 10000)
-            rg = gpu_ctx.phase_blocks(ex["pileup"], s, e, hip_lib.make_params(eps))
-            ro = oracle_mod.phase_blocks(ex["pileup"], s, e, oracle_mod.make_params(eps), threads=8)
-            for b in range(rg.n_blocks):
-                if rg.best_ploidy[b] == 0:
+            # a dyadic epsilon pins the PRODUCT (both arithmetics exact, S1 independent of the hash orders); any other epsilon checks the
+            # oracle's restatement of the reference's running sums in emulated hash order and nothing else
+            dyadic = float(eps * 2 ** 20).is_integer()
+            rg = gpu_ctx.phase_blocks(ex["pileup"], s, e, hip_lib.make_params(eps)) if dyadic else None
+            if not dyadic:
+                oracle_mod.set_arith_mode(1); oracle_mod.set_order_mode(2)
+            try:
+                ro = oracle_mod.phase_blocks(ex["pileup"], s, e, oracle_mod.make_params(eps), threads=8 if dyadic else 1)
+            finally:
+                oracle_mod.set_arith_mode(0); oracle_mod.set_order_mode(0)
+            for b in range(ro.n_blocks):
+                if ro.best_ploidy[b] == 0:
                     continue
                 ref = mecs[k]; k += 1
-                tried = int(rg.ploidies_tried[b])
-                assert np.array_equal(ref[:tried].view(np.uint64), rg.mec[b, :tried].view(np.uint64)), (run, c.name, b, "HIP vs reference")
+                tried = int(ro.ploidies_tried[b])
+                if dyadic:
+                    assert np.array_equal(ref[:tried].view(np.uint64), rg.mec[b, :tried].view(np.uint64)), (run, c.name, b, "HIP vs reference")
                 assert np.array_equal(ref[:tried].view(np.uint64), ro.mec[b, :tried].view(np.uint64)), (run, c.name, b, "oracle vs reference")
         assert k == len(mecs)
