@@ -318,9 +318,22 @@ HapBlock hap_block_from_partition(const Pile& P, const std::vector<std::vector<u
 struct SD { uint64_t same, diff, m; double same_f, diff_f; };   // same = Q24, diff = Q24 + m*eps; *_f: the running f64 sums (arithmetic mode 1)
 inline SD distance_read_haplo_epsilon_empty(const Pile& P, uint32_t r, const Hap& hap, double epsilon = 0.0) {
     SD d{0, 0, 0, 0.0, 0.0};
-    const bool running = P.order != nullptr;
+    const bool running = P.order != nullptr;                 // (arithmetic mode 1; mode 0 — the timed CPU baseline — pays nothing for it)
+    if (!running) {
+        for (uint32_t c = P.beg(r); c < P.end(r); ++c) {
+            const Site* s = hap.find(P.p->snp[c]);
+            uint64_t mx = 0;                                   // :36-44 empty_pos <=> no non-zero count
+            if (s) for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) mx = std::max(mx, s->q[a]);
+            if (mx == 0) { d.m += 1; continue; }               // :45-48 diff += epsilon
+            uint8_t a = P.p->allele[c];
+            uint64_t w = g_w.q24[P.p->qual[c]];
+            bool has = (s->present >> a) & 1;                  // :52-71  same if the read's allele is (tied for) the consensus, else diff
+            if (has && s->q[a] == mx) d.same += w; else d.diff += w;
+        }
+        return d;
+    }
     for (uint32_t cc = P.beg(r); cc < P.end(r); ++cc) {
-        const uint32_t c = running ? P.order[cc] : cc;       // `for pos in r.positions.iter()` (:35): an FxHashSet
+        const uint32_t c = P.order[cc];                      // `for pos in r.positions.iter()` (:35): an FxHashSet
         const Site* s = hap.find(P.p->snp[c]);
         uint64_t mx = 0;                                   // :36-44 empty_pos <=> no non-zero count
         if (s) for (int a = 0; a < FLORIA_MAX_ALLELES; ++a) if ((s->present >> a) & 1) mx = std::max(mx, s->q[a]);
