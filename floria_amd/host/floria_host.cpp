@@ -2,6 +2,8 @@
 #include "floria_host.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <set>
 
 namespace floria {
 
@@ -94,6 +96,37 @@ std::vector<std::vector<HapNode>> generate_hap_graph(Session& s, const std::vect
     floria_hip_hap_graph_free(hg);
     floria_hip_block_result_free(res);
     return cols;
+}
+
+// utils_frags::remove_monomorphic_allele (utils_frags.rs:713-772).  phred_scale = 1f32 - 10f32^(-q/10) widened to f64 (:702-711); the
+// per-(SNP, allele) sums only add such weights, all multiples of 2^-24: exact in any order, so the hash-map order of the reference does not matter.
+std::vector<Frag> remove_monomorphic_allele(std::vector<Frag> frags, double error) {
+    std::map<SnpPosition, std::map<Genotype, double>> allele_count_map;
+    for (const Frag& f : frags)
+        for (const auto& kv : f.seq_dict) {
+            const float prob = 1.0f - powf(10.0f, (float)f.qual_dict.at(kv.first) / -10.0f);
+            allele_count_map[kv.first][kv.second] += (double)prob;
+        }
+    std::set<SnpPosition> mono;
+    for (const auto& am : allele_count_map) {
+        if (am.second.size() == 1) { mono.insert(am.first); continue; }
+        std::vector<double> vals;
+        for (const auto& kv : am.second) vals.push_back(kv.second);
+        std::sort(vals.begin(), vals.end(), [](double a, double b) { return a > b; });
+        if (vals[0] * error > vals[1]) mono.insert(am.first);
+    }
+    std::vector<Frag> out;
+    for (Frag& f : frags) {
+        for (auto it = f.seq_dict.begin(); it != f.seq_dict.end();) {
+            if (mono.count(it->first)) { f.qual_dict.erase(it->first); f.snp_pos_to_seq_pos.erase(it->first); it = f.seq_dict.erase(it); } else ++it;
+        }
+        if (f.seq_dict.empty()) continue;
+        f.first_position = f.seq_dict.begin()->first; f.last_position = f.seq_dict.rbegin()->first;
+        out.push_back(std::move(f));
+    }
+    std::sort(out.begin(), out.end());
+    for (size_t i = 0; i < out.size(); ++i) out[i].counter_id = i;
+    return out;
 }
 
 // ---- Batch: every device stage once for MANY contigs ----------------------------------------------------------------------------------

@@ -54,6 +54,10 @@ struct Options {
     bool overwrite = false;             // --overwrite
     std::vector<std::string> list_to_phase;   // -G
     bool reassign_short = false;        // hidden flag; not supported (part_block_manip.rs:235-270)
+    bool output_reads = false;          // --output-reads: fastq of every haploset's reads (file_writer.rs:370-560)
+    bool gzip = false;                  // --gzip-reads
+    bool trim_reads = false;            // --extra-trimming
+    bool ignore_monomorphic = false;    // --ignore-monomorphic (utils_frags.rs:713-772)
     int device = 0;
 };
 
@@ -68,6 +72,8 @@ struct Frag {
     bool is_paired = false;
     GnPosition first_pos_base = SIZE_MAX, last_pos_base = SIZE_MAX;      // reference span of the alignment (0-based start, end exclusive)
     size_t seq_len[2] = {0, 0};                                          // bases of seq_string[0], seq_string[1]
+    std::string seq_string[2];                                           // only kept with --output-reads: DnaString::from_acgt_bytes of SEQ (anything but ACGT -> A)
+    std::vector<uint8_t> qual_string[2];                                 // QUAL + 33
     std::map<SnpPosition, std::pair<uint8_t, GnPosition>> snp_pos_to_seq_pos;
     void update(SnpPosition snp_pos, Genotype geno, uint8_t qual) {      // update_frag, types_structs.rs:286-324
         seq_dict[snp_pos] = geno; qual_dict[snp_pos] = qual;
@@ -211,6 +217,13 @@ private:
     std::vector<floria_pileup> piles_;
     std::vector<floria_hip_contig*> handles_;
 };
+// utils_frags::remove_monomorphic_allele (utils_frags.rs:713-772, --ignore-monomorphic): SNPs where one allele carries (almost) all of the
+// phred weight are dropped from every read; reads left without SNPs are dropped; the rest is sorted and renumbered
+std::vector<Frag> remove_monomorphic_allele(std::vector<Frag> frags, double error);
+// write_reads + write_nosnp_reads (file_writer.rs:86-150, 370-560, --output-reads): long_reads/{i}_part.fastq, short_reads/{i}_part_paired{1,2}.fastq, snpless*.fastq
+void write_reads(const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec, const std::string& out_bam_part_dir,
+                 bool extend_read_clipping, const std::vector<uint8_t>& hapqs, bool gzip);
+void write_nosnp_reads(const std::string& out_bam_part_dir, const std::vector<const Frag*>& snpless_frags, bool gzip);
 // write_outputs for a contig whose statistics were computed by Batch::stats_and_hapq
 void write_outputs(const ContigWork& w, const Options& options);
 // the same in two halves, for hosts that write the contigs of a batch from several threads: the files of the contig (returns its

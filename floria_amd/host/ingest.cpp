@@ -186,7 +186,8 @@ int64_t reference_end(const BamRecord& r) {                 // bam_endpos
 }
 
 // frag_from_record (file_reader.rs:661-736)
-Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPosition>& snp_positions, const std::map<GnPosition, std::vector<Genotype>>& pos_allele_map, size_t counter_id) {
+Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPosition>& snp_positions, const std::map<GnPosition, std::vector<Genotype>>& pos_allele_map, size_t counter_id,
+                      bool keep_sequences) {
     Frag frag;
     frag.id = rec.qname; frag.counter_id = counter_id;
     frag.is_paired = (rec.flags & F_PAIRED1) || (rec.flags & F_PAIRED2);
@@ -228,6 +229,15 @@ Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPositi
         if (consumes_r(op)) r += len;                                          // D / N over a SNP: pair[0] is None -> no call
     }
     frag.seq_len[0] = rec.seq.size();
+    if (keep_sequences) {                                                      // :728-734
+        frag.seq_string[0].resize(rec.seq.size());
+        for (size_t i = 0; i < rec.seq.size(); ++i) {
+            const char c = rec.seq[i];
+            frag.seq_string[0][i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : ((c == 'a' || c == 'c' || c == 'g' || c == 't') ? (char)(c - 32) : 'A');
+        }
+        frag.qual_string[0].resize(rec.qual.size());
+        for (size_t i = 0; i < rec.qual.size(); ++i) frag.qual_string[0][i] = rec.qual[i] > 222 ? 255 : (uint8_t)(rec.qual[i] + 33);     // checked_add(33).unwrap_or(255)
+    }
     return frag;
 }
 
@@ -454,7 +464,7 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
         if (!alignment_passed_check(rec.flags, rec.mapq, use_supplementary, filter_supplementary, o.mapq_cutoff).first) continue;
         auto ins = name_ix.emplace(rec.qname, names.size());
         if (ins.second) { names.push_back(rec.qname); buckets.emplace_back(); }
-        Frag fr = frag_from_record(rec, snp_positions, pos_allele_map, this_count);
+        Frag fr = frag_from_record(rec, snp_positions, pos_allele_map, this_count, o.output_reads);
         if (ref_seq) realign(*ref_seq, fr, rec.seq, snp_to_gn, pos_allele_map);                    // :416-423
         buckets[ins.first->second].push_back({rec.flags, std::move(fr)});
     }
@@ -475,6 +485,7 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
             ff->first_pos_base = std::min(ff->first_pos_base, sf->first_pos_base);
             ff->last_pos_base = std::min(ff->last_pos_base, sf->last_pos_base);           // (min, as in the reference, :547)
             ff->seq_len[1] = sf->seq_len[0];
+            ff->seq_string[1] = std::move(sf->seq_string[0]); ff->qual_string[1] = std::move(sf->qual_string[0]);   // :551-554
             for (auto& kv : sf->snp_pos_to_seq_pos) ff->snp_pos_to_seq_pos[kv.first] = {1, kv.second.second};
             ref_frags.push_back(std::move(*ff));
         } else if (frags.size() == 1 && (frags[0].flags & F_SUPP) == 0) {

@@ -8,8 +8,9 @@
 //   floria-hip -b reads.bam -v calls.vcf -r reference.fa -o results [-e 0.04] [-l 10000] [-n 10] [-p 5] [-d 0.0005] [-s 2] [-m 15]
 //              [-t 10] [-G contig ...] [-X] [--no-stop-heuristic] [--snp-count-filter 100] [--supp-aln-dist-cutoff 40000] [--overwrite]
 //
-// Flags of the reference that are not supported and say so: -H/--hybrid, --reassign-short, --bin-by-cov, --output-reads,
-// --gzip-reads, --extra-trimming, --ignore-monomorphic, -q (accepted and ignored by the reference too).  Extras: --device N,
+//              [--output-reads [--gzip-reads] [--extra-trimming]] [--ignore-monomorphic]
+// Flags of the reference that are not supported and say so: the hidden -H/--hybrid, --reassign-short, --bin-by-cov (-q is accepted and
+// ignored, as in the reference).  Extras: --device N,
 // --batch-contigs N / --batch-cells N (size of a device batch), --debug (debug_graph.txt per contig), and for tests --dump-frags FILE,
 // --ingest-only, --no-realign, --stitch-graph FILE.
 #include <sys/stat.h>
@@ -122,8 +123,11 @@ int main(int argc, char** argv) {
             else if (a == "--ingest-only") ingest_only = true;          // (tests) stop after ingest: needs no GPU
             else if (a == "--stitch-graph") stitch_graph = val();       // (tests) N / E lines of a hap graph -> F / P lines on stdout: needs no GPU
             else if (a == "-h" || a == "--help") { usage(); return 0; }
-            else if (a == "-H" || a == "--hybrid" || a == "--reassign-short" || a == "--bin-by-cov" || a == "--output-reads" || a == "--gzip-reads" ||
-                     a == "--extra-trimming" || a == "--ignore-monomorphic")
+            else if (a == "--output-reads") o.output_reads = true;
+            else if (a == "--gzip-reads") o.gzip = true;
+            else if (a == "--extra-trimming") o.trim_reads = true;
+            else if (a == "--ignore-monomorphic") o.ignore_monomorphic = true;
+            else if (a == "-H" || a == "--hybrid" || a == "--reassign-short" || a == "--bin-by-cov")
                 throw Error(FLORIA_E_UNSUPPORTED, "option " + a + " of floria is not supported by floria-hip");
             else throw Error(FLORIA_E_INVALID, "unknown option " + a);
         }
@@ -237,6 +241,7 @@ int main(int argc, char** argv) {
                     w.contig_len = fa == fasta.end() ? 0 : fa->second.size();
                     std::sort(w.all_frags.begin(), w.all_frags.end());                     // floria.rs:289-293
                     for (size_t k = 0; k < w.all_frags.size(); ++k) w.all_frags[k].counter_id = k;
+                    if (o.ignore_monomorphic) w.all_frags = remove_monomorphic_allele(std::move(w.all_frags), o.epsilon);     // floria.rs:315-317
                 });
                 done += take;
                 for (ContigWork& w : got) {

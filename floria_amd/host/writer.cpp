@@ -10,6 +10,8 @@
 // counted here on the host (set_to_seq_dict(.., false), utils_frags.rs:160-175).
 #include "floria_host.hpp"
 
+#include <zlib.h>
+
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -173,10 +175,122 @@ void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part
         if (n) check(floria_hip_haploset_stats(s.ctx(), one, 1, nullptr, off.data(), reads.data(), rng.data(), (uint32_t)n, st.data()));
     }
     append_ploidy_row(o, write_contig_files(part, ranges, dir, prefix, contig, snp_to_gn, snpless_frags, contig_len, hq, st));
+    if (o.output_reads) { write_reads(part, ranges, dir, !o.trim_reads, hq.hapqs, o.gzip); write_nosnp_reads(dir, snpless_frags, o.gzip); }
 }
 
-std::string write_contig_files(const ContigWork& w, const Options&) {
-    return write_contig_files(w.final_parts, w.final_ranges, w.out_dir, w.name, w.name, *w.snp_to_genome_pos, w.snpless, w.contig_len, w.hq, w.stats);
+// ---- --output-reads (file_writer.rs:86-150, 168-217, 370-560) ----------------------------------------------------------------------
+namespace {
+// bio::io::fastq::Writer::write(id, None, seq, qual) -> "@id\nseq\n+\nqual\n", into a plain or gzip file
+struct FastqOut {
+    std::string path; bool gz; FILE* f = nullptr; gzFile g = nullptr;
+    FastqOut(const std::string& p, bool gzip) : path(p), gz(gzip) {
+        if (gz) g = gzopen(p.c_str(), "wb"); else f = fopen(p.c_str(), "wb");
+        if (!g && !f) throw Error(FLORIA_E_INVALID, "Can't create file " + p);
+    }
+    void put(const void* d, size_t n) { if (gz) gzwrite(g, d, (unsigned)n); else fwrite(d, 1, n, f); }
+    void write(const std::string& id, const char* seq, size_t ns, const uint8_t* qual, size_t nq) {
+        put("@", 1); put(id.data(), id.size()); put("\n", 1); put(seq, ns); put("\n+\n", 3); put(qual, nq); put("\n", 1);
+    }
+    void close() { if (g) { gzclose(g); g = nullptr; } if (f) { fclose(f); f = nullptr; } }
+    ~FastqOut() { close(); }
+};
+const uint8_t BANG = 33;
+std::string revcomp(const std::string& s) {
+    std::string r(s.rbegin(), s.rend());
+    for (char& c : r) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';        // (seq_string holds ACGT only)
+    return r;
+}
+// write_paired_reads_no_trim (:168-217): mate 1 as stored, mate 2 reverse-complemented with its qualities as stored
+void write_paired_reads_no_trim(FastqOut& w1, FastqOut& w2, const Frag& frag) {
+    if (frag.seq_string[0].empty()) w1.write(frag.id + "/1", "N", 1, &BANG, 1);
+    else w1.write(frag.id + "/1", frag.seq_string[0].data(), frag.seq_string[0].size(), frag.qual_string[0].data(), frag.qual_string[0].size());
+    if (frag.seq_string[1].empty()) w2.write(frag.id + "/2", "N", 1, &BANG, 1);
+    else { const std::string rc = revcomp(frag.seq_string[1]); w2.write(frag.id + "/2", rc.data(), rc.size(), frag.qual_string[1].data(), frag.qual_string[1].size()); }
+}
+}  // namespace
+
+void write_nosnp_reads(const std::string& dir, const std::vector<const Frag*>& snpless_frags, bool gzip) {
+    const std::string gz = gzip ? ".gz" : "";
+    const std::string p0 = dir + "/long_reads/snpless.fastq" + gz, p1 = dir + "/short_reads/snpless_paired1.fastq" + gz, p2 = dir + "/short_reads/snpless_paired2.fastq" + gz;
+    bool paired_written = false, single_end_written = false;
+    {
+        FastqOut w(p0, gzip), w1(p1, gzip), w2(p2, gzip);
+        for (const Frag* frag : snpless_frags) {
+            if (frag->is_paired) { paired_written = true; write_paired_reads_no_trim(w1, w2, *frag); }
+            else {
+                single_end_written = true;
+                if (frag->seq_string[0].empty()) w.write(frag->id, "N", 1, &BANG, 1);
+                else w.write(frag->id, frag->seq_string[0].data(), frag->seq_string[0].size(), frag->qual_string[0].data(), frag->qual_string[0].size());
+            }
+        }
+    }
+    if (!paired_written) { remove(p1.c_str()); remove(p2.c_str()); }
+    if (!single_end_written) remove(p0.c_str());
+}
+
+void write_reads(const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& ranges, const std::string& dir,
+                 bool extend_read_clipping, const std::vector<uint8_t>& hapqs, bool gzip) {
+    constexpr size_t EXTENSION_BASES = 25;                                       // constants.rs:22
+    mkdir_p(dir + "/short_reads"); mkdir_p(dir + "/long_reads");
+    for (size_t i = 0; i < part.size(); ++i) {
+        if (part[i].empty() || ranges.empty()) continue;                         // (hapqs[i] < HAPQ_CUTOFF = 0 never holds)
+        (void)hapqs;
+        const SnpPosition left_snp_pos = ranges[i].first, right_snp_pos = ranges[i].second;
+        std::vector<const Frag*> vec_part(part[i]);
+        std::sort(vec_part.begin(), vec_part.end(), [](const Frag* a, const Frag* b) { return *a < *b; });
+        const std::string gz = gzip ? ".gz" : "";
+        const std::string p0 = dir + "/long_reads/" + std::to_string(i) + "_part.fastq" + gz, p1 = dir + "/short_reads/" + std::to_string(i) + "_part_paired1.fastq" + gz,
+                          p2 = dir + "/short_reads/" + std::to_string(i) + "_part_paired2.fastq" + gz;
+        bool paired_written = false, single_end_written = false;
+        {
+            FastqOut w(p0, gzip), w1(p1, gzip), w2(p2, gzip);
+            for (const Frag* fp : vec_part) {
+                const Frag& frag = *fp;
+                if (frag.seq_string[0].empty() && frag.seq_string[1].empty()) continue;            // no primary sequence
+                if (frag.first_position > right_snp_pos || frag.last_position < left_snp_pos) continue;   // fell off a merged haplogroup's range
+                size_t left_seq_pos = 0;
+                if (!(frag.first_position > left_snp_pos && extend_read_clipping)) {
+                    auto it = frag.snp_pos_to_seq_pos.lower_bound(left_snp_pos);                  // first SNP of the read at or after the left end
+                    if (it == frag.snp_pos_to_seq_pos.end()) throw Error(FLORIA_E_INVALID, "left snp position of partition for the read was not found.");
+                    left_seq_pos = it->second.second;
+                }
+                left_seq_pos = left_seq_pos > EXTENSION_BASES ? left_seq_pos - EXTENSION_BASES : 0;
+                size_t right_seq_pos; uint8_t right_read_pair;
+                if (frag.last_position < right_snp_pos && extend_read_clipping) {
+                    right_read_pair = frag.is_paired ? 1 : 0;
+                    right_seq_pos = frag.seq_string[right_read_pair].empty() ? 0 : frag.seq_string[right_read_pair].size() - 1;
+                } else {
+                    auto it = frag.snp_pos_to_seq_pos.upper_bound(right_snp_pos);                 // last SNP of the read at or before the right end
+                    if (it == frag.snp_pos_to_seq_pos.begin()) throw Error(FLORIA_E_INVALID, "right snp position of partition for the read was not found.");
+                    --it;
+                    right_seq_pos = it->second.second; right_read_pair = it->second.first;
+                }
+                const size_t rlen = frag.seq_string[right_read_pair].size();
+                if (rlen == 0) right_seq_pos = 0;
+                else if (rlen > EXTENSION_BASES + 1 && right_seq_pos < rlen - EXTENSION_BASES - 1) right_seq_pos += EXTENSION_BASES;
+                else right_seq_pos = rlen - 1;
+                if (frag.is_paired) { paired_written = true; write_paired_reads_no_trim(w1, w2, frag); }
+                else {
+                    single_end_written = true;
+                    if (left_seq_pos > right_seq_pos) continue;                                  // (a read id that is not unique, or supplementary pieces)
+                    const size_t n0 = frag.seq_string[0].size();
+                    if (right_seq_pos + 1 > n0) throw Error(FLORIA_E_INVALID, "read " + frag.id + ": sequence position past the end of the primary alignment's sequence (the reference panics here)");
+                    w.write(frag.id, frag.seq_string[0].data() + left_seq_pos, right_seq_pos + 1 - left_seq_pos, frag.qual_string[0].data() + left_seq_pos, right_seq_pos + 1 - left_seq_pos);
+                }
+            }
+        }
+        if (!paired_written) { remove(p1.c_str()); remove(p2.c_str()); }
+        if (!single_end_written) remove(p0.c_str());
+    }
+}
+
+std::string write_contig_files(const ContigWork& w, const Options& o) {
+    std::string row = write_contig_files(w.final_parts, w.final_ranges, w.out_dir, w.name, w.name, *w.snp_to_genome_pos, w.snpless, w.contig_len, w.hq, w.stats);
+    if (o.output_reads) {                                                                   // file_writer.rs:68-84
+        write_reads(w.final_parts, w.final_ranges, w.out_dir, !o.trim_reads, w.hq.hapqs, o.gzip);
+        write_nosnp_reads(w.out_dir, w.snpless, o.gzip);
+    }
+    return row;
 }
 void write_outputs(const ContigWork& w, const Options& o) { append_ploidy_row(o, write_contig_files(w, o)); }
 void append_contig_ploidy_row(const Options& o, const std::string& row) { append_ploidy_row(o, row); }

@@ -86,7 +86,7 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
     for i, q in enumerate(snp_pos):
         other[i] = [b for b in BASES if b != ref[q] and b != alt[i]][0]
     paired = lay["kind"] == "short"
-    out_reads, recs = [], []
+    out_reads, recs, qual_by_name = [], [], {}
     for r in range(p.n_reads):
         snps, als, quals = p.read(r)
         cell = {int(s) - 1: (int(a), int(q)) for s, a, q in zip(snps, als, quals)}          # SNP index -> (allele, qual)
@@ -95,7 +95,7 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
             segs.append((int(lay["start2"][r]), min(int(lay["end2"][r]), clen)))
         name = f"{contig.name}_r{r}"
         lost = set()
-        recs_r = []
+        recs_r, quals_r = [], []
         for k, (b, e) in enumerate(segs):
             e = max(e, b + 1)
             seq = ref[b:e].copy()
@@ -134,10 +134,12 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
             if paired:
                 flag = 1 | 2 | (64 | 32 if k == 0 else 128 | 16)
             recs_r.append((pos, bam_record(0, pos, name, flag, mapq, cigar, bytes(seq), qual), bytes(seq), cigar))
+            quals_r.append(bytes(qual))
         cells = [(i + 1, a, q) for i, (a, q) in sorted(cell.items()) if i not in lost]
         span = (min(b for b, _ in segs), min(max(e, b + 1) for b, e in segs)) if paired else (segs[0][0], max(segs[0][1], segs[0][0] + 1))
         out_reads.append((name, cells, span, recs_r, sum(max(e, b + 1) - b for b, e in segs)))
-    return dict(ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
+        qual_by_name[name] = quals_r
+    return dict(quals=qual_by_name, ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
 
 
 def nw_affine_batch(Q, R, match=1, mismatch=-1, gap_open=-2, gap_extend=-1):
@@ -256,7 +258,10 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, 
         first = np.array([r[0][0] for r in pile_reads], np.int64)
         last = np.array([r[0][-1] for r in pile_reads], np.int64)
         perm = np.lexsort((np.arange(len(pile_reads)), -last, first))
+        by_name = {nm: (recs_r, d["quals"][nm]) for nm, _, _, recs_r, _ in reads}
         expect[c.name] = dict(pileup=pile, names=[names[i] for i in perm], spans=[spans[i] for i in perm], seq_len=[slens[i] for i in perm],
+                              paired=c.layout["kind"] == "short",
+                              read_alignments={nm: [(pos, seq, cig, q) for (pos, _rec, seq, cig), q in zip(*by_name[nm])] for nm in by_name},
                               snp_pos0=np.array([q for q, _, _ in d["snps"]], np.uint64), contig_len=d["contig_len"],
                               snpless=[(nm, sp, sl) for nm, cells, sp, _, sl in reads if not cells],
                               alignments=sorted([(pos, seq, cig) for _, _, _, recs_r, _ in d["reads"] for pos, _, seq, cig in recs_r], key=lambda t: t[0]))

@@ -148,6 +148,11 @@ struct FxSet {
         }
         growth_left = cap_of(buckets) - items;
     }
+    void reserve(size_t additional) {                                                                 // RawTable::reserve -> reserve_rehash
+        if (additional <= growth_left) return;
+        const size_t new_items = items + additional, full = cap_of(buckets);
+        if (buckets != 0 && new_items <= full / 2) rehash_in_place(); else resize(std::max(new_items, full + 1));
+    }
     bool insert(uint64_t key) {
         if (growth_left == 0) {                                                                       // reserve(1)
             const size_t new_items = items + 1, full = cap_of(buckets);
@@ -350,16 +355,21 @@ inline SD distance_read_haplo_epsilon_empty(const Pile& P, uint32_t r, const Hap
 inline double sd_same(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) == 1 ? d.same_f : qm_to_f64(d.same, 0, eps); }
 inline double sd_diff(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) == 1 ? d.diff_f : qm_to_f64(d.diff, d.m, eps); }
 
-// Frag.positions: FxHashSet<SnpPosition>, filled in ascending order by the CIGAR walk (file_reader.rs:661-736); its iteration order
-// is the table's bucket order.  -> for every read the permutation of its cells in that order.
+// Frag.positions (file_reader.rs:729-733) = seq_dict.keys().collect::<FxHashSet<_>>(): seq_dict is an FxHashMap filled in ascending
+// order by the CIGAR walk (:661-727, growing as it goes); `collect` reserves room for all keys at once and inserts them in the map's
+// iteration order; iterating the set then walks ITS buckets.  -> for every read the permutation of its cells in that order.
+// (Mates and supplementary alignments merged by combine_frags extend the first alignment's set by the second's, :540-542; the pileup
+// does not say which cell came from which alignment, so such reads are emulated as one alignment.)
 inline std::vector<uint32_t> build_cell_order(const floria_pileup* p) {
     std::vector<uint32_t> ord(p->read_off[p->n_reads]);
     for (uint32_t r = 0; r < p->n_reads; ++r) {
         const uint32_t b = p->read_off[r], e = p->read_off[r + 1];
-        FxSet fs;
-        for (uint32_t c = b; c < e; ++c) fs.insert(p->snp[c]);
+        FxSet seq_dict, positions;
+        for (uint32_t c = b; c < e; ++c) seq_dict.insert(p->snp[c]);
+        positions.reserve(e - b);
+        seq_dict.for_each([&](uint64_t pos) { positions.insert(pos); });
         uint32_t k = b;
-        fs.for_each([&](uint64_t pos) { ord[k++] = (uint32_t)(std::lower_bound(p->snp + b, p->snp + e, (uint32_t)pos) - p->snp); });
+        positions.for_each([&](uint64_t pos) { ord[k++] = (uint32_t)(std::lower_bound(p->snp + b, p->snp + e, (uint32_t)pos) - p->snp); });
     }
     return ord;
 }

@@ -321,3 +321,107 @@ def expected_files(pileup, names, parts, ranges, stats, hapqs, rel_err, avg_err,
            f"{rust_fixed(c15.sum() / S, 3)}\t{rust_fixed(c30.sum() / S, 3)}\t{rust_fixed(c45.sum() / S, 3)}\t{rust_fixed(avg_err, 4)}\n")
     return {f"{contig}.vartigs": "".join(vart), "vartig_info.txt": "".join(info), f"{contig}.haplosets": "".join(hset),
             "reads_without_snps.tsv": "READ_NAME\tREAD_LENGTH_IN_BASES\n" + "".join(f"{nm}\t{sl}\n" for nm, sl in snpless_rows), "ploidy_row": row}
+
+
+# ---- --output-reads (file_writer.rs:86-150, 168-217, 370-560), restated for the synthetic data sets of floria_amd/synth_bam.py ----------
+def _fastq(name, seq, qual):
+    return b"@" + name.encode() + b"\n" + seq + b"\n+\n" + qual + b"\n"
+
+
+def _acgt(seq):
+    return bytes(c if c in b"ACGT" else (c - 32 if c in b"acgt" else 65) for c in seq)          # DnaString::from_acgt_bytes
+
+
+def _rc(seq):
+    return bytes({65: 84, 67: 71, 71: 67, 84: 65}[c] for c in reversed(seq))
+
+
+def read_records(names, pileup, alignments, snp_pos0, paired):
+    """per read (pileup order): dict(name, paired, first, last, seq[2], qual[2], pos2seq {snp: (mate, offset in that mate's SEQ)}) —
+    what frag_from_record + combine_frags leave in a Frag (file_reader.rs:505-560, 661-736)"""
+    snp_pos0 = np.asarray(snp_pos0, np.int64)
+    out = []
+    for i, nm in enumerate(names):
+        s, _, _ = pileup.read(i)
+        called = set(int(x) for x in s)
+        seqs, quals, pos2seq = [b"", b""], [b"", b""], {}
+        for k, (pos, seq, cigar, qual) in enumerate(alignments[nm]):
+            seqs[k] = _acgt(seq); quals[k] = bytes(min(255, q + 33) for q in qual)
+            q, r = 0, pos
+            for op, ln in cigar:
+                if op == "M":
+                    lo, hi = np.searchsorted(snp_pos0, r, "left"), np.searchsorted(snp_pos0, r + ln, "left")
+                    for x in range(lo, hi):
+                        if x + 1 in called:
+                            pos2seq[x + 1] = (k, q + int(snp_pos0[x]) - r)
+                if op in "MIS":
+                    q += ln
+                if op in "MDN":
+                    r += ln
+        out.append(dict(name=nm, paired=paired, first=int(pileup.first[i]), last=int(pileup.last[i]), seq=seqs, qual=quals, pos2seq=pos2seq))
+    return out
+
+
+def _paired_no_trim(rec):
+    a = _fastq(rec["name"] + "/1", rec["seq"][0], rec["qual"][0]) if rec["seq"][0] else _fastq(rec["name"] + "/1", b"N", b"!")
+    b = _fastq(rec["name"] + "/2", _rc(rec["seq"][1]), rec["qual"][1]) if rec["seq"][1] else _fastq(rec["name"] + "/2", b"N", b"!")
+    return a, b
+
+
+def expected_read_files(parts, ranges, recs, snpless_recs, extend_read_clipping=True, extension=25):
+    """-> {relative path: bytes} of long_reads/ and short_reads/ (uncompressed content)"""
+    files = {}
+    for i, (reads, (lo, hi)) in enumerate(zip(parts, ranges)):
+        if len(reads) == 0:
+            continue
+        single, p1, p2 = [], [], []
+        for r in sorted(int(x) for x in reads):
+            rec = recs[r]
+            if not rec["seq"][0] and not rec["seq"][1]:
+                continue
+            if rec["first"] > hi or rec["last"] < lo:
+                continue
+            if rec["first"] > lo and extend_read_clipping:
+                left = 0
+            else:
+                t = lo
+                while t not in rec["pos2seq"]:
+                    t += 1
+                left = rec["pos2seq"][t][1]
+            left = left - extension if left > extension else 0
+            if rec["last"] < hi and extend_read_clipping:
+                rp = 1 if rec["paired"] else 0
+                right = len(rec["seq"][rp]) - 1 if rec["seq"][rp] else 0
+            else:
+                t = hi
+                while t not in rec["pos2seq"]:
+                    t -= 1
+                rp, right = rec["pos2seq"][t]
+            n = len(rec["seq"][rp])
+            if n == 0:
+                right = 0
+            elif n > extension + 1 and right < n - extension - 1:
+                right += extension
+            else:
+                right = n - 1
+            if rec["paired"]:
+                a, b = _paired_no_trim(rec); p1.append(a); p2.append(b)
+            else:
+                if left > right:
+                    single.append(None); continue
+                single.append(_fastq(rec["name"], rec["seq"][0][left:right + 1], rec["qual"][0][left:right + 1]))
+        if p1:
+            files[f"short_reads/{i}_part_paired1.fastq"] = b"".join(p1); files[f"short_reads/{i}_part_paired2.fastq"] = b"".join(p2)
+        if single:
+            files[f"long_reads/{i}_part.fastq"] = b"".join(x for x in single if x is not None)
+    single, p1, p2 = [], [], []
+    for rec in snpless_recs:
+        if rec["paired"]:
+            a, b = _paired_no_trim(rec); p1.append(a); p2.append(b)
+        else:
+            single.append(_fastq(rec["name"], rec["seq"][0], rec["qual"][0]) if rec["seq"][0] else _fastq(rec["name"], b"N", b"!"))
+    if p1:
+        files["short_reads/snpless_paired1.fastq"] = b"".join(p1); files["short_reads/snpless_paired2.fastq"] = b"".join(p2)
+    if single:
+        files["long_reads/snpless.fastq"] = b"".join(single)
+    return files

@@ -10,6 +10,7 @@ correct ingest must produce is known exactly.  Every stage of the driver is chec
   files (C++ writers)       == oracle/stitch.py: expected_files, byte for byte; headers parse with the regexes of the
                                reference's scripts/haplotag_bam.py:7-10
 """
+import gzip
 import os
 import re
 import subprocess
@@ -100,6 +101,30 @@ def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra
         for fn in (f"{c.name}.vartigs", f"{c.name}.haplosets", "vartig_info.txt", "reads_without_snps.tsv"):
             assert open(os.path.join(cdir, fn)).read() == want[fn], fn
         assert ploidy_rows[1 + k] == want["ploidy_row"]
+        # ---- --output-reads: fastq of every haploset (file_writer.rs:370-560) against the restatement in oracle/stitch.py ---------------
+        if "--output-reads" in extra:
+            recs = stitch.read_records(ex["names"], pile, ex["read_alignments"], ex["snp_pos0"], ex["paired"])
+            by_name = {r["name"]: r for r in recs}
+            def rec_of(nm):
+                if nm in by_name:
+                    return by_name[nm]
+                al = ex["read_alignments"][nm]
+                seqs = [stitch._acgt(a[1]) for a in al] + [b""] * (2 - len(al)); quals = [bytes(q + 33 for q in a[3]) for a in al] + [b""] * (2 - len(al))
+                return dict(name=nm, paired=ex["paired"], first=0, last=0, seq=seqs, qual=quals, pos2seq={})
+            want_reads = stitch.expected_read_files(parts, ranges, recs, [rec_of(nm) for nm, _ in gaps], extend_read_clipping="--extra-trimming" not in extra)
+            got_reads = {}
+            for sub in ("long_reads", "short_reads"):
+                assert os.path.isdir(os.path.join(cdir, sub))
+                for fn in os.listdir(os.path.join(cdir, sub)):
+                    raw = open(os.path.join(cdir, sub, fn), "rb").read()
+                    if "--gzip-reads" in extra:
+                        assert fn.endswith(".gz")
+                        raw = gzip.decompress(raw); fn = fn[:-3]
+                    got_reads[f"{sub}/{fn}"] = raw
+            assert sorted(got_reads) == sorted(want_reads)
+            for fn in want_reads:
+                assert got_reads[fn] == want_reads[fn], fn
+            assert sum(len(v) for v in want_reads.values()) > 0
         # ---- the reference's downstream scripts can read the headers (scripts/haplotag_bam.py:7-10) ------------------------------------
         heads = [ln for ln in open(os.path.join(cdir, f"{c.name}.haplosets")) if ln.startswith(">")]
         assert len(heads) == sum(1 for p in parts if len(p)) > 0
@@ -140,6 +165,20 @@ def test_paired_short_reads(floria_hip, oracle_mod, tmp_path):
     # 2 x 150 bp pairs: mates merge into one Frag (combine_frags, file_reader.rs:505-560)
     c = synth.make_config_contig(3, 2, 0.3, keep_layout=True)
     run_and_check(floria_hip, oracle_mod, tmp_path, [c], 500)
+
+
+@pytest.mark.parametrize("extra", [("--output-reads",), ("--output-reads", "--gzip-reads", "--extra-trimming")])
+def test_output_reads_long(floria_hip, oracle_mod, tmp_path, extra):
+    # the reads of every haploset as fastq, clipped to the haploset's SNP range +- 25 bases (reads reaching past an end keep that end
+    # unless --extra-trimming); a tenth of the reads carry soft clips and indels, so sequence offsets differ from reference offsets
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    run_and_check(floria_hip, oracle_mod, tmp_path, [c], 10000, extra=extra)
+
+
+def test_output_reads_paired(floria_hip, oracle_mod, tmp_path):
+    # pairs are written whole: mate 1 as aligned, mate 2 reverse-complemented with its qualities as stored (file_writer.rs:168-217)
+    c = synth.make_config_contig(3, 2, 0.3, keep_layout=True)
+    run_and_check(floria_hip, oracle_mod, tmp_path, [c], 500, extra=("--output-reads",))
 
 
 def test_auto_estimated_parameters(floria_hip, tmp_path):

@@ -247,3 +247,34 @@ def test_realign_shortcut_is_exact_under_sequencing_errors(floria_hip, tmp_path,
         assert g["cells"] == list(zip(s.tolist(), a.tolist(), q.tolist())), f"read {i}"
         n_changed += sum(1 for x, y in zip(g["cells"], g0["cells"]) if x != y)
     assert n_changed > 0 if sub_rate > 0.1 else True                              # noise flips some calls, the same ones in both
+
+
+def test_ignore_monomorphic(floria_hip, tmp_path):
+    # --ignore-monomorphic (utils_frags.rs:713-772): SNPs whose second allele carries less than epsilon of the first's phred weight are
+    # dropped from every read before phasing; reads are re-sorted (Frag::cmp) and renumbered, reads left without SNPs dropped.
+    import collections
+    eps = 0.03125
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    prefix = str(tmp_path / "d")
+    synth_bam.write_dataset(prefix, [c], seed=5, realign=False)
+    plain, _ = ingest(floria_hip, prefix, tmp_path, extra=("--no-realign", "-e", str(eps)))
+    filt, _ = ingest(floria_hip, prefix, tmp_path, extra=("--no-realign", "-e", str(eps), "--ignore-monomorphic"))
+    plain, filt = plain[c.name]["reads"], filt[c.name]["reads"]
+    w = collections.defaultdict(lambda: collections.defaultdict(float))
+    for g in plain:
+        for snp, al, q in g["cells"]:
+            w[snp][al] += float(np.float32(1.0) - np.float32(10.0) ** (np.float32(q) / np.float32(-10.0)))
+    mono = set()
+    for snp, m in w.items():
+        v = sorted(m.values(), reverse=True)
+        if len(v) == 1 or v[0] * eps > v[1]:
+            mono.add(snp)
+    assert 0 < len(mono) < len(w)
+    want = []
+    for k, g in enumerate(plain):
+        cells = [x for x in g["cells"] if x[0] not in mono]
+        if cells:
+            want.append((cells[0][0], -cells[-1][0], k, g["name"], cells))
+    want.sort()
+    assert [(x[3], x[4]) for x in want] == [(g["name"], g["cells"]) for g in filt]
+    assert [g["first"] for g in filt] == [x[4][0][0] for x in want] and [g["last"] for g in filt] == [x[4][-1][0] for x in want]
