@@ -2,7 +2,7 @@
 for v in "$@"; do
   make -C floria_amd/csrc -B EXTRA="$v -DFLORIA_PROF" libfloria_hip.so > /dev/null 2>&1 || { echo "BUILD FAILED: $v"; continue; }
   echo "== $v"
-  python bench.py --steps 1 --warmup 1 --cpu-sample 0 2>&1 | grep -E "^\[prof\]" | tail -1 | python -c "
+  python bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --pipeline 0 --resident-only 2>&1 | grep -E "^\[prof\]" | tail -1 | python -c "
 import sys,re
 import collections
 d=collections.defaultdict(float)
