@@ -37,6 +37,7 @@ struct BeamArgs {
     uint32_t* queue_head;
     const uint8_t* blk_done;       // stop rule already fired for this block (graph_processing.rs:198-251)
     uint64_t* state_pool;          // [slots][nbuf][span_max][ploidy][A]
+    uint64_t  state_stride;        // bytes per slot (beam_slab_kernel: the u64 slabs followed by their code bytes)
     uint32_t* hist_pool;           // [slots][hist_stride] traceback records
     uint64_t  hist_stride;
     const double* binom_tab;       // host libm table of stable_binom_cdf_p_rev(n,k), tri-indexed, n <= binom_nmax

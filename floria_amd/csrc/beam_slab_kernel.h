@@ -16,7 +16,10 @@
 // Everything observable is unchanged: per-pair (same, diff), p-values, pruning, child scores, the 128-bit
 // linear state hash for the duplicate test, the std::BinaryHeap order — bit-identical to beam_kernel.h.
 // Slab layout: [pos][allele] u64 (16 B per SNP for biallelic data): consecutive cells of a read are consecutive
-// 16-B pieces, so four cells share a 64-B line.
+// 16-B pieces, so four cells share a 64-B line.  Next to the sums every slab keeps one CODE byte per position — bit a set <=> allele a
+// attains the position's maximal sum, 0 <=> nothing observed — which is all the distance needs (`same` <=> bit of the read's allele,
+// empty <=> 0): phase A reads 1 byte per (slab, cell) instead of 16, the sums are only touched by the read-modify-write that refreshes the
+// code, by copies and by the window-exit hash terms.  (Pileups with q = 0 cells keep classifying from the sums: their presence bit is part of it.)
 #pragma once
 #include "wave_util.h"
 
@@ -60,11 +63,16 @@ __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
 // at least 0.5/d away from every integer, while the float error (1-ulp reciprocal, one product) is < 4e-7 * x/d < 0.42/d
 __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return (uint32_t)(((float)x + 0.5f) * rcp_d); }
 constexpr int SLAB_NS_MAX = 512;
+constexpr int SLAB_DUMMY_WORDS = 64 * FLORIA_MAX_ALLELES * 2 + 16;      // u32 words of per-slot scratch behind the traceback rows (host reserves them)
 constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
 #ifndef FLORIA_SLAB_U
 #define FLORIA_SLAB_U 6
 #endif
-constexpr int SLAB_U = FLORIA_SLAB_U;      // ploidy * (ploidy*beam) slabs per resident job
+constexpr int SLAB_U = FLORIA_SLAB_U;      // 16-B slab loads in flight per lane (q = 0 pileups: classification from the sums)
+#ifndef FLORIA_SLAB_CU
+#define FLORIA_SLAB_CU 8
+#endif
+constexpr int SLAB_CU = FLORIA_SLAB_CU;    // code-byte loads in flight per lane (<= 8: a batch's weights are summed in 32 bits, 8 * 2^28)
 
 struct SlabLds {
     uint32_t off_coff, off_caw, off_crp1, off_crp2;
@@ -141,11 +149,19 @@ void beam_slab_kernel(BeamArgs g) {
 
     const uint32_t pos_bytes = A * 8;
     const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
-    char* pool = (char*)(g.state_pool + (uint64_t)blockIdx.x * ((uint64_t)LM * g.span_max * p * A));
+    char* pool = (char*)g.state_pool + (uint64_t)blockIdx.x * g.state_stride;      // [NS slabs][span_max][A] u64, then [NS][span_pad] code bytes
+#ifdef FLORIA_SLAB_NO_CODES
+    constexpr bool CODES = false;         // (A/B switch: classify from the sums everywhere)
+#else
+    constexpr bool CODES = !Q0;
+#endif
+    const uint32_t span_pad = (g.span_max + 15u) & ~15u;
+    uint8_t* const codes = (uint8_t*)(pool + (uint64_t)NS * slab_bytes);
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
     uint64_t* r_t1 = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS));      // tail of the slot's traceback region (host reserves it)
     uint64_t* r_t2 = r_t1 + NS;
-    uint64_t* dummy = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS - 128));      // 64 scratch words for branch-free tails
+    uint64_t* dummy = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS - SLAB_DUMMY_WORDS));      // scratch for branch-free tails: 64 lanes x A sums, then 64 code bytes
+    uint8_t* const dummy_code = (uint8_t*)(dummy + 64 * A);
     const uint64_t lane_lt = (1ull << lane) - 1;
 
     const uint32_t S = 64 / p;
@@ -160,7 +176,7 @@ void beam_slab_kernel(BeamArgs g) {
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
-    unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0;
+    unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0, c_copy_pos = 0, c_ncopy = 0, c_add_items = 0, c_zero_items = 0, c_nlead = 0, c_trunc = 0;
 #endif
 
     for (;;) {
@@ -367,7 +383,31 @@ void beam_slab_kernel(BeamArgs g) {
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
                     // SLAB_U independent 16-B loads in flight per lane; the loop is wave-uniform (invalid slots and idle lanes read
                     // cell 0 of a slab with weight 0: no branches), and the next read is staged behind the first batch of loads
-                    if (act) {
+                    if (act && CODES) {
+                        // one code byte per (slab, cell): bit `allele` <=> same, 0 <=> empty position
+                        const uint8_t* const cbase = codes + (uint32_t)live_id[li] * span_pad;
+                        for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_CU * Gs) {
+                            uint32_t offs[SLAB_CU], aws[SLAB_CU], cd[SLAB_CU];
+#pragma unroll
+                            for (int u = 0; u < SLAB_CU; ++u) {
+                                const uint32_t c = c0 + u * Gs; const bool v = c < nin; const uint32_t cx = v ? c : 0;
+                                offs[u] = c_snp[cx] - pos0; aws[u] = v ? c_aw[cx] : 0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < SLAB_CU; ++u) cd[u] = cbase[offs[u]];
+                            ps = 0; pd = 0;
+#pragma unroll
+                            for (int u = 0; u < SLAB_CU; ++u) {
+                                const uint32_t w = aws[u] & 0x0fffffffu;
+                                const bool same = ((cd[u] >> (aws[u] >> 28)) & 1u) != 0;
+                                ps += same ? w : 0u;
+                                pd += (cd[u] != 0 && !same) ? w : 0u;
+                                m += (c0 + u * Gs < nin && cd[u] == 0) ? 1u : 0u;
+                            }
+                            qs += ps; qd += pd;
+                        }
+                    }
+                    if (act && !CODES) {
                         for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_U * Gs) {
                             uint32_t offs[SLAB_U], aws[SLAB_U];
 #pragma unroll
@@ -592,6 +632,10 @@ void beam_slab_kernel(BeamArgs g) {
             }
             BEAM_TICK(3);
             // copies of the written window [first_rel, hi_rel] for the new versions that could not go in place
+#ifdef FLORIA_PROF
+            c_ncopy += ncopy; if (ncopy && hi_rel >= (int32_t)first_rel) c_copy_pos += (unsigned long long)ncopy * (uint32_t)(hi_rel - (int32_t)first_rel + 1);
+            c_trunc += trunc ? 1 : 0;
+#endif
             if (ncopy && hi_rel >= (int32_t)first_rel) {
                 const uint32_t cnt2 = ((uint32_t)(hi_rel - (int32_t)first_rel + 1) * A) >> 1;
                 uint64_t cm2 = cmask;
@@ -608,6 +652,12 @@ void beam_slab_kernel(BeamArgs g) {
                         d[x] = v0; d[x + 64] = v1; d[x + 128] = v2; d[x + 192] = v3;
                     }
                     for (; x < cnt2; x += 64) d[x] = s[x];
+                    if (CODES) {
+                        const uint8_t* sc = codes + (su * span_pad + first_rel);
+                        uint8_t* dc = codes + (du * span_pad + first_rel);
+                        const uint32_t cb = (uint32_t)(hi_rel - (int32_t)first_rel + 1);
+                        for (uint32_t y = lane; y < cb; y += 64) dc[y] = sc[y];
+                    }
                 }
             }
             __syncthreads();
@@ -624,10 +674,21 @@ void beam_slab_kernel(BeamArgs g) {
             if (new_hi > hi_rel) {
                 const uint32_t cntz = (uint32_t)(new_hi - hi_rel) * A;
                 const uint32_t items = nl * cntz;
+#ifdef FLORIA_PROF
+                c_zero_items += items / A;
+#endif
                 const float rcp_cntz = __builtin_amdgcn_rcpf((float)cntz);
                 for (uint32_t x = lane; x < items; x += 64) {
                     const uint32_t e = items < (1u << 20) ? div_small(x, rcp_cntz) : x / cntz, o = x - e * cntz;
                     *(uint64_t*)(pool + ((uint32_t)live_id[e] * slab_bytes + (uint32_t)(hi_rel + 1) * pos_bytes + o * 8)) = 0;
+                }
+                if (CODES) {
+                    const uint32_t cz = (uint32_t)(new_hi - hi_rel), items_c = nl * cz;
+                    const float rcp_cz = __builtin_amdgcn_rcpf((float)cz);
+                    for (uint32_t x = lane; x < items_c; x += 64) {
+                        const uint32_t e = items_c < (1u << 20) ? div_small(x, rcp_cz) : x / cz, o = x - e * cz;
+                        codes[(uint32_t)live_id[e] * span_pad + (uint32_t)(hi_rel + 1) + o] = 0;
+                    }
                 }
             }
             __syncthreads();
@@ -636,6 +697,9 @@ void beam_slab_kernel(BeamArgs g) {
             {
                 const uint64_t lmask = __ballot(lead);
                 const uint32_t nlead = (uint32_t)__popcll(lmask);
+#ifdef FLORIA_PROF
+                c_nlead += nlead; c_add_items += (unsigned long long)nlead * L;
+#endif
                 // leaders' target slabs, compacted into freelist[] (reused as scratch)
                 if (lead) freelist[__popcll(lmask & lane_lt)] = newid[u_old];
                 for (uint32_t t = 0; t < ntiles; ++t) {
@@ -649,9 +713,54 @@ void beam_slab_kernel(BeamArgs g) {
                         w = aw & 0x0fffffffu;
                         return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + (c_snp[c] - pos0) * pos_bytes + (aw >> 28) * 8));
                     };
-                    // 4 read-modify-writes in flight per lane, branch-free: the tail slots go to the lane's dummy word in the slot's
+                    // read-modify-writes in flight per lane, branch-free: the tail slots go to the lane's dummy words in the slot's
                     // scratch.  (A load left unconsumed on some path makes hipcc wait vmcnt(0) at the top of the next step, i.e.
                     // for the acknowledgement of these stores, before phase A can issue its loads.)
+                    if (CODES) {
+                        // the position's A sums come in together (one 16-B piece for biallelic data): add the read's weight, store the changed
+                        // sum, and refresh the position's code byte from the new sums
+                        constexpr int AU = 4;
+                        for (uint32_t x0 = 0; x0 < items; x0 += 64 * AU) {
+                            uint32_t w[AU], al[AU]; uint64_t* base[AU]; uint8_t* cptr[AU];
+#pragma unroll
+                            for (int u = 0; u < AU; ++u) {
+                                const uint32_t xx = x0 + lane + 64 * u;
+                                const bool ok = xx < items;
+                                const uint32_t xs = ok ? xx : 0;
+                                const uint32_t e = div_small(xs, rcp_tl), c = xs - e * tl;
+                                const uint32_t aw = c_aw[c], pr = c_snp[c] - pos0, sl = (uint32_t)freelist[e];
+                                w[u] = aw & 0x0fffffffu; al[u] = aw >> 28;
+                                base[u] = ok ? (uint64_t*)(pool + (sl * slab_bytes + pr * pos_bytes)) : dummy + lane * A;
+                                cptr[u] = ok ? codes + (sl * span_pad + pr) : dummy_code + lane;
+                            }
+                            ulonglong2 vv[AU][A / 2];
+#pragma unroll
+                            for (int u = 0; u < AU; ++u)
+#pragma unroll
+                                for (int x = 0; x < A / 2; ++x) vv[u][x] = ((const ulonglong2*)base[u])[x];
+#pragma unroll
+                            for (int u = 0; u < AU; ++u) {
+                                uint64_t v[A];
+#pragma unroll
+                                for (int x = 0; x < A; x += 2) { v[x] = vv[u][x / 2].x; v[x + 1] = vv[u][x / 2].y; }
+                                uint64_t nv = 0;
+#pragma unroll
+                                for (int x = 0; x < A; ++x) { if (x == (int)al[u]) { v[x] += w[u]; nv = v[x]; } }
+                                base[u][al[u]] = nv;
+                                uint32_t code;
+                                if (A == 2) code = (v[0] | v[1]) ? ((v[0] >= v[1] ? 1u : 0u) | (v[1] >= v[0] ? 2u : 0u)) : 0u;
+                                else {
+                                    uint64_t mx = 0;
+#pragma unroll
+                                    for (int x = 0; x < A; ++x) mx = v[x] > mx ? v[x] : mx;
+                                    code = 0;
+#pragma unroll
+                                    for (int x = 0; x < A; ++x) code |= (mx != 0 && v[x] == mx) ? (1u << x) : 0u;
+                                }
+                                *cptr[u] = (uint8_t)code;
+                            }
+                        }
+                    } else
                     for (uint32_t x0 = 0; x0 < items; x0 += 256) {
                         uint32_t w[4]; uint64_t* ptr[4]; uint64_t v[4];
 #pragma unroll
@@ -706,6 +815,7 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[24], wall_clock64() - t_wall0); atomicAdd(&g.prof[25], clock64() - t_core0); atomicAdd(&g.prof[26], 1ull);
                      atomicAdd(&g.prof[26 + g.ploidy], wall_clock64() - t_wall0);
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
+                     atomicAdd(&g.prof[32], c_copy_pos); atomicAdd(&g.prof[33], c_ncopy); atomicAdd(&g.prof[34], c_add_items); atomicAdd(&g.prof[35], c_zero_items); atomicAdd(&g.prof[36], c_nlead); atomicAdd(&g.prof[37], c_trunc);
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     n_fallback = wave_sum_u32(n_fallback);

@@ -373,7 +373,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.shortcut = p == 1 && !K.no_p1_shortcut;
         q.state_bytes = (uint64_t)LM * span_max * p * A * 8;
         // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
-        q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + 128 + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + 64 dummy u64 words (beam_slab_kernel's branch-free tails)
+        q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + fl::SLAB_DUMMY_WORDS + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + the dummy words of beam_slab_kernel's branch-free tails
         q.SL = fl::slab_lds_layout(LM, p, any_q0);
         q.WL = fl::wide_lds_layout(LM, p, any_q0);
         q.LY = fl::beam_lds_layout(LM);
@@ -382,7 +382,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         const uint32_t waves_per_simd = (q.beam_spec && p <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES;
         q.beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * waves_per_simd, by_lds);
         q.beam_slots = std::min(q.beam_slots, nj_max);
-        const bool fits32 = q.state_bytes < 0xf0000000ull;
+        const uint64_t slab_code_bytes = (uint64_t)LM * p * ((span_max + 15u) & ~15u);              // beam_slab_kernel: one code byte per (slab, position)
+        const bool fits32 = q.state_bytes + slab_code_bytes < 0xf0000000ull;
         // shared-slab kernels: register heap for ploidy*beam <= 63 (the CLI defaults give <= 50), LDS heap beyond; the generic kernel
         // (per-state slabs, any size) remains for beams whose slab tables fit neither
         const bool wide_ok = fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && q.WL.total <= 150 * 1024;
@@ -394,6 +395,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             case 3: q.wide = wide_ok; q.slab = q.slab && !wide_ok; break;      // wide (where it applies)
             default: break;
         }
+        if (q.slab) q.state_bytes += slab_code_bytes;
         if (!q.shortcut) {
             if (q.LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
             if (q.wide) q.beam_slots = std::min<uint32_t>(q.beam_slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.WL.total + 512))));
@@ -492,7 +494,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     fl::BeamArgs a{};
                     a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
                     a.queue_head = gqueue; a.blk_done = d_done;
-                    a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane);
+                    a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane); a.state_stride = q.state_bytes;
                     a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
                     a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
                     a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
@@ -1239,7 +1241,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
               // zero-initialised, contiguous (ONE memset): partition output, mec / num_alleles / iters, stop-rule state, queue counters, diagnostics
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
               s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4),
-              s_q = seg(8ull * floria_hip_ctx::MAX_LANES * FLORIA_MAX_PLOIDY + 16), s_diag = seg(16 + 8 * 32), s_steps = seg(16);
+              s_q = seg(8ull * floria_hip_ctx::MAX_LANES * FLORIA_MAX_PLOIDY + 16), s_diag = seg(16 + 8 * 48), s_steps = seg(16);
     const size_t zero_bytes = cursor - s_out.off;
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
     char* M = ctx->misc.as<char>();
@@ -1324,7 +1326,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     TR.mark("results on the host");
     if (diag[1]) { return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
 #ifdef FLORIA_PROF
-    { unsigned long long prof[32]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
+    { unsigned long long prof[48]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 48; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
 #endif
     memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
     // the pruning decisions of the (block, ploidy) jobs the reference runs, i.e. ploidy <= ploidies_tried (a speculative stage may have run more)
