@@ -40,7 +40,7 @@ def _reg2bin(beg, end):
     return 0
 
 
-_CIG = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5}
+_CIG = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
 _NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
 _NT16_LUT = np.full(256, 15, np.uint8)
 for _c, _i in _NT16.items():
@@ -49,7 +49,7 @@ for _c, _i in _NT16.items():
 
 def bam_record(tid, pos, name, flag, mapq, cigar, seq, qual, next_pos=-1, tlen=0):
     """cigar: list of (op char, len); seq: bytes of ACGTN; qual: uint8 array."""
-    ref_len = sum(n for op, n in cigar if op in "MDN")
+    ref_len = sum(n for op, n in cigar if op in "MDN=X")
     nm = name.encode() + b"\0"
     cig = b"".join(struct.pack("<I", (n << 4) | _CIG[op]) for op, n in cigar)
     codes = _NT16_LUT[np.frombuffer(seq, np.uint8)]

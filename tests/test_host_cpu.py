@@ -278,3 +278,95 @@ def test_ignore_monomorphic(floria_hip, tmp_path):
     want.sort()
     assert [(x[3], x[4]) for x in want] == [(g["name"], g["cells"]) for g in filt]
     assert [g["first"] for g in filt] == [x[4][0][0] for x in want] and [g["last"] for g in filt] == [x[4][-1][0] for x in want]
+
+
+def test_hand_built_alignments_flags_cigar_ops_and_supplementary_merging(floria_hip, tmp_path):
+    """Records the generator never writes, expectations derived by hand from file_reader.rs: alignment_passed_check (:184-235: paired
+    or low-MAPQ supplementary, MAPQ, error flags, secondary), the CIGAR walk over = X N D I S H (:661-727), allele index of a multi-allelic
+    record, combine_frags' supplementary branch (:566-655: merge when every gap between the pieces is <= --supp-aln-dist-cutoff, else
+    the primary alone; only supplementary pieces -> dropped; last_pos_base = min), -X."""
+    rng = np.random.default_rng(5)
+    clen = 60000
+    ref = synth_bam.BASES[rng.integers(0, 4, size=clen)].copy()
+    snp_pos = 1000 + 500 * np.arange(100)                                   # SNP i+1 at 0-based position snp_pos[i]
+    nxt = {65: 67, 67: 71, 71: 84, 84: 65}                                    # A->C->G->T->A
+    alt = np.array([nxt[int(ref[q])] for q in snp_pos], np.uint8)
+    alt2 = np.array([nxt[int(a)] for a in alt], np.uint8)                     # second ALT of the multi-allelic record (SNP 21)
+    third = np.array([nxt[int(a)] for a in alt2], np.uint8)                   # a base that is no allele of a biallelic record
+    prefix = str(tmp_path / "h")
+    with open(prefix + ".fa", "w") as f:
+        f.write(">c\n" + bytes(ref).decode() + "\n")
+    with open(prefix + ".vcf", "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=c,length=%d>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts\n" % clen)
+        for i, q in enumerate(snp_pos):
+            a = chr(alt[i]) + ("," + chr(alt2[i]) if i == 20 else "")
+            f.write(f"c\t{q + 1}\t.\t{chr(ref[q])}\t{a}\t50\tPASS\t.\tGT\t0/1\n")
+
+    def seq_of(beg, end, calls):                                              # reference bases with `calls` {snp index: base}
+        s = ref[beg:end].copy()
+        for i, b in calls.items():
+            s[snp_pos[i] - beg] = b
+        return s
+    recs = []
+
+    def add(name, pos, flag, mapq, cigar, seq):
+        recs.append((pos, synth_bam.bam_record(0, pos, name, flag, mapq, cigar, bytes(seq), np.full(len(seq), 30, np.uint8))))
+    # A plain: SNPs 1..6 (positions 1000..3500), ALT everywhere
+    add("A_plain", 900, 0, 60, [("M", 3000)], seq_of(900, 3900, {i: alt[i] for i in range(6)}))
+    # B =/X ops and a soft clip: same span, REF at SNP 1, ALT at 2..6
+    add("B_eqx", 900, 0, 60, [("S", 7), ("=", 100), ("X", 1), ("=", 2899)], np.concatenate([synth_bam.BASES[rng.integers(0, 4, size=7)], seq_of(900, 3900, {i: alt[i] for i in range(1, 6)})]))
+    # C a 2000-base N skip: 5900..6899 aligned (SNPs 11, 12), 6900..8899 skipped (13..16), 8900..9899 aligned (SNPs 17, 18)
+    add("C_skipN", 5900, 0, 60, [("M", 1000), ("N", 2000), ("M", 1000)], np.concatenate([seq_of(5900, 6900, {10: alt[10], 11: alt[11]}), seq_of(8900, 9900, {16: alt[16], 17: alt[17]})]))
+    # D primary (SNPs 41..43) + supplementary 3000 bases on (SNPs 49, 50; hard-clipped): merged
+    add("D_supp_near", 20900, 0, 60, [("M", 1200), ("S", 700)], np.concatenate([seq_of(20900, 22100, {40: alt[40], 41: alt[41], 42: alt[42]}), seq_of(24900, 25600, {})]))
+    add("D_supp_near", 24900, 2048, 60, [("H", 1200), ("M", 700)], seq_of(24900, 25600, {48: alt[48], 49: alt[49]}))
+    # E primary (SNPs 61, 62) + supplementary 29 500 bases before it (SNPs 1, 2): beyond --supp-aln-dist-cutoff 10000 -> the primary alone
+    add("E_supp_far", 30900, 0, 60, [("M", 700)], seq_of(30900, 31600, {60: alt[60], 61: alt[61]}))
+    add("E_supp_far", 900, 2048, 60, [("M", 700)], seq_of(900, 1600, {0: alt[0], 1: alt[1]}))
+    # F only the supplementary piece survives (the primary has MAPQ 5): dropped
+    add("F_supp_only", 40900, 0, 5, [("M", 700)], seq_of(40900, 41600, {80: alt[80]}))
+    add("F_supp_only", 42900, 2048, 60, [("M", 700)], seq_of(42900, 43600, {84: alt[84]}))
+    # G supplementary below MAPQ 60 is ignored: the primary alone
+    add("G_supp_lowq", 44900, 0, 60, [("M", 700)], seq_of(44900, 45600, {88: alt[88], 89: alt[89]}))
+    add("G_supp_lowq", 46900, 2048, 59, [("M", 700)], seq_of(46900, 47600, {92: alt[92]}))
+    # H secondary, I duplicate, I2 unmapped flag: filtered
+    add("H_secondary", 900, 256, 60, [("M", 700)], seq_of(900, 1600, {0: alt[0]}))
+    add("I_duplicate", 900, 1024, 60, [("M", 700)], seq_of(900, 1600, {0: alt[0]}))
+    add("I2_qcfail", 900, 512, 60, [("M", 700)], seq_of(900, 1600, {0: alt[0]}))
+    # J multi-allelic record (SNP 21: REF, ALT1, ALT2): second ALT -> genotype 2; K a base that is no allele -> no call at SNP 23
+    add("J_multi", 10900, 0, 60, [("M", 1200)], seq_of(10900, 12100, {20: alt2[20], 21: alt[21], 22: ref[snp_pos[22]]}))
+    add("K_nocall", 11900, 0, 60, [("M", 700)], seq_of(11900, 12600, {22: third[22], 23: alt[23]}))
+    # L covers no SNP: goes to the reads without SNPs
+    add("L_snpless", 1100, 0, 60, [("M", 300)], seq_of(1100, 1400, {}))
+    # M deletion across SNP 31 and an insertion before SNP 32: D removes the call, I shifts the read offset
+    s_m = seq_of(15900, 17100, {30: alt[30], 31: alt[31], 32: alt[32]})
+    s_m = np.concatenate([s_m[:100], s_m[101:300], synth_bam.BASES[rng.integers(0, 4, size=4)], s_m[300:]])       # delete offset 100 (= SNP 31 at 16000), insert 4 at offset 300
+    add("M_indels", 15900, 0, 60, [("M", 100), ("D", 1), ("M", 199), ("I", 4), ("M", 900)], s_m)
+    recs.sort(key=lambda t: t[0])
+    synth_bam.write_bam(prefix + ".bam", [("c", clen)], [r for _, r in recs])
+
+    def run(extra):
+        got, _ = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10", "--no-realign", "--supp-aln-dist-cutoff", "10000") + extra)
+        return {g["name"]: g for g in got["c"]["reads"]}, [x[0] for x in got["c"]["snpless"]]
+    got, snpless = run(())
+    cells = {nm: [(c[0], c[1]) for c in g["cells"]] for nm, g in got.items()}
+    assert sorted(got) == ["A_plain", "B_eqx", "C_skipN", "D_supp_near", "E_supp_far", "G_supp_lowq", "J_multi", "K_nocall", "M_indels"]
+    assert snpless == ["L_snpless"]
+    assert cells["A_plain"] == [(i, 1) for i in range(1, 7)]
+    assert cells["B_eqx"] == [(1, 0)] + [(i, 1) for i in range(2, 7)]
+    assert cells["C_skipN"] == [(11, 1), (12, 1), (17, 1), (18, 1)]
+    assert cells["D_supp_near"] == [(41, 1), (42, 1), (43, 1), (49, 1), (50, 1)]
+    assert got["D_supp_near"]["span"] == (20900, 22100)                       # first_pos_base = min, last_pos_base = min (:635-636)
+    assert cells["E_supp_far"] == [(61, 1), (62, 1)]
+    assert cells["G_supp_lowq"] == [(89, 1), (90, 1)]
+    assert cells["J_multi"] == [(21, 2), (22, 1), (23, 0)]
+    assert cells["K_nocall"] == [(24, 1)]
+    assert cells["M_indels"] == [(32, 1), (33, 1)]
+    assert all(c[2] == 30 for g in got.values() for c in g["cells"])
+    # -X: supplementary alignments are not used at all
+    got_x, _ = run(("-X",))
+    assert [(c[0], c[1]) for c in got_x["D_supp_near"]["cells"]] == [(41, 1), (42, 1), (43, 1)] and got_x["D_supp_near"]["span"] == (20900, 22100)
+    # default cutoff 40000: E's pieces are 29 500 bases apart -> merged
+    got_d, _ = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10", "--no-realign"))
+    e = {g["name"]: g for g in got_d["c"]["reads"]}["E_supp_far"]
+    assert [(c[0], c[1]) for c in e["cells"]] == [(1, 1), (2, 1), (61, 1), (62, 1)] and e["span"] == (900, 1600)
