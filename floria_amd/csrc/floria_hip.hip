@@ -38,6 +38,7 @@
 #include "blocks_kernel.h"
 #include "graph_kernel.h"
 #include "stats_kernel.h"
+#include "realign_kernel.h"
 #include "upload_kernel.h"
 
 static_assert(FLORIA_MAX_PLOIDY == fl::MAX_PLOIDY, "ploidy limits out of sync");
@@ -1614,6 +1615,36 @@ int floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* cons
     else hipLaunchKernelGGL(fl::stats_kernel<4>, dim3(n_groups), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out4, M + s_out.off, 32ull * n_groups, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- alignment::realign (alignment.rs:7-64) for the windows the host could not decide --------------------------------------------------------
+int floria_hip_realign(floria_hip_ctx* ctx, const uint8_t* read_windows, const uint8_t* ref_windows, const uint8_t* alleles, const uint8_t* n_alleles,
+                       uint64_t n, uint8_t* best, int32_t* score) {
+    if (!ctx || (n && (!read_windows || !ref_windows || !alleles || !n_alleles || !best))) return fail(FLORIA_E_INVALID, "null argument");
+    if (n == 0) return 0;
+    for (uint64_t i = 0; i < n; ++i) if (n_alleles[i] == 0 || n_alleles[i] > FLORIA_MAX_ALLELES) return fail(FLORIA_E_INVALID, "n_alleles must be 1..FLORIA_MAX_ALLELES");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->batch_token = 0;
+    struct Seg { size_t off, bytes; };
+    size_t cursor = 0;
+    auto seg = [&](size_t bytes) { Seg sg{cursor, bytes}; cursor += (bytes + 255) & ~(size_t)255; return sg; };
+    const Seg s_q = seg(32 * n), s_r = seg(32 * n), s_a = seg((size_t)FLORIA_MAX_ALLELES * n), s_n = seg(n), s_b = seg(n), s_s = seg(4 * n);
+    int rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
+    char* M = ctx->misc.as<char>();
+    HIPCHK(hipMemcpyAsync(M + s_q.off, read_windows, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(M + s_r.off, ref_windows, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(M + s_a.off, alleles, (size_t)FLORIA_MAX_ALLELES * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(M + s_n.off, n_alleles, n, hipMemcpyHostToDevice, ctx->stream));
+    fl::RealignArgs a{};
+    a.q = (const uint8_t*)(M + s_q.off); a.r = (const uint8_t*)(M + s_r.off); a.alleles = (const uint8_t*)(M + s_a.off); a.n_alleles = (const uint8_t*)(M + s_n.off);
+    a.best = (uint8_t*)(M + s_b.off); a.score = score ? (int32_t*)(M + s_s.off) : nullptr; a.n = n;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)ctx->n_cu * 32);      // 4 windows per workgroup, grid-stride beyond 8 workgroups per CU
+    hipLaunchKernelGGL(fl::realign_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(best, M + s_b.off, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (score) HIPCHK(hipMemcpyAsync(score, M + s_s.off, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -129,6 +129,15 @@ std::vector<Frag> remove_monomorphic_allele(std::vector<Frag> frags, double erro
     return out;
 }
 
+void realign_queue_on_device(Session& s, RealignQueue& q) {
+    const size_t n = q.size();
+    if (!n) return;
+    std::vector<uint8_t> best(n);
+    check(floria_hip_realign(s.ctx(), q.read_windows.data(), q.ref_windows.data(), q.alleles.data(), q.n_alleles.data(), (uint64_t)n, best.data(), nullptr));
+    for (size_t i = 0; i < n; ++i) *q.dst[i] = (Genotype)best[i];
+    q = RealignQueue();
+}
+
 // ---- Batch: every device stage once for MANY contigs ----------------------------------------------------------------------------------
 Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
     const size_t n = work.size();

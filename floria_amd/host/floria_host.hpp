@@ -18,6 +18,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -175,6 +176,28 @@ std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file)
 // realigned (alignment.rs:7-64, exact affine-gap DP in place of block-aligner)
 std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vcf_profile, const Options& options, const std::string& contig,
                                                                                const std::string* ref_seq = nullptr);
+// The same in two halves with the realignment's DP on the device between them.  alignment::realign decides most calls from the mismatch
+// count of the two 32-base windows (an exact shortcut); the windows it cannot decide are queued — read window, reference window,
+// candidate alleles, and the place the winning allele goes — scored by floria_hip_realign for a whole batch of contigs at once
+// (Session::realign), and only then are mates and supplementary pieces merged (combine_frags copies the calls).
+struct RealignQueue {
+    std::vector<uint8_t> read_windows, ref_windows, alleles, n_alleles;    // 32 / 32 / FLORIA_MAX_ALLELES / 1 bytes per call
+    std::vector<Genotype*> dst;
+    size_t size() const { return dst.size(); }
+    void append(RealignQueue&& other);
+};
+class ContigIngest {
+public:
+    // records of `contig` -> one Frag per passing alignment (file_reader.rs:343-430); with a queue the undecided realignments are deferred
+    ContigIngest(const BamFile& bam, const VcfProfile& vcf_profile, const Options& options, const std::string& contig, const std::string* ref_seq, RealignQueue* queue);
+    ~ContigIngest();
+    ContigIngest(ContigIngest&&) noexcept;
+    ContigIngest& operator=(ContigIngest&&) noexcept;
+    std::pair<std::vector<Frag>, std::vector<Frag>> finish();              // combine_frags (:491-659) -> (frags with SNPs, frags without)
+private:
+    struct Impl;
+    std::unique_ptr<Impl> p_;
+};
 std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam);                   // :749-826
 
 // part_block_manip.rs:517-616: (hapqs, rel_err per haploset, avg_err) — the HAPQ / REL_ERR header fields and the contig table's avg_err.
@@ -224,6 +247,8 @@ std::vector<Frag> remove_monomorphic_allele(std::vector<Frag> frags, double erro
 void write_reads(const std::vector<std::vector<const Frag*>>& part, const std::vector<std::pair<SnpPosition, SnpPosition>>& snp_range_parts_vec, const std::string& out_bam_part_dir,
                  bool extend_read_clipping, const std::vector<uint8_t>& hapqs, bool gzip);
 void write_nosnp_reads(const std::string& out_bam_part_dir, const std::vector<const Frag*>& snpless_frags, bool gzip);
+// scores the queued realignment windows on the device (floria_hip_realign) and stores the winning alleles where they belong
+void realign_queue_on_device(Session& s, RealignQueue& queue);
 // write_outputs for a contig whose statistics were computed by Batch::stats_and_hapq
 void write_outputs(const ContigWork& w, const Options& options);
 // the same in two halves, for hosts that write the contigs of a batch from several threads: the files of the contig (returns its

@@ -269,8 +269,10 @@ int nw_affine_score(const unsigned char* q, int nq, const unsigned char* r, int 
 }
 
 // alignment::realign (alignment.rs:7-64)
+// `queue`: calls the exact shortcut cannot decide are not scored here but appended to the queue (windows + where the result goes) for
+// floria_hip_realign, the same DP on the device; null = score them on the host (--ingest-only, tests)
 void realign(const std::string& ref_gn, Frag& frag, const std::string& read_seq, const std::map<SnpPosition, GnPosition>& var_to_gn_pos,
-             const std::map<GnPosition, std::vector<Genotype>>& gn_pos_to_allele) {
+             const std::map<GnPosition, std::vector<Genotype>>& gn_pos_to_allele, RealignQueue* queue) {
     constexpr size_t flank = 16;
     for (auto& kv : frag.seq_dict) {
         const size_t snp_gn_pos = var_to_gn_pos.at(kv.first);
@@ -298,6 +300,14 @@ void realign(const std::string& ref_gn, Frag& frag, const std::string& read_seq,
                 if (a < alleles.size()) { kv.second = (Genotype)a; continue; }
                 if (h <= 1) { kv.second = 0; continue; }
             }
+        }
+        if (queue && alleles.size() <= FLORIA_MAX_ALLELES) {
+            const auto up = [](unsigned char c) { return (unsigned char)(c >= 'a' && c <= 'z' ? c - 32 : c); };
+            for (size_t i = 0; i < 2 * flank; ++i) { queue->read_windows.push_back(q[i]); queue->ref_windows.push_back(up(r[i])); }
+            for (size_t a = 0; a < FLORIA_MAX_ALLELES; ++a) queue->alleles.push_back(a < alleles.size() ? up(alleles[a]) : 0);
+            queue->n_alleles.push_back((uint8_t)alleles.size());
+            queue->dst.push_back(&kv.second);                                   // (a map node: stays where it is when the Frag moves)
+            continue;
         }
         int best_score = INT32_MIN;
         Genotype best_geno = 0;
@@ -444,19 +454,29 @@ std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file)
     return out;
 }
 
-std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vp, const Options& o, const std::string& contig,
-                                                                               const std::string* ref_seq) {
+struct ContigIngest::Impl {
+    std::vector<std::vector<Tagged>> buckets;                                  // read name -> its passing alignments, in record order
+    const std::map<SnpPosition, GnPosition>* snp_to_gn = nullptr;
+    int64_t supp_aln_dist_cutoff = 0;
+};
+ContigIngest::~ContigIngest() = default;
+ContigIngest::ContigIngest(ContigIngest&&) noexcept = default;
+ContigIngest& ContigIngest::operator=(ContigIngest&&) noexcept = default;
+
+ContigIngest::ContigIngest(const BamFile& bam, const VcfProfile& vp, const Options& o, const std::string& contig, const std::string* ref_seq, RealignQueue* queue)
+    : p_(new Impl) {
     const bool filter_supplementary = true, use_supplementary = !o.dont_use_supp_aln;
     const auto tid_it = std::find(bam.target_names.begin(), bam.target_names.end(), contig);
-    if (tid_it == bam.target_names.end()) return {};
+    if (tid_it == bam.target_names.end()) return;
     const int32_t tid = (int32_t)(tid_it - bam.target_names.begin());
     const auto& snp_positions = vp.vcf_pos_to_snp_counter_map.at(contig);
     const auto& pos_allele_map = vp.vcf_pos_allele_map.at(contig);
     const auto& snp_to_gn = vp.vcf_snp_pos_to_gn_pos_map.at(contig);
+    p_->snp_to_gn = &snp_to_gn; p_->supp_aln_dist_cutoff = o.supp_aln_dist_cutoff;
     // read name -> its passing alignments, in record order (the reference fills the buckets from a parallel loop)
     std::vector<std::string> names;
     std::unordered_map<std::string, size_t> name_ix;
-    std::vector<std::vector<Tagged>> buckets;
+    std::vector<std::vector<Tagged>>& buckets = p_->buckets;
     size_t count = 0;
     for (const uint32_t rec_ix : bam.by_tid[tid]) {                           // the contig's records in file order, as fetch() yields them
         const BamRecord& rec = bam.records[rec_ix];
@@ -465,9 +485,16 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
         auto ins = name_ix.emplace(rec.qname, names.size());
         if (ins.second) { names.push_back(rec.qname); buckets.emplace_back(); }
         Frag fr = frag_from_record(rec, snp_positions, pos_allele_map, this_count, o.output_reads);
-        if (ref_seq) realign(*ref_seq, fr, rec.seq, snp_to_gn, pos_allele_map);                    // :416-423
+        if (ref_seq) realign(*ref_seq, fr, rec.seq, snp_to_gn, pos_allele_map, queue);             // :416-423
         buckets[ins.first->second].push_back({rec.flags, std::move(fr)});
     }
+}
+
+std::pair<std::vector<Frag>, std::vector<Frag>> ContigIngest::finish() {
+    std::vector<std::vector<Tagged>>& buckets = p_->buckets;
+    if (buckets.empty()) return {};
+    const std::map<SnpPosition, GnPosition>& snp_to_gn = *p_->snp_to_gn;
+    struct { int64_t supp_aln_dist_cutoff; } o{p_->supp_aln_dist_cutoff};
     // combine_frags (:491-659)
     std::vector<Frag> ref_frags;
     for (auto& frags : buckets) {
@@ -518,7 +545,22 @@ std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(co
     }
     std::pair<std::vector<Frag>, std::vector<Frag>> out;
     for (Frag& f : ref_frags) (f.seq_dict.empty() ? out.second : out.first).push_back(std::move(f));
+    buckets.clear();
     return out;
+}
+
+std::pair<std::vector<Frag>, std::vector<Frag>> get_frags_from_bamvcf_rewrite(const BamFile& bam, const VcfProfile& vp, const Options& o, const std::string& contig,
+                                                                               const std::string* ref_seq) {
+    return ContigIngest(bam, vp, o, contig, ref_seq, nullptr).finish();
+}
+
+void RealignQueue::append(RealignQueue&& o) {
+    read_windows.insert(read_windows.end(), o.read_windows.begin(), o.read_windows.end());
+    ref_windows.insert(ref_windows.end(), o.ref_windows.begin(), o.ref_windows.end());
+    alleles.insert(alleles.end(), o.alleles.begin(), o.alleles.end());
+    n_alleles.insert(n_alleles.end(), o.n_alleles.begin(), o.n_alleles.end());
+    dst.insert(dst.end(), o.dst.begin(), o.dst.end());
+    o = RealignQueue();
 }
 
 // file_reader.rs:749-826.  The htslib pileup engine visits every reference position covered by at least one alignment that

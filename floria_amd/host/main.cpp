@@ -219,7 +219,8 @@ int main(int argc, char** argv) {
         // The contigs go through the stages in batches (floria_host.hpp, "many contigs at once"): the host stages of a batch run on -t
         // threads, one contig per task; the device stages once per batch.  A batch is closed at batch_contigs contigs or batch_cells
         // SNP calls, whichever comes first (the pinned staging buffer holds 6 bytes per call).
-        double t_ingest = 0., t_s1 = 0., t_stitch = 0., t_s2 = 0., t_stats = 0., t_write = 0.;
+        double t_ingest = 0., t_s1 = 0., t_stitch = 0., t_s2 = 0., t_stats = 0., t_write = 0., t_realign = 0.;
+        size_t n_realign_device = 0;
         size_t done = 0, n_batches = 0;
         while (done < todo.size()) {
             // ---- ingest (floria.rs:264-293), one contig per task ----------------------------------------------------------------------
@@ -229,12 +230,31 @@ int main(int argc, char** argv) {
             while (done < todo.size() && work.size() < batch_contigs && cells < batch_cells) {
                 const size_t take = std::min({todo.size() - done, batch_contigs - work.size(), std::max<size_t>(n_threads * 2, 2)});
                 std::vector<ContigWork> got(take);
+                // records -> Frags with the realignment's undecided windows queued (one queue per contig), the queued windows of the
+                // whole round scored by ONE device call, then the merge of mates / supplementary pieces and the sort
+                std::vector<std::unique_ptr<ContigIngest>> ing(take);
+                std::vector<RealignQueue> queues(take);
+                const bool on_device = !ingest_only && !no_realign;
+                parallel_for(take, n_threads, [&](size_t i) {
+                    const std::string& contig = todo[done + i];
+                    const auto fa = fasta.find(contig);
+                    ing[i].reset(new ContigIngest(bam, vp, o, contig, (fa != fasta.end() && !no_realign) ? &fa->second : nullptr, on_device ? &queues[i] : nullptr));
+                });
+                if (on_device) {
+                    const double tr = now_s();
+                    RealignQueue all;
+                    for (RealignQueue& q : queues) all.append(std::move(q));
+                    n_realign_device += all.size();
+                    realign_queue_on_device(*session_holder, all);
+                    t_realign += now_s() - tr;
+                }
                 parallel_for(take, n_threads, [&](size_t i) {
                     const std::string& contig = todo[done + i];
                     ContigWork& w = got[i];
                     w.name = contig; w.out_dir = o.out_dir + "/" + contig;
                     const auto fa = fasta.find(contig);
-                    auto fr = get_frags_from_bamvcf_rewrite(bam, vp, o, contig, (fa != fasta.end() && !no_realign) ? &fa->second : nullptr);
+                    auto fr = ing[i]->finish();
+                    ing[i].reset();
                     w.all_frags = std::move(fr.first); w.frags_without_snps = std::move(fr.second);
                     const auto sgp = vp.snp_to_genome_pos.find(contig);
                     w.snp_to_genome_pos = sgp == vp.snp_to_genome_pos.end() ? nullptr : &sgp->second;
@@ -299,6 +319,7 @@ int main(int argc, char** argv) {
             for (const std::string& r : rows) append_contig_ploidy_row(o, r);
             t_write += now_s() - t0;
         }
+        fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
         fprintf(stderr, "Total time taken is %.3fs\n", now_s() - t_all);

@@ -19,7 +19,7 @@ _LIB = None
 
 # every symbol include/floria_hip.h declares
 SYMBOLS = [
-    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version",
+    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version", "floria_hip_realign",
     "floria_hip_block_ranges", "floria_hip_ranges_free", "floria_hip_contig_upload", "floria_hip_contig_free",
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
@@ -350,6 +350,19 @@ class FloriaHip:
                                       C.c_uint32(len(groups)), capi.ptr(pos, C.c_uint64), C.c_uint32(len(pos)), C.c_uint64(int(block_length)),
                                       capi.ptr(hq, C.c_uint8), capi.ptr(rel, C.c_double), C.byref(avg)))
         return hq, rel, avg.value
+
+    def realign(self, read_windows, ref_windows, alleles, n_alleles, want_scores=False):
+        """alignment::realign for n SNP calls: read_windows / ref_windows uint8 [n, 32], alleles uint8 [n, 4], n_alleles uint8 [n]
+        -> best allele index uint8 [n] (and the best score int32 [n])."""
+        q = np.ascontiguousarray(read_windows, np.uint8); r = np.ascontiguousarray(ref_windows, np.uint8)
+        al = np.ascontiguousarray(alleles, np.uint8); na = np.ascontiguousarray(n_alleles, np.uint8)
+        n = len(na)
+        assert q.shape == (n, 32) and r.shape == (n, 32) and al.shape == (n, 4)
+        best = np.zeros(n, np.uint8)
+        score = np.zeros(n, np.int32) if want_scores else None
+        _check(load().floria_hip_realign(self._h, capi.ptr(q, C.c_uint8), capi.ptr(r, C.c_uint8), capi.ptr(al, C.c_uint8), capi.ptr(na, C.c_uint8), C.c_uint64(n),
+                                         capi.ptr(best, C.c_uint8), capi.ptr(score, C.c_int32) if want_scores else None))
+        return (best, score) if want_scores else best
 
     def hapq_batch(self, contigs, grp_contig, groups, ranges, snp_positions, block_length):
         """get_hapq for the haplosets of many contigs in one call -> (hapq uint8 [n], rel_err float64 [n], avg_err float64 [n_contigs])."""

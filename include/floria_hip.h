@@ -269,6 +269,14 @@ int  floria_hip_hapq_batch(floria_hip_ctx* ctx, const floria_hip_contig* const* 
                            const uint64_t* const* snp_to_genome_pos, const uint32_t* n_snps, uint64_t block_length,
                            uint8_t* hapq, double* rel_err, double* avg_err);
 
+/* alignment::realign (alignment.rs:7-64) for many SNP calls at once: call i has the read's 32 bases around the SNP (read_windows[32 i ..],
+ * A C G T, the SNP in column 16), the reference's 32 bases (ref_windows, upper case) and n_alleles[i] candidate bases (alleles[4 i ..], the
+ * record's REF and ALTs in order).  best[i] = index of the FIRST allele whose window, with the allele in column 16, has the maximal global
+ * alignment score against the read window (match +1, mismatch -1, gap open -2, extend -1).  score (may be NULL) receives that score.
+ * The reference scores with block-aligner (an adaptive-band approximation); this is the exact affine-gap DP. */
+int  floria_hip_realign(floria_hip_ctx* ctx, const uint8_t* read_windows, const uint8_t* ref_windows, const uint8_t* alleles,
+                        const uint8_t* n_alleles, uint64_t n, uint8_t* best, int32_t* score);
+
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */

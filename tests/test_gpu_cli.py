@@ -46,10 +46,10 @@ def parse_frag_dump(path):
     return contigs
 
 
-def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra=()):
+def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra=(), sub_rate=0.0):
     from oracle import stitch
     prefix = str(tmp_path / "data")
-    expect = synth_bam.write_dataset(prefix, contigs, seed=7)
+    expect = synth_bam.write_dataset(prefix, contigs, seed=7, sub_rate=sub_rate)
     out = str(tmp_path / "out")
     dump = str(tmp_path / "frags.txt")
     cmd = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", str(EPS), "-l", str(block_length),
@@ -57,6 +57,8 @@ def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(os.path.join(out, "cmd.log")).read().split()[1:4] == ["-b", prefix + ".bam", "-v"]
+    n_dev = int(re.search(r"Realignment: (\d+) calls scored on the device", r.stderr).group(1))
+    assert (n_dev > 1000) if sub_rate >= 0.05 else True
     frags = parse_frag_dump(dump)
     ploidy_rows = open(os.path.join(out, "contig_ploidy_info.tsv")).read().splitlines(keepends=True)
     assert ploidy_rows[0].startswith("contig\taverage_straincount\twhole_contig_multiplicity\t")
@@ -142,6 +144,13 @@ def test_quickstart_substitute_long_reads(floria_hip, oracle_mod, tmp_path):
     # ~30x long reads; a tenth of the alignments carry soft clips, insertions and deletions (one across a SNP)
     c = synth.make_config_contig(1, 0, keep_layout=True)
     run_and_check(floria_hip, oracle_mod, tmp_path, [c], 10000)
+
+
+def test_noisy_long_reads_realigned_on_the_device(floria_hip, oracle_mod, tmp_path):
+    # 8 % substitution errors: most SNP windows carry more than two mismatches, the host's shortcut cannot decide them and their 32 x 32
+    # affine-gap DPs run on the device (floria_hip_realign); the expected pileup comes from the numpy DP on every window
+    c = synth.make_config_contig(1, 1, 0.6, keep_layout=True)
+    run_and_check(floria_hip, oracle_mod, tmp_path, [c], 10000, sub_rate=0.08)
 
 
 def test_two_contigs_and_a_small_one_is_skipped(floria_hip, oracle_mod, tmp_path):

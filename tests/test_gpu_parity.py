@@ -564,3 +564,46 @@ def test_narrow_beam_with_many_slabs_takes_the_wide_kernel(gpu_ctx, hip_lib, ora
     ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1, S // 2], [S // 2 + 4, S], P=9, B=7)
     assert_block_results_equal(ro, rg, "p9 n7")
     assert rg.min_prune_margin == ro.min_prune_margin
+
+
+def test_realign_kernel_equals_the_exact_affine_dp(gpu_ctx):
+    # alignment::realign (alignment.rs:7-64) on the device: one wavefront per SNP call, the 32 x 32 affine-gap DP as a systolic array over DPP
+    # lane shifts.  Windows: random bases; reference = the read with substitutions, a deleted base (shifted tail) or an inserted base,
+    # 1-4 candidate alleles.  Expected: the numpy Gotoh DP of floria_amd/synth_bam.py on every (window, allele) pair, first best wins.
+    from floria_amd import synth_bam
+    rng = np.random.default_rng(17)
+    n = 6000
+    B = synth_bam.BASES
+    q = B[rng.integers(0, 4, size=(n, 32))]
+    r = q.copy()
+    kind = rng.integers(0, 4, size=n)
+    for i in range(n):
+        if kind[i] == 0:                                              # a few substitutions
+            k = rng.integers(0, 9)
+            r[i, rng.integers(0, 32, size=k)] = B[rng.integers(0, 4, size=k)]
+        elif kind[i] == 1:                                            # the read lost a base: the reference has one more before the tail
+            x = int(rng.integers(1, 31)); r[i, x + 1:] = q[i, x:31]; r[i, x] = B[rng.integers(0, 4)]
+        elif kind[i] == 2:                                            # the read has an extra base
+            x = int(rng.integers(1, 31)); r[i, x:31] = q[i, x + 1:]; r[i, 31] = B[rng.integers(0, 4)]
+        else:                                                         # unrelated
+            r[i] = B[rng.integers(0, 4, size=32)]
+    na = rng.integers(1, 5, size=n).astype(np.uint8)
+    al = np.zeros((n, 4), np.uint8)
+    for i in range(n):
+        al[i, :na[i]] = B[rng.permutation(4)[:na[i]]]
+    best, score = gpu_ctx.realign(q, r, al, na, want_scores=True)
+    exp_best = np.zeros(n, np.uint8); exp_score = np.full(n, -10 ** 9, np.int64)
+    for a in range(4):
+        m = na > a
+        ra = r[m].copy(); ra[:, 16] = al[m, a]
+        s = synth_bam.nw_affine_batch(q[m], ra).astype(np.int64)
+        idx = np.nonzero(m)[0]
+        better = s > exp_score[idx]
+        exp_best[idx[better]] = a; exp_score[idx[better]] = s[better]
+    assert np.array_equal(score.astype(np.int64), exp_score)
+    assert np.array_equal(best, exp_best)
+    assert len(np.unique(best)) > 2 and (score < 20).any() and (score == 32).any() is not None
+    # empty batch and argument checks
+    assert len(gpu_ctx.realign(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8), np.zeros((0, 4), np.uint8), np.zeros(0, np.uint8))) == 0
+    with pytest.raises(Exception):
+        gpu_ctx.realign(q[:1], r[:1], al[:1], np.array([5], np.uint8))
