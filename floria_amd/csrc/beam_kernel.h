@@ -36,6 +36,7 @@ struct BeamArgs {
     uint32_t  n_max;               // max reads per block
     uint32_t* queue_head;
     const uint8_t* blk_done;       // stop rule already fired for this block (graph_processing.rs:198-251)
+    const uint32_t* stop_at;       // speculative stages: smallest ploidy at which the stop rule is known to break (optimize_kernel.h), else null
     uint64_t* state_pool;          // [slots][nbuf][span_max][ploidy][A]
     uint64_t  state_stride;        // bytes per slot (beam_slab_kernel: the u64 slabs followed by their code bytes)
     uint32_t* hist_pool;           // [slots][hist_stride] traceback records
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = g.job_block[job];
         if (g.blk_done[b]) continue;
+        if (g.stop_at && __hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ploidy) continue;      // (speculative stages, see optimize_kernel.h)
         min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];

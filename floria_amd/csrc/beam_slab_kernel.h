@@ -186,6 +186,8 @@ void beam_slab_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = uni(g.job_block[job]);
         if (g.blk_done[b]) continue;
+        if (g.stop_at && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
+        bool dropped = false;
         min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];
@@ -246,6 +248,7 @@ void beam_slab_kernel(BeamArgs g) {
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
+            if (g.stop_at && (i & 63u) == 63u && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
             const uint32_t cbeg = cm_cur.cbeg, L = cm_cur.L;
             const uint32_t first_rel = sm_cur.first - pos0;
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
@@ -787,7 +790,8 @@ void beam_slab_kernel(BeamArgs g) {
             start_rel = first_rel;
         }
 
-        if (n > 0) {
+        if (dropped) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }     // (an LDS-DMA of the next read may still be in flight)
+        if (n > 0 && !dropped) {
             H.hp_id = lane;
             uint32_t ecur = H.sorted_first();
             uint8_t* out = g.part_out + roff;

@@ -146,6 +146,8 @@ struct Knobs {
     uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
     uint32_t spec_desc = 0;       // speculative stage: launch the highest ploidy first
+    uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
+    bool spec_flat = false;       // (A/B) speculative stages without stream priorities and without the early stop-rule flags
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
 };
 
@@ -161,7 +163,9 @@ struct floria_hip_ctx {
     static constexpr uint32_t MAX_GROUPS = 8;
     static constexpr uint32_t MAX_LANES = 32;
     hipStream_t gstream[MAX_LANES] = {};
+    hipStream_t gstream_low[MAX_LANES] = {};      // speculative stages: the lanes of ploidy >= 4 (dispatched after the ploidies every block needs)
     hipEvent_t ev_fork[MAX_LANES] = {}, ev_join[MAX_LANES] = {};
+    hipEvent_t ev_gate[MAX_GROUPS] = {};       // speculative stages: the beam search of ploidy 2 of group g has finished (ploidies >= 4 start behind it)
     hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
     hipEvent_t ev_rids = nullptr;
     hipEvent_t ev_chunk[MAX_GROUPS + 1] = {};  // floria_hip_phase_pileups_batch: chunk g of the cell arrays has landed and is flattened
@@ -303,6 +307,7 @@ enum { K_BEAM = 0, K_OPT = 1, K_SEL = 2, K_H2D = 3, K_D2H = 4, K_REASSIGN = 5, K
 
 void sync_all(floria_hip_ctx* ctx) {
     for (uint32_t g = 0; g < floria_hip_ctx::MAX_LANES; ++g) if (ctx->gstream[g]) (void)hipStreamSynchronize(ctx->gstream[g]);
+    for (uint32_t g = 0; g < floria_hip_ctx::MAX_LANES; ++g) if (ctx->gstream_low[g]) (void)hipStreamSynchronize(ctx->gstream_low[g]);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->flat_stream) (void)hipStreamSynchronize(ctx->flat_stream);
     (void)hipStreamSynchronize(ctx->stream);
@@ -344,7 +349,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
               const uint32_t* d_jobs, uint64_t tot_reads, uint32_t n_max, uint32_t span_max, const floria_params* prm, uint8_t* d_planes,
               uint8_t* d_beam_part, const std::vector<std::vector<uint32_t>>& stages, hipEvent_t* chunk_ev, double* d_mec, double* d_na, uint32_t* d_iters, uint8_t* d_done, uint32_t* d_best,
               uint32_t* d_tried, uint32_t* d_queue, double* d_margin, uint32_t* d_diag,
-              unsigned long long* d_steps, EventTimer& T, bool& p1_shortcut) {
+              unsigned long long* d_steps, EventTimer& T, bool& p1_shortcut, uint32_t* d_stop, uint32_t* d_ready) {
     const uint32_t P = prm->max_ploidy, B = prm->beam;
     const Knobs& K = ctx->knobs;
     p1_shortcut = false;
@@ -453,6 +458,18 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
     hipStream_t ls[floria_hip_ctx::MAX_LANES];
     for (uint32_t l = 0; l < n_lanes; ++l) {
         if (l == 0) { ls[0] = ctx->stream; continue; }
+        if (W > 1 && (l % W) >= 3 && !K.spec_flat) {        // a speculative stage's lanes of ploidy >= 4: lowest dispatch priority, so that the ploidies every
+                                                            // block needs get the wave slots first and the stop rule is known before most of these jobs start
+            if (!ctx->gstream_low[l]) {
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                if (hipStreamCreateWithPriority(&ctx->gstream_low[l], hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreateWithFlags(&ctx->gstream_low[l], hipStreamNonBlocking)); }
+            }
+            if (!ctx->ev_join[l]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[l], hipEventDisableTiming));
+            if (!ctx->ev_fork[l]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork[l], hipEventDisableTiming));
+            ls[l] = ctx->gstream_low[l];
+            continue;
+        }
         if (!ctx->gstream[l]) HIPCHK(hipStreamCreateWithFlags(&ctx->gstream[l], hipStreamNonBlocking));
         if (!ctx->ev_join[l]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[l], hipEventDisableTiming));
         if (!ctx->ev_fork[l]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork[l], hipEventDisableTiming));
@@ -491,10 +508,10 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                 uint8_t* lane_part = d_beam_part + (uint64_t)j * (tot_reads + 16);
                 // ---- beam search -----------------------------------------------------------------------------------------
                 if (!q.shortcut) {
-                    const uint32_t slots = std::min(q.beam_slots, nj);
+                    const uint32_t slots_full = std::min(q.beam_slots, nj);
                     fl::BeamArgs a{};
                     a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
-                    a.queue_head = gqueue; a.blk_done = d_done;
+                    a.queue_head = gqueue; a.blk_done = d_done; a.stop_at = (stage.size() > 1 && !K.spec_flat) ? d_stop : nullptr;
                     a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane); a.state_stride = q.state_bytes;
                     a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
                     a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
@@ -505,6 +522,15 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
+                    const bool gated = stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p >= 4;
+                    // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
+                    // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
+                    const uint32_t slots = gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
+                    if (gated) {          // ploidies few blocks need start when ploidy 2 has left the chip: by the time their jobs run, the stop rule of most
+                                          // blocks is known and the jobs are dropped at dequeue or within 64 reads
+                        if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
+                        HIPCHK(hipStreamWaitEvent(st, ctx->ev_gate[g], 0));
+                    }
                     int t = T.begin(K_BEAM, st);
                     if (q.wide) {
                         if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
@@ -523,6 +549,10 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     T.end(t);
                     HIPCHK(hipGetLastError());
                     ctx->timing.beam_launches++;
+                    if (stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p == 2) {
+                        if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
+                        HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
+                    }
                 }
                 // ---- optimise + MEC stats ------------------------------------------------------------------------------
                 {
@@ -541,6 +571,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.fuse_select = stage.size() == 1 ? 1 : 0;
                     a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
                     a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
+                    if (stage.size() > 1 && !K.spec_flat) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
                     int t = T.begin(K_OPT, st);
                     auto launch = [&](auto kern) -> hipError_t {
                         if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
@@ -637,6 +668,9 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(4, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
+        K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
+        if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_DIV")) K.spec_gate_div = (uint32_t)std::max(1, std::min(16, atoi(v)));
+        K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
         else c->stage_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     }
@@ -653,6 +687,8 @@ void floria_hip_destroy(floria_hip_ctx* c) {
     c->stage.release();
     for (uint32_t g = 0; g < floria_hip_ctx::MAX_LANES; ++g) {
         if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
+        if (c->gstream_low[g]) (void)hipStreamDestroy(c->gstream_low[g]);
+        if (g < floria_hip_ctx::MAX_GROUPS && c->ev_gate[g]) (void)hipEventDestroy(c->ev_gate[g]);
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
         if (c->ev_fork[g]) (void)hipEventDestroy(c->ev_fork[g]);
     }
@@ -1219,8 +1255,10 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     {
         int spec = ctx->knobs.speculate;
         const bool slab_path = P * prm->beam <= 63 && !ctx->knobs.beam_path;          // the wide-beam kernels own whole CUs: nothing to gain there
-        // (measured on config-4 shards: all ploidies at once wins below ~2k blocks — 250 contigs: 33 vs 40 ms — and loses above — 500 contigs: 64 vs 47 ms)
-        if (spec < 0) spec = (slab_path && (G == 1 || chunked) && P >= 3 && jobs.size() * 2 <= (size_t)ctx->n_cu * 16) ? 1 : 0;
+        // (measured on config-4 shards, resident, with the gated high ploidies and the early stop-rule flags of run_phase: all ploidies at once wins up to
+        // ~3k blocks — 125 / 250 / 375 contigs: 21 / 24 / 32 ms against 38 / 41 / 44.5 ms — is level at 3.6k blocks — 500 contigs: 44-47 against 48.5 ms —
+        // and loses above — 750 contigs: 59-69 against 56 ms, the full 2000: 141-155 against 99 ms)
+        if (spec < 0) spec = (slab_path && P >= 3 && jobs.size() <= (size_t)ctx->n_cu * 12) ? 1 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
@@ -1241,15 +1279,17 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
               s_margin = seg(8ull * n_blocks * P + 16),
               // zero-initialised, contiguous (ONE memset): partition output, mec / num_alleles / iters, stop-rule state, queue counters, diagnostics
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
-              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4),
+              s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_ready = seg(4ull * n_blocks + 4),
               s_q = seg(8ull * floria_hip_ctx::MAX_LANES * FLORIA_MAX_PLOIDY + 16), s_diag = seg(16 + 8 * 48), s_steps = seg(16);
     const size_t zero_bytes = cursor - s_out.off;
+    const Seg s_stop = seg(4ull * n_blocks + 4);             // speculative stages: smallest ploidy at which the stop rule is known to break, 0xffffffff = unknown
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
     char* M = ctx->misc.as<char>();
     th = T.begin(K_H2D);
     HIPCHK(hipMemcpyAsync(M0 + s_roff.off, roff.data(), 8ull * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream));
     if (!jobs.empty()) HIPCHK(hipMemcpyAsync(M + s_jobs.off, jobs.data(), 4ull * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(M + s_out.off, 0, zero_bytes, ctx->stream));
+    if (stage_w > 1) HIPCHK(hipMemsetAsync(M + s_stop.off, 0xff, s_stop.bytes, ctx->stream));
     const double inf = std::numeric_limits<double>::infinity();
     T.end(th);
     if (n_blocks) {
@@ -1286,7 +1326,8 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     rc = run(ctx, any_q0, bs, jobs, group_off, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
              (uint8_t*)(M + s_bpart.off), stages, chunked ? SC.chunk_ev : nullptr, (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
-             (double*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut);
+             (double*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut,
+             (uint32_t*)(M + s_stop.off), (uint32_t*)(M + s_ready.off));
     if (rc) { sync_all(ctx); return rc; }
     TR.mark("every launch queued");
     int t_rids = -1;

@@ -53,7 +53,27 @@ struct OptArgs {
     uint8_t*  blk_done_w;
     uint32_t* best_ploidy;
     uint32_t* tried;
+    // speculative stages (several ploidies of a block in flight at once): the stop rule is published per block as soon as the two MEC
+    // values it compares exist — stop_at[b] = the smallest ploidy at which the reference's loop breaks (as far as known), ready[b] =
+    // bit p set once mec[b][p-1] is final.  Jobs of a block with ploidy > stop_at[b] are dropped wherever they are (beam: at dequeue
+    // and every 64 reads; here: at dequeue): their results could not be looked at by select_kernel.  Null outside speculative stages.
+    uint32_t* stop_at;
+    uint32_t* ready;
+    double    thresholds[FLORIA_MAX_PLOIDY + 2];      // mec_threshold of every ploidy (host libm pow)
 };
+// fired(q): the reference's loop breaks at ploidy q (graph_processing.rs:196-251); needs mec[q-1] (q > 1) and mec[q], num_alleles[q]
+__device__ inline bool stop_rule_fires(const OptArgs& g, uint32_t b, uint32_t q) {
+    const double mec_q = __hip_atomic_load(&g.mec[(uint64_t)b * g.max_ploidy + q - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double na_q = __hip_atomic_load(&g.num_alleles[(uint64_t)b * g.max_ploidy + q - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double expected = na_q * g.eps;
+    if (q > 1) {
+        const double mec_prev = __hip_atomic_load(&g.mec[(uint64_t)b * g.max_ploidy + q - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((mec_q / mec_prev) < g.thresholds[q]) { /* do nothing */ }
+        else if (g.stopping_heuristic) return true;
+        return mec_q < expected;
+    }
+    return mec_q < expected;
+}
 #ifdef FLORIA_PROF
 #define OPT_TICK(ph) do { __syncthreads(); if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[ph], _t - t_last); t_last = _t; } } while (0)
 #else
@@ -139,6 +159,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = g.job_block[job];
         if (g.blk_done[b]) continue;
+        if (g.stop_at && __hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) continue;      // (uniform: every thread reads the same word)
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
@@ -423,6 +444,12 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 } else if (mecv < expected) stop = true;                                               // :247-250
                 g.tried[b] = p;
                 if (stop || p == g.max_ploidy) { g.blk_done_w[b] = 1; g.best_ploidy[b] = best; }
+            }
+            if (g.stop_at) {
+                __threadfence();                                                              // mec / num_alleles of (b, p) before the ready bit
+                const uint32_t have = atomicOr(&g.ready[b], 1u << p) | (1u << p);
+                for (uint32_t q = p; q <= p + 1 && q <= g.max_ploidy; ++q)
+                    if (((have >> q) & 1u) && (q == 1 || ((have >> (q - 1)) & 1u)) && stop_rule_fires(g, b, q)) atomicMin(&g.stop_at[b], q);
             }
         }
     }
