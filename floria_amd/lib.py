@@ -50,6 +50,7 @@ def build(force=False):
 
 
 def load():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")      # streams of the job groups / upload pipeline on separate hardware queues (read when HIP initialises)
     global _LIB
     if _LIB is None:
         if not os.path.exists(_SO):
