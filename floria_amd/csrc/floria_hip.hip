@@ -1260,6 +1260,9 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // and loses above — 750 contigs: 59-69 against 56 ms, the full 2000: 141-155 against 99 ms)
         if (spec < 0) spec = (slab_path && P >= 3 && jobs.size() <= (size_t)ctx->n_cu * 12) ? 1 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
+        // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
+        // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
+        if (ctx->knobs.speculate < 0 && spec && P * G > 10) spec = 0;
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
                               if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
@@ -1440,7 +1443,8 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     uint64_t cells = 0;
     for (uint32_t i = 0; i < n_contigs; ++i) if (pileups[i].n_reads && pileups[i].read_off) cells += pileups[i].read_off[pileups[i].n_reads];
     // auto: ~0.5 GB of host pileup per chunk, at most 5 (measured on BASELINE config 4, 2.65 GB: 5 chunks, the first one half-size, are best)
-    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (448ull << 20)));
+    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (200ull << 20)));
+    // (measured, config 4, H2D-inclusive: 500 contigs / 0.66 GB: 2 chunks 60.5 ms, 3-4 chunks 56.5; 1000 contigs / 1.33 GB: 2 chunks 86 ms, 4-5 chunks 77; 2000 contigs: 5 chunks)
     UploadPlan UP;
     int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(want_chunks, floria_hip_ctx::MAX_GROUPS), UP);
     if (rc) return rc;
