@@ -448,6 +448,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             if (g.stop_at) {
                 __threadfence();                                                              // mec / num_alleles of (b, p) before the ready bit
                 const uint32_t have = atomicOr(&g.ready[b], 1u << p) | (1u << p);
+                __threadfence();                                                              // the other ploidy's mec / num_alleles after its ready bit
                 for (uint32_t q = p; q <= p + 1 && q <= g.max_ploidy; ++q)
                     if (((have >> q) & 1u) && (q == 1 || ((have >> (q - 1)) & 1u)) && stop_rule_fires(g, b, q)) atomicMin(&g.stop_at[b], q);
             }
