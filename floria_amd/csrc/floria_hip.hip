@@ -717,6 +717,8 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
     else if (k == "opt_global") K.opt_global = value != 0;
+    else if (k == "spec_flat") K.spec_flat = value != 0;
+    else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 4));

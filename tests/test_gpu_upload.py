@@ -226,6 +226,18 @@ def test_ploidy_stages_do_not_change_results(gpu_ctx, hip_lib, oracle_mod, cfg, 
     for spec in (1, 2):
         assert_block_results_equal(out[0], out[spec], f"speculate {spec}")
         assert out[0].min_prune_margin == out[spec].min_prune_margin
+    # the same with the chip over-subscribed (few wave slots: most jobs of the higher ploidies are dequeued after the stop rule of their
+    # block is known and are dropped, others are dropped in mid-run), with the pruning switched off, and with full-size gated grids
+    try:
+        gpu_ctx.set_option("speculate", 1)
+        for slots, flat, div in ((48, 0, 2), (48, 1, 2), (16, 0, 1), (0, 0, 4)):
+            gpu_ctx.set_option("slots", slots); gpu_ctx.set_option("spec_flat", flat); gpu_ctx.set_option("spec_gate_div", div)
+            for rep in range(2):
+                r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+                assert_block_results_equal(out[0], r, f"speculate 1, slots {slots}, flat {flat}, gate_div {div}, rep {rep}")
+                assert out[0].min_prune_margin == r.min_prune_margin
+    finally:
+        gpu_ctx.set_option("speculate", -1); gpu_ctx.set_option("slots", 0); gpu_ctx.set_option("spec_flat", 0); gpu_ctx.set_option("spec_gate_div", 2)
     n0 = bc.count(0)
     ro = oracle_mod.phase_blocks(contigs[0].pileup, bs[:n0], be[:n0], oracle_mod.make_params(EPS, C["max_ploidy"], C["beam"]), threads=8)
     assert np.array_equal(ro.mec.view(np.uint64), out[1].mec[:n0].view(np.uint64)) and np.array_equal(ro.ploidies_tried, out[1].ploidies_tried[:n0])
