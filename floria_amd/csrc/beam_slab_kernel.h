@@ -117,7 +117,8 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 
 // TP / TB: ploidy and beam width as compile-time constants (0 = read them from the arguments): LDS offsets become immediates, the
 // per-partition loops unroll and divisions by p turn into multiplications; the host picks TP = p, TB = 10 for the CLI's default beam.
-template <int A, bool Q0, int TP = 0, int TB = 0>
+// SPEC: the launch belongs to a speculative stage (stop_at is set): only that instance carries the checks that drop a job whose ploidy turned out not to be needed
+template <int A, bool Q0, int TP = 0, int TB = 0, bool SPEC = false>
 #ifndef FLORIA_SLAB_LOW_P_MAX
 #define FLORIA_SLAB_LOW_P_MAX 3
 #endif
@@ -186,7 +187,7 @@ void beam_slab_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = uni(g.job_block[job]);
         if (g.blk_done[b]) continue;
-        if (g.stop_at && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
+        if (SPEC && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
         bool dropped = false;
         min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
@@ -248,7 +249,7 @@ void beam_slab_kernel(BeamArgs g) {
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            if (g.stop_at && (i & 63u) == 63u && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
+            if (SPEC && (i & 63u) == 63u && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
             const uint32_t cbeg = cm_cur.cbeg, L = cm_cur.L;
             const uint32_t first_rel = sm_cur.first - pos0;
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
@@ -722,7 +723,10 @@ void beam_slab_kernel(BeamArgs g) {
                     if (CODES) {
                         // the position's A sums come in together (one 16-B piece for biallelic data): add the read's weight, store the changed
                         // sum, and refresh the position's code byte from the new sums
-                        constexpr int AU = 4;
+#ifndef FLORIA_SLAB_AU
+#define FLORIA_SLAB_AU 4
+#endif
+                        constexpr int AU = FLORIA_SLAB_AU;       // read-modify-writes in flight per lane and pass (a step has ~125 of them over 64 lanes)
                         for (uint32_t x0 = 0; x0 < items; x0 += 64 * AU) {
                             uint32_t w[AU], al[AU]; uint64_t* base[AU]; uint8_t* cptr[AU];
 #pragma unroll
@@ -790,8 +794,8 @@ void beam_slab_kernel(BeamArgs g) {
             start_rel = first_rel;
         }
 
-        if (dropped) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }     // (an LDS-DMA of the next read may still be in flight)
-        if (n > 0 && !dropped) {
+        if (SPEC && dropped) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }     // (an LDS-DMA of the next read may still be in flight)
+        if (n > 0 && !(SPEC && dropped)) {
             H.hp_id = lane;
             uint32_t ecur = H.sorted_first();
             uint8_t* out = g.part_out + roff;

@@ -536,11 +536,18 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
                         else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(slots), dim3(64), q.WL.total, st, a); }
                     } else if (q.slab) {
-                        if (any_q0) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                        else if (q.beam_spec && p == 2) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
-                        else if (q.beam_spec && p == 3) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
-                        else if (q.beam_spec && p == 4) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
-                        else if (q.beam_spec && p == 5) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), q.SL.total, st, a);
+                        const bool sp = a.stop_at != nullptr;      // speculative stage: the instances that can drop a job
+                        if (any_q0) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                      else hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                        else if (q.beam_spec && p == 2) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                        else if (q.beam_spec && p == 3) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                        else if (q.beam_spec && p == 4) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                        else if (q.beam_spec && p == 5) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                        else if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, false, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
                         else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), q.SL.total, st, a);
                     } else {
                         HIPCHK(big_lds((const void*)fl::beam_kernel<A>, q.LY.total));
