@@ -17,10 +17,12 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <utility>
 #include <vector>
 
@@ -153,20 +155,45 @@ struct VcfProfile {          // types_structs.rs:53-58, per contig; plus get_gen
     std::map<std::string, std::map<SnpPosition, GnPosition>> vcf_snp_pos_to_gn_pos_map;
     std::map<std::string, std::vector<GnPosition>> snp_to_genome_pos;
 };
+// A record is a set of views into the inflated BAM stream the BamFile keeps alive: nothing is copied or unpacked per record
+// (200 k long reads = 2 GB of bases; a per-record std::string each made the parallel decode slower than the serial one).
+struct BamSeqView {                    // SEQ, 4 bits per base
+    const unsigned char* packed = nullptr; size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    char operator[](size_t k) const { const unsigned char b = packed[k >> 1]; return "=ACMGRSVTWYHKDBN"[(k & 1) ? (b & 15) : (b >> 4)]; }
+};
+struct BamBytesView {                  // QUAL
+    const uint8_t* p = nullptr; size_t n = 0;
+    size_t size() const { return n; }
+    uint8_t operator[](size_t k) const { return p[k]; }
+};
+struct BamCigarView {                  // n x u32 (len << 4 | op), possibly unaligned
+    const unsigned char* p = nullptr; size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint32_t operator[](size_t k) const { uint32_t v; memcpy(&v, p + 4 * k, 4); return v; }
+};
 struct BamRecord {
     int32_t tid = -1, pos = 0;
     uint8_t mapq = 0;
     uint16_t flags = 0;
-    std::string qname;
-    std::vector<uint32_t> cigar;       // len << 4 | op
-    std::string seq;                   // ASCII bases
-    std::vector<uint8_t> qual;
+    std::string_view qname;
+    BamCigarView cigar;
+    BamSeqView seq;                    // ASCII bases through operator[]
+    BamBytesView qual;
 };
 struct BamFile {
+    std::vector<unsigned char> raw;    // the inflated stream (the records point into it: a BamFile may be moved, not copied)
     std::vector<std::string> target_names;
     std::vector<uint64_t> target_len;
     std::vector<BamRecord> records;    // file order
     std::vector<std::vector<uint32_t>> by_tid;     // record indices per target, file order (what an indexed fetch() of the contig yields)
+    BamFile() = default;
+    BamFile(BamFile&&) = default;
+    BamFile& operator=(BamFile&&) = default;
+    BamFile(const BamFile&) = delete;
+    BamFile& operator=(const BamFile&) = delete;
 };
 BamFile read_bam(const std::string& path, size_t threads = 1);                         // BGZF + BAM, whole file (no index needed); members and records decode in parallel
 std::vector<std::string> get_contigs_to_phase(const BamFile& bam);                     // file_reader.rs:738-746

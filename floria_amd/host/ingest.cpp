@@ -181,7 +181,7 @@ inline bool consumes_r(int op) { return op == 0 || op == 2 || op == 3 || op == 7
 
 int64_t reference_end(const BamRecord& r) {                 // bam_endpos
     int64_t len = 0;
-    for (uint32_t c : r.cigar) if (consumes_r(cig_op(c))) len += cig_len(c);
+    for (size_t k = 0; k < r.cigar.size(); ++k) { const uint32_t c = r.cigar[k]; if (consumes_r(cig_op(c))) len += cig_len(c); }
     return (int64_t)r.pos + (len ? len : 1);
 }
 
@@ -189,7 +189,7 @@ int64_t reference_end(const BamRecord& r) {                 // bam_endpos
 Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPosition>& snp_positions, const std::map<GnPosition, std::vector<Genotype>>& pos_allele_map, size_t counter_id,
                       bool keep_sequences) {
     Frag frag;
-    frag.id = rec.qname; frag.counter_id = counter_id;
+    frag.id = std::string(rec.qname); frag.counter_id = counter_id;
     frag.is_paired = (rec.flags & F_PAIRED1) || (rec.flags & F_PAIRED2);
     frag.first_position = UINT32_MAX; frag.last_position = 0;
     size_t leading_hardclips = 0;
@@ -200,7 +200,8 @@ Frag frag_from_record(const BamRecord& rec, const std::map<GnPosition, SnpPositi
     int64_t r = rec.pos;
     // the SNPs of the contig the alignment spans: walk them together with the CIGAR (positions ascend in both)
     auto snp_it = snp_positions.lower_bound((GnPosition)std::max<int64_t>(0, r));
-    for (uint32_t c : rec.cigar) {
+    for (size_t ck = 0; ck < rec.cigar.size(); ++ck) {
+        const uint32_t c = rec.cigar[ck];
         const int op = cig_op(c);
         const uint32_t len = cig_len(c);
         if (op == 0 || op == 7 || op == 8) {                                   // aligned pairs (Some(q), Some(r))
@@ -271,7 +272,7 @@ int nw_affine_score(const unsigned char* q, int nq, const unsigned char* r, int 
 // alignment::realign (alignment.rs:7-64)
 // `queue`: calls the exact shortcut cannot decide are not scored here but appended to the queue (windows + where the result goes) for
 // floria_hip_realign, the same DP on the device; null = score them on the host (--ingest-only, tests)
-void realign(const std::string& ref_gn, Frag& frag, const std::string& read_seq, const std::map<SnpPosition, GnPosition>& var_to_gn_pos,
+void realign(const std::string& ref_gn, Frag& frag, const BamSeqView& read_seq, const std::map<SnpPosition, GnPosition>& var_to_gn_pos,
              const std::map<GnPosition, std::vector<Genotype>>& gn_pos_to_allele, RealignQueue* queue) {
     constexpr size_t flank = 16;
     for (auto& kv : frag.seq_dict) {
@@ -329,7 +330,9 @@ BamFile read_bam(const std::string& path, size_t threads) {
     const std::vector<unsigned char> packed = slurp(path);
     if (trace) fprintf(stderr, "[read_bam] file %.3fs (%zu MiB)\n", now() - t0, packed.size() >> 20);
     t0 = now();
-    const std::vector<unsigned char> raw = bgzf_inflate_all(packed, path, threads);
+    BamFile bam;
+    bam.raw = bgzf_inflate_all(packed, path, threads);
+    const std::vector<unsigned char>& raw = bam.raw;
     if (trace) fprintf(stderr, "[read_bam] inflate %.3fs (%zu MiB)\n", now() - t0, raw.size() >> 20);
     t0 = now();
     Cursor c{raw.data(), raw.size(), 0, path};
@@ -338,7 +341,6 @@ BamFile read_bam(const std::string& path, size_t threads) {
     c.o = 4;
     const uint32_t l_text = c.u32(); c.need(l_text); c.o += l_text;
     const uint32_t n_ref = c.u32();
-    BamFile bam;
     for (uint32_t i = 0; i < n_ref; ++i) {
         const uint32_t l_name = c.u32(); c.need(l_name);
         bam.target_names.emplace_back((const char*)raw.data() + c.o, l_name ? l_name - 1 : 0); c.o += l_name;
@@ -356,7 +358,6 @@ BamFile read_bam(const std::string& path, size_t threads) {
     bam.records.resize(rec_off.size() - 1);
     const size_t per = 256;
     parallel_tasks((bam.records.size() + per - 1) / per, threads, [&](size_t t) {
-        static const char* SEQ16 = "=ACMGRSVTWYHKDBN";
         for (size_t i = t * per; i < std::min(bam.records.size(), (t + 1) * per); ++i) {
             Cursor d{raw.data(), rec_off[i + 1] - 4, rec_off[i], path};             // (bounded by the record's own end)
             BamRecord& r = bam.records[i];
@@ -364,15 +365,11 @@ BamFile read_bam(const std::string& path, size_t threads) {
             const uint8_t l_read_name = d.u8(); r.mapq = d.u8(); (void)d.u16();
             const uint16_t n_cigar = d.u16(); r.flags = d.u16();
             const uint32_t l_seq = d.u32(); (void)d.i32(); (void)d.i32(); (void)d.i32();
-            d.need(l_read_name); r.qname.assign((const char*)raw.data() + d.o, l_read_name ? l_read_name - 1 : 0); d.o += l_read_name;
-            r.cigar.resize(n_cigar);
-            for (uint16_t k = 0; k < n_cigar; ++k) r.cigar[k] = d.u32();
+            d.need(l_read_name); r.qname = std::string_view((const char*)raw.data() + d.o, l_read_name ? l_read_name - 1 : 0); d.o += l_read_name;
+            d.need((size_t)4 * n_cigar); r.cigar = BamCigarView{raw.data() + d.o, n_cigar}; d.o += (size_t)4 * n_cigar;
             d.need((size_t)(l_seq + 1) / 2 + l_seq);
-            r.seq.resize(l_seq);
-            for (uint32_t k = 0; k + 1 < l_seq; k += 2) { const unsigned char b = raw[d.o + k / 2]; r.seq[k] = SEQ16[b >> 4]; r.seq[k + 1] = SEQ16[b & 15]; }
-            if (l_seq & 1) r.seq[l_seq - 1] = SEQ16[raw[d.o + l_seq / 2] >> 4];
-            d.o += (l_seq + 1) / 2;
-            r.qual.assign(raw.data() + d.o, raw.data() + d.o + l_seq);              // (auxiliary tags are not needed)
+            r.seq = BamSeqView{raw.data() + d.o, l_seq}; d.o += (l_seq + 1) / 2;
+            r.qual = BamBytesView{raw.data() + d.o, l_seq};                         // (auxiliary tags are not needed)
         }
     });
     for (size_t i = 0; i < bam.records.size(); ++i) {
@@ -482,8 +479,8 @@ ContigIngest::ContigIngest(const BamFile& bam, const VcfProfile& vp, const Optio
         const BamRecord& rec = bam.records[rec_ix];
         const size_t this_count = count++;
         if (!alignment_passed_check(rec.flags, rec.mapq, use_supplementary, filter_supplementary, o.mapq_cutoff).first) continue;
-        auto ins = name_ix.emplace(rec.qname, names.size());
-        if (ins.second) { names.push_back(rec.qname); buckets.emplace_back(); }
+        auto ins = name_ix.emplace(std::string(rec.qname), names.size());
+        if (ins.second) { names.emplace_back(rec.qname); buckets.emplace_back(); }
         Frag fr = frag_from_record(rec, snp_positions, pos_allele_map, this_count, o.output_reads);
         if (ref_seq) realign(*ref_seq, fr, rec.seq, snp_to_gn, pos_allele_map, queue);             // :416-423
         buckets[ins.first->second].push_back({rec.flags, std::move(fr)});
@@ -579,7 +576,8 @@ std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam) {
     bool done = false;
     auto base_at = [](const BamRecord& r, int64_t pos, char* base) -> bool {          // false: deletion / refskip / not aligned here
         size_t q = 0; int64_t ref = r.pos;
-        for (uint32_t c : r.cigar) {
+        for (size_t ck = 0; ck < r.cigar.size(); ++ck) {
+            const uint32_t c = r.cigar[ck];
             const int op = cig_op(c); const int64_t len = cig_len(c);
             if (consumes_r(op) && pos < ref + len) {
                 if (!(op == 0 || op == 7 || op == 8)) return false;
