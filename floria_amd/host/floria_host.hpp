@@ -15,6 +15,7 @@
 // Where the reference panics or exits (malformed VCF positions, :422-425) these functions throw floria::Error carrying the
 // library's message.  There is no CPU fallback: constructing a Session without a usable MI355X throws.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -64,12 +65,51 @@ struct Options {
     int device = 0;
 };
 
-// types_structs.rs:68-85 (the fields the hot path reads); ordered maps: positions ascend
+// The per-read maps of the reference's Frag (FxHashMap<SnpPosition, _>, types_structs.rs:72-84) as a sorted vector with std::map's
+// interface: a read has ~100 entries, inserted in ascending order by the CIGAR walk — one allocation instead of one tree node per entry
+// (std::map made the ingest of 200 k long reads spend its time in malloc/free: 53 M nodes), iteration ascends like the BTreeMap-like uses need.
+template <class K, class V> class FlatMap {
+public:
+    typedef std::pair<K, V> value_type;
+    typedef typename std::vector<value_type>::iterator iterator;
+    typedef typename std::vector<value_type>::const_iterator const_iterator;
+    typedef typename std::vector<value_type>::const_reverse_iterator const_reverse_iterator;
+    iterator begin() { return v_.begin(); }
+    iterator end() { return v_.end(); }
+    const_iterator begin() const { return v_.begin(); }
+    const_iterator end() const { return v_.end(); }
+    const_reverse_iterator rbegin() const { return v_.rbegin(); }
+    const_reverse_iterator rend() const { return v_.rend(); }
+    size_t size() const { return v_.size(); }
+    bool empty() const { return v_.empty(); }
+    void clear() { v_.clear(); }
+    iterator lower_bound(const K& k) { return std::lower_bound(v_.begin(), v_.end(), k, [](const value_type& a, const K& b) { return a.first < b; }); }
+    const_iterator lower_bound(const K& k) const { return std::lower_bound(v_.begin(), v_.end(), k, [](const value_type& a, const K& b) { return a.first < b; }); }
+    iterator upper_bound(const K& k) { return std::upper_bound(v_.begin(), v_.end(), k, [](const K& a, const value_type& b) { return a < b.first; }); }
+    const_iterator upper_bound(const K& k) const { return std::upper_bound(v_.begin(), v_.end(), k, [](const K& a, const value_type& b) { return a < b.first; }); }
+    iterator find(const K& k) { iterator it = lower_bound(k); return it != v_.end() && it->first == k ? it : v_.end(); }
+    const_iterator find(const K& k) const { const_iterator it = lower_bound(k); return it != v_.end() && it->first == k ? it : v_.end(); }
+    size_t count(const K& k) const { return find(k) != v_.end() ? 1 : 0; }
+    V& operator[](const K& k) {
+        if (v_.empty() || v_.back().first < k) { v_.emplace_back(k, V()); return v_.back().second; }
+        iterator it = lower_bound(k);
+        if (it != v_.end() && it->first == k) return it->second;
+        return v_.insert(it, value_type(k, V()))->second;
+    }
+    V& at(const K& k) { iterator it = find(k); if (it == v_.end()) throw std::out_of_range("FlatMap::at"); return it->second; }
+    const V& at(const K& k) const { const_iterator it = find(k); if (it == v_.end()) throw std::out_of_range("FlatMap::at"); return it->second; }
+    iterator erase(iterator it) { return v_.erase(it); }
+    size_t erase(const K& k) { iterator it = find(k); if (it == v_.end()) return 0; v_.erase(it); return 1; }
+private:
+    std::vector<value_type> v_;
+};
+
+// types_structs.rs:68-85 (the fields the hot path reads); ordered (flat) maps: positions ascend
 struct Frag {
     std::string id;
     size_t counter_id = 0;
-    std::map<SnpPosition, Genotype> seq_dict;
-    std::map<SnpPosition, uint8_t> qual_dict;
+    FlatMap<SnpPosition, Genotype> seq_dict;
+    FlatMap<SnpPosition, uint8_t> qual_dict;
     SnpPosition first_position = UINT32_MAX, last_position = 0;
     // the fields ingest fills for the writers (types_structs.rs:80-84)
     bool is_paired = false;
@@ -77,7 +117,7 @@ struct Frag {
     size_t seq_len[2] = {0, 0};                                          // bases of seq_string[0], seq_string[1]
     std::string seq_string[2];                                           // only kept with --output-reads: DnaString::from_acgt_bytes of SEQ (anything but ACGT -> A)
     std::vector<uint8_t> qual_string[2];                                 // QUAL + 33
-    std::map<SnpPosition, std::pair<uint8_t, GnPosition>> snp_pos_to_seq_pos;
+    FlatMap<SnpPosition, std::pair<uint8_t, GnPosition>> snp_pos_to_seq_pos;
     void update(SnpPosition snp_pos, Genotype geno, uint8_t qual) {      // update_frag, types_structs.rs:286-324
         seq_dict[snp_pos] = geno; qual_dict[snp_pos] = qual;
         if (snp_pos < first_position) first_position = snp_pos;

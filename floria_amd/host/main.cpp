@@ -319,11 +319,18 @@ int main(int argc, char** argv) {
             });
             for (const std::string& r : rows) append_contig_ploidy_row(o, r);
             t_write += now_s() - t0;
+            // the Frags of a batch are millions of small objects: freeing them goes to a thread of its own, the next batch's ingest does not wait for it
+            std::thread([w = std::make_shared<std::vector<ContigWork>>(std::move(work))]() mutable { w.reset(); }).detach();
         }
         fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
         fprintf(stderr, "Total time taken is %.3fs\n", now_s() - t_all);
+        // everything is written and closed: leave without tearing down the records, maps and sequences one by one (seconds for a large BAM)
+        if (dump.is_open()) dump.close();
+        session_holder.reset();
+        fflush(nullptr);
+        std::_Exit(0);
     } catch (const Error& e) {
         fprintf(stderr, "floria-hip: error: %s\n", e.what());
         return 1;
