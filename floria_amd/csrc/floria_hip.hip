@@ -135,7 +135,7 @@ BigCache g_big;
 // ONCE, at floria_hip_create (FLORIA_HIP_GROUPS, FLORIA_HIP_BEAM=generic|slab|wide, FLORIA_HIP_NO_SPECIALIZED, FLORIA_HIP_NO_P1_SHORTCUT,
 // FLORIA_HIP_OPT_THREADS, FLORIA_HIP_OPT_GLOBAL, FLORIA_HIP_SPECULATE); none of them changes results.
 struct Knobs {
-    uint32_t groups = 0;          // job groups (0 = auto: 2 when the batch has >= 2048 non-empty blocks)
+    uint32_t groups = 0;          // job groups (0 = auto: 2 when the batch has >= 48 x CUs non-empty blocks)
     uint32_t beam_path = 0;       // 0 auto | 1 generic | 2 slab | 3 wide
     uint32_t no_specialized = 0;  // runtime ploidy / beam width instead of the template instances
     uint32_t no_p1_shortcut = 0;  // run the beam kernel for ploidy 1 too
@@ -1246,7 +1246,9 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     // job groups (longest-first inside each group).  Resident inputs: dealt round-robin so every group sees the same size mix.
     // Chunked inputs (cells still arriving): group g = the blocks of chunk g, whose stream waits for the chunk's event.
     const bool chunked = SC.chunk_ev != nullptr && SC.n_chunks > 1;
-    uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : 2;
+    // (measured, config 4, resident: one group wins while a stage has less than three rounds of jobs — 750 / 1000 / 1500 contigs: 55 / 61.5 / 80.5 ms against
+    // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms)
+    uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 48 ? 2 : 1);
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
     if (chunked) G = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
     std::vector<uint32_t> group_off(G + 1, 0);

@@ -380,11 +380,11 @@ def test_bench_scale_properties(gpu_ctx, hip_lib, oracle_mod, monkeypatch):
     for i, c in enumerate(contigs):
         s, e = hip_lib.get_range_with_lengths(c.snp_pos, 10000)
         bc += [i] * len(s); bs += list(s); be += list(e)
-    assert len(bc) >= 2048                                           # two job groups by default
+    assert len(bc) >= 2048                                           # enough blocks for two and three job groups (auto takes one below 48 x CUs blocks)
     gpu_ctx.set_option("groups", 1)
     one = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
     assert gpu_ctx.timing()["streams"] == 1
-    gpu_ctx.set_option("groups", 0)
+    gpu_ctx.set_option("groups", 2)
     two = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
     assert gpu_ctx.timing()["streams"] == 2
     gpu_ctx.set_option("groups", 3)
