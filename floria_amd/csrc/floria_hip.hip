@@ -146,6 +146,7 @@ struct Knobs {
     uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
     uint32_t spec_desc = 0;       // speculative stage: launch the highest ploidy first
+    uint32_t pipe_groups = 0;     // floria_hip_phase_pileups_batch: job groups of a chunked call (0 = one per chunk)
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
     bool spec_flat = false;       // (A/B) speculative stages without stream priorities and without the early stop-rule flags
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
@@ -676,6 +677,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
         K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
+        if (const char* v = getenv("FLORIA_HIP_PIPE_GROUPS")) K.pipe_groups = (uint32_t)std::max(0, std::min<int>(atoi(v), floria_hip_ctx::MAX_GROUPS));
         if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_DIV")) K.spec_gate_div = (uint32_t)std::max(1, std::min(16, atoi(v)));
         K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
@@ -724,6 +726,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
     else if (k == "opt_global") K.opt_global = value != 0;
+    else if (k == "pipe_groups") K.pipe_groups = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "spec_flat") K.spec_flat = value != 0;
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
@@ -1250,11 +1253,19 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms)
     uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 48 ? 2 : 1);
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
-    if (chunked) G = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
+    // chunked: consecutive chunks may share a job group (knob pipe_groups), which then starts when its LAST chunk has landed
+    std::vector<uint32_t> chunk_group;
+    hipEvent_t group_ev[floria_hip_ctx::MAX_GROUPS] = {};
+    if (chunked) {
+        const uint32_t nc = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
+        G = ctx->knobs.pipe_groups ? std::min<uint32_t>(ctx->knobs.pipe_groups, nc) : nc;
+        chunk_group.resize(SC.n_chunks);
+        for (uint32_t c = 0; c < SC.n_chunks; ++c) { chunk_group[c] = std::min<uint32_t>((uint32_t)((uint64_t)std::min(c, nc - 1) * G / nc), G - 1); group_ev[chunk_group[c]] = SC.chunk_ev[std::min(c, nc - 1)]; }
+    }
     std::vector<uint32_t> group_off(G + 1, 0);
     if (chunked) {
         std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
-        for (uint32_t g = 0; g < G; ++g) { for (uint32_t b : jobs) if (std::min(SC.contig_chunk[bc[b]], G - 1) == g) dealt.push_back(b); group_off[g + 1] = (uint32_t)dealt.size(); }
+        for (uint32_t g = 0; g < G; ++g) { for (uint32_t b : jobs) if (chunk_group[SC.contig_chunk[bc[b]]] == g) dealt.push_back(b); group_off[g + 1] = (uint32_t)dealt.size(); }
         jobs.swap(dealt);
     } else if (G > 1) {
         std::vector<uint32_t> dealt; dealt.reserve(jobs.size());
@@ -1338,7 +1349,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     bool p1_shortcut = false;
     auto run = nall == 2 ? run_phase<2> : run_phase<4>;
     rc = run(ctx, any_q0, bs, jobs, group_off, (const uint32_t*)(M + s_jobs.off), tot, n_max, span_max, prm, (uint8_t*)(M + s_planes.off),
-             (uint8_t*)(M + s_bpart.off), stages, chunked ? SC.chunk_ev : nullptr, (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
+             (uint8_t*)(M + s_bpart.off), stages, chunked ? group_ev : nullptr, (double*)(M + s_mec.off), (double*)(M + s_na.off), (uint32_t*)(M + s_it.off),
              (uint8_t*)(M + s_done.off), (uint32_t*)(M + s_best.off), (uint32_t*)(M + s_tried.off), (uint32_t*)(M + s_q.off),
              (double*)(M + s_margin.off), (uint32_t*)(M + s_diag.off), (unsigned long long*)(M + s_steps.off), T, p1_shortcut,
              (uint32_t*)(M + s_stop.off), (uint32_t*)(M + s_ready.off));

@@ -287,7 +287,7 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
  * the gate / priorities / early stop-rule flags), "spec_gate_div" (grid divisor of the gated ploidies, default 2), "beam_path" (0 auto,
  * 1 generic, 2 slab, 3 wide), "no_specialized", "no_p1_shortcut", "opt_threads" (0|128|512|1024), "opt_global",
  * "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload), "upload_chunks" (chunks of
- * floria_hip_phase_pileups_batch, 0 = auto). */
+ * floria_hip_phase_pileups_batch, 0 = auto), "pipe_groups" (job groups of a chunked call, 0 = one per chunk: measured best). */
 int  floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus
