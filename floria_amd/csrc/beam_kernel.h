@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
         if (job >= g.n_jobs) break;
         const uint32_t b = g.job_block[job];
         if (g.blk_done[b]) continue;
-        if (g.stop_at && __hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ploidy) continue;      // (speculative stages, see optimize_kernel.h)
+        if (g.stop_at && (uint32_t)__shfl((int)__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0) < g.ploidy) continue;      // (speculative stages, see optimize_kernel.h; lane 0's reading for the whole wave)
         min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];

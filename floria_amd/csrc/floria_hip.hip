@@ -1277,14 +1277,15 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     {
         int spec = ctx->knobs.speculate;
         const bool slab_path = P * prm->beam <= 63 && !ctx->knobs.beam_path;          // the wide-beam kernels own whole CUs: nothing to gain there
-        // (measured on config-4 shards, resident, with the gated high ploidies and the early stop-rule flags of run_phase: all ploidies at once wins up to
-        // ~3k blocks — 125 / 250 / 375 contigs: 21 / 24 / 32 ms against 38 / 41 / 44.5 ms — is level at 3.6k blocks — 500 contigs: 44-47 against 48.5 ms —
-        // and loses above — 750 contigs: 59-69 against 56 ms, the full 2000: 141-155 against 99 ms)
-        if (spec < 0) spec = (slab_path && P >= 3 && jobs.size() <= (size_t)ctx->n_cu * 12) ? 1 : 0;
+        // (measured on config-4 shards, resident, with the gated high ploidies and the early stop-rule flags of run_phase; ms for speculate = 0 / 1 / 2:
+        //   915 blocks 37.6 / 21.3 / 24.3   1822: 40.4 / 24.8 / 27.1   2724: 44.1 / 32.2 / 32.7   3636: 48.0 / 46.5 / 36.8   4543: 50.9 / 57.7 / 44.9
+        //   5455: 55.5 / 69.1 / 50.9   6348: 58.7 / 80.8 / 56.9   7249: 61.6 / - / 62.5   14503: 98.6 / 141-155 / 115.5)
+        // -> every ploidy at once up to 11 x CUs blocks, {1,2,3} then {4..P} up to 25 x CUs, one ploidy per stage above
+        if (spec < 0) spec = !(slab_path && P >= 3) ? 0 : jobs.size() <= (size_t)ctx->n_cu * 11 ? 1 : (jobs.size() <= (size_t)ctx->n_cu * 25 && P >= 4) ? 2 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
         // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
-        if (ctx->knobs.speculate < 0 && spec && P * G > 10) spec = 0;
+        if (ctx->knobs.speculate < 0 && spec) { const uint32_t w = spec == 1 ? P : std::max<uint32_t>(std::min(3u, P), P > 3 ? P - 3 : 0); if (w * G > 10) spec = 0; }
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
                               if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
@@ -1467,8 +1468,14 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     // auto: ~0.5 GB of host pileup per chunk, at most 5 (measured on BASELINE config 4, 2.65 GB: 5 chunks, the first one half-size, are best)
     const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (200ull << 20)));
     // (measured, config 4, H2D-inclusive: 500 contigs / 0.66 GB: 2 chunks 60.5 ms, 3-4 chunks 56.5; 1000 contigs / 1.33 GB: 2 chunks 86 ms, 4-5 chunks 77; 2000 contigs: 5 chunks)
+    // batches small enough for speculative ploidy stages (s1_core) keep chunk groups x stage width within the hardware queues
     UploadPlan UP;
-    int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(want_chunks, floria_hip_ctx::MAX_GROUPS), UP);
+    uint32_t chunk_cap = floria_hip_ctx::MAX_GROUPS;
+    if (!ctx->knobs.upload_chunks && ctx->knobs.speculate < 0 && prm->max_ploidy >= 3) {
+        if (n_blocks <= (uint32_t)ctx->n_cu * 11) chunk_cap = std::max<uint32_t>(1, 10 / prm->max_ploidy);
+        else if (n_blocks <= (uint32_t)ctx->n_cu * 25 && prm->max_ploidy >= 4) chunk_cap = std::max<uint32_t>(1, 10 / std::max<uint32_t>(3, prm->max_ploidy - 3));
+    }
+    int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(std::min(want_chunks, chunk_cap), floria_hip_ctx::MAX_GROUPS), UP);
     if (rc) return rc;
     std::vector<floria_hip_contig*> handles(n_contigs, nullptr);
     auto drop = [&](int code) { sync_all(ctx); for (auto* h : handles) if (h) { h->arena = nullptr; delete h; } arena_put(UP.A); return code; };

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     __shared__ uint64_t s_errq[MAX_PLOIDY], s_goodq[MAX_PLOIDY];
     __shared__ uint32_t s_errm[MAX_PLOIDY];
     __shared__ uint32_t s_size[MAX_PLOIDY];
-    __shared__ uint32_t s_ncand, s_nmoves, s_job;
+    __shared__ uint32_t s_ncand, s_nmoves, s_job, s_skip;
     __shared__ uint32_t s_chg_lo, s_chg_hi;          // positions whose code byte changed in the last batch of moves (HL)
     __shared__ double s_score;
     uint32_t* s_moved = (uint32_t*)smem;
@@ -153,13 +153,19 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) s_job = atomicAdd(g.queue_head, 1u);
+        if (tid == 0) {
+            const uint32_t j0 = atomicAdd(g.queue_head, 1u);
+            s_job = j0;
+            // stop_at[] changes while this launch runs (other workgroups publish their blocks' stop rule): ONE thread reads it and the
+            // workgroup acts on that value — threads reading it separately could disagree and part ways around the barriers below
+            s_skip = (j0 < g.n_jobs && g.stop_at && __hip_atomic_load(&g.stop_at[g.job_block[j0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) ? 1u : 0u;
+        }
         __syncthreads();
         const uint32_t job = s_job;
         if (job >= g.n_jobs) break;
         const uint32_t b = g.job_block[job];
-        if (g.blk_done[b]) continue;
-        if (g.stop_at && __hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) continue;      // (uniform: every thread reads the same word)
+        if (g.blk_done[b]) continue;                    // (written only by the workgroup that owns block b in a launch: the same for every thread)
+        if (s_skip) continue;
         const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
         const uint64_t roff = g.bs.blk_read_off[b];
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
