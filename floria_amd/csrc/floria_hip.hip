@@ -166,6 +166,7 @@ struct floria_hip_ctx {
     hipStream_t gstream[MAX_LANES] = {};
     hipStream_t gstream_low[MAX_LANES] = {};      // speculative stages: the lanes of ploidy >= 4 (dispatched after the ploidies every block needs)
     hipEvent_t ev_fork[MAX_LANES] = {}, ev_join[MAX_LANES] = {};
+    hipEvent_t ev_chain[MAX_GROUPS][FLORIA_MAX_PLOIDY + 2] = {};   // speculate = 4: the beam search of (group, ploidy) has finished (ploidy + 1 starts behind it)
     hipEvent_t ev_gate[MAX_GROUPS] = {};       // speculative stages: the beam search of ploidy 2 of group g has finished (ploidies >= 4 start behind it)
     hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
     hipEvent_t ev_rids = nullptr;
@@ -523,7 +524,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
-                    const bool gated = stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p >= 4;
+                    const bool chained = K.speculate == 4 && stage.size() > 1;      // every ploidy >= 3 behind the beam search of the one below, pruned by the stop flags
+                    if (chained && p >= 3 && ctx->ev_chain[g][p - 1]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_chain[g][p - 1], 0));
+                    const bool gated = !chained && stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p >= 4;
                     // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
                     // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
                     const uint32_t slots = gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
@@ -557,7 +560,11 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     T.end(t);
                     HIPCHK(hipGetLastError());
                     ctx->timing.beam_launches++;
-                    if (stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p == 2) {
+                    if (chained && p >= 2) {
+                        if (!ctx->ev_chain[g][p]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_chain[g][p], hipEventDisableTiming));
+                        HIPCHK(hipEventRecord(ctx->ev_chain[g][p], st));
+                    }
+                    if (!chained && stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p == 2) {
                         if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
                         HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
                     }
@@ -672,7 +679,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
-        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(3, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(4, atoi(v)));
         if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(4, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
@@ -698,6 +705,7 @@ void floria_hip_destroy(floria_hip_ctx* c) {
         if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
         if (c->gstream_low[g]) (void)hipStreamDestroy(c->gstream_low[g]);
         if (g < floria_hip_ctx::MAX_GROUPS && c->ev_gate[g]) (void)hipEventDestroy(c->ev_gate[g]);
+        if (g < floria_hip_ctx::MAX_GROUPS) for (hipEvent_t e2 : c->ev_chain[g]) if (e2) (void)hipEventDestroy(e2);
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
         if (c->ev_fork[g]) (void)hipEventDestroy(c->ev_fork[g]);
     }
@@ -729,7 +737,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "pipe_groups") K.pipe_groups = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "spec_flat") K.spec_flat = value != 0;
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
-    else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
+    else if (k == "speculate") { if (value < -1 || value > 4) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3 | 4"); K.speculate = (int32_t)value; }
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 4));
     else if (k == "trace") K.trace = value != 0;
@@ -1286,7 +1294,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
         // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
         if (ctx->knobs.speculate < 0 && spec) { const uint32_t w = spec == 1 ? P : std::max<uint32_t>(std::min(3u, P), P > 3 ? P - 3 : 0); if (w * G > 10) spec = 0; }
-        if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
+        if (spec == 1 || spec == 4) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
                               if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
         else if (spec == 3) { stages.emplace_back(); for (uint32_t p = 1; p < P; ++p) stages.back().push_back(p); stages.push_back({P}); }

@@ -283,7 +283,7 @@ int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
 
 /* Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy
- * stages: -1 auto, 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}), "spec_flat" (1: speculative stages without
+ * stages: -1 auto, 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}, 3 {1..P-1} then {P}, 4 chained: measured, not used by auto), "spec_flat" (1: speculative stages without
  * the gate / priorities / early stop-rule flags), "spec_gate_div" (grid divisor of the gated ploidies, default 2), "beam_path" (0 auto,
  * 1 generic, 2 slab, 3 wide), "no_specialized", "no_p1_shortcut", "opt_threads" (0|128|512|1024), "opt_global",
  * "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload), "upload_chunks" (chunks of
