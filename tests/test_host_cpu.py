@@ -370,3 +370,11 @@ def test_hand_built_alignments_flags_cigar_ops_and_supplementary_merging(floria_
     got_d, _ = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10", "--no-realign"))
     e = {g["name"]: g for g in got_d["c"]["reads"]}["E_supp_far"]
     assert [(c[0], c[1]) for c in e["cells"]] == [(1, 1), (2, 1), (61, 1), (62, 1)] and e["span"] == (900, 1600)
+
+
+def test_flatmap_behaves_like_std_map():
+    # the Frag maps are sorted vectors with std::map's interface (floria_host.hpp: FlatMap): random operations against std::map
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.check_call(["make", "-C", cpp, "-B", "flatmap_test"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(cpp, "flatmap_test")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
