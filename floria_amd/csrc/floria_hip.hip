@@ -147,6 +147,7 @@ struct Knobs {
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
     uint32_t spec_desc = 0;       // speculative stage: launch the highest ploidy first
     uint32_t pipe_groups = 0;     // floria_hip_phase_pileups_batch: job groups of a chunked call (0 = one per chunk)
+    uint32_t spec_gate_p = 2;     // speculative stages: the ploidy whose finished beam search opens the gate for ploidies >= 4
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
     bool spec_flat = false;       // (A/B) speculative stages without stream priorities and without the early stop-rule flags
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
@@ -564,7 +565,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         if (!ctx->ev_chain[g][p]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_chain[g][p], hipEventDisableTiming));
                         HIPCHK(hipEventRecord(ctx->ev_chain[g][p], st));
                     }
-                    if (!chained && stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p == 2) {
+                    if (!chained && stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p == K.spec_gate_p) {
                         if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
                         HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
                     }
@@ -685,6 +686,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
         K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_PIPE_GROUPS")) K.pipe_groups = (uint32_t)std::max(0, std::min<int>(atoi(v), floria_hip_ctx::MAX_GROUPS));
+        if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_P")) K.spec_gate_p = atoi(v) == 3 ? 3 : 2;
         if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_DIV")) K.spec_gate_div = (uint32_t)std::max(1, std::min(16, atoi(v)));
         K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
