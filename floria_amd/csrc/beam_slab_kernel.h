@@ -63,6 +63,7 @@ __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
 // at least 0.5/d away from every integer, while the float error (1-ulp reciprocal, one product) is < 4e-7 * x/d < 0.42/d
 __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return (uint32_t)(((float)x + 0.5f) * rcp_d); }
 constexpr int SLAB_NS_MAX = 512;
+template <int N> struct IC { static constexpr int value = N; };
 constexpr int SLAB_DUMMY_WORDS = 64 * FLORIA_MAX_ALLELES * 2 + 16;      // u32 words of per-slot scratch behind the traceback rows (host reserves them)
 constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
 #ifndef FLORIA_SLAB_U
@@ -270,9 +271,10 @@ void beam_slab_kernel(BeamArgs g) {
                 uint64_t b1 = 0, b2 = 0;
                 uint32_t snps[SLAB_TILE / 64];
 #pragma unroll
-                for (int u = 0; u < SLAB_TILE / 64; ++u) snps[u] = c_snp[lane + 64 * u];       // (stale words beyond tl are masked below)
+                for (int u = 0; u < SLAB_TILE / 64; ++u) { snps[u] = 0; if ((uint32_t)(64 * u) < tl) snps[u] = c_snp[lane + 64 * u]; }       // (stale words beyond tl are masked below)
 #pragma unroll
                 for (int u = 0; u < SLAB_TILE / 64; ++u) {
+                    if ((uint32_t)(64 * u) >= tl) break;
                     const uint32_t c = lane + 64 * u;
                     const bool in = c < tl && (int32_t)(snps[u] - pos0) <= hi_rel;
                     if (Q0) {
@@ -318,130 +320,185 @@ void beam_slab_kernel(BeamArgs g) {
 #ifdef FLORIA_PROF
             c_nlive += nlive; c_nin += nin; c_nstates += nstates; c_L += L;
 #endif
-            uint32_t Gs = 1, lgGs = 0;
-            while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
             const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
             const bool trunc = tend >= (int32_t)start_rel;            // some written position leaves the hash window this step
-            const uint32_t per = 64u >> lgGs;                   // slabs per pass
-            for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
-                const uint32_t li = l0 + (lane >> lgGs), sub = lane & (Gs - 1);
-                const bool act = li < nlive;
-                const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
-                uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
-                uint32_t m = 0;
-                {   // positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel] (in ~45 % of the steps, 1-2 positions).  The
-                    // multipliers depend on the position only, so they are requested together with the sums: one memory round trip, no
-                    // branch on the loaded value (a zero sum contributes zero).
-                    for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
+            if constexpr (!CODES) {
+                uint32_t Gs = 1, lgGs = 0;
+                while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
+                const uint32_t per = 64u >> lgGs;                   // slabs per pass
+                for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
+                    const uint32_t li = l0 + (lane >> lgGs), sub = lane & (Gs - 1);
+                    const bool act = li < nlive;
+                    const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
+                    uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
+                    uint32_t m = 0;
+                    {   // positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel] (in ~45 % of the steps, 1-2 positions).  The
+                        // multipliers depend on the position only, so they are requested together with the sums: one memory round trip, no
+                        // branch on the loaded value (a zero sum contributes zero).
+                        for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
+                            if (act) {
+                                uint64_t v[A], r1[A], r2[A], p1[A], p2[A];
+                                const char* vp = pool + (slab_off + (uint32_t)pr * pos_bytes);
+    #pragma unroll
+                                for (int h = 0; h < A / 2; ++h) { const ulonglong2 w2 = *(const ulonglong2*)(vp + 16 * h); v[2 * h] = w2.x; v[2 * h + 1] = w2.y; }
+    #pragma unroll
+                                for (int al = 0; al < A; ++al) {
+                                    const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al);
+                                    r1[al] = g.Rq1[hx]; r2[al] = g.Rq2[hx];
+                                    if (Q0) { p1[al] = g.Rp1[hx]; p2[al] = g.Rp2[hx]; }
+                                }
+    #pragma unroll
+                                for (int al = 0; al < A; ++al) {
+                                    const uint64_t qv = Q0 ? (v[al] & QMASK63) : v[al];
+                                    t1 += r1[al] * qv; t2 += r2[al] * qv;
+                                    if (Q0) { t1 += v[al] ? p1[al] : 0ull; t2 += v[al] ? p2[al] : 0ull; }
+                                }
+                            }
+                        }
+                    }
+                    uint32_t ps = 0, pd = 0;
+                    auto cell = [&](const ulonglong2* vv, uint32_t aw, uint32_t c, bool valid) {
+                        const uint32_t al = aw >> 28;
+                        const uint32_t w = aw & 0x0fffffffu;
+                        bool nonempty, same;
+                        uint64_t va;
+                        if (A == 2) {
+                            const uint64_t v0 = Q0 ? (vv[0].x & QMASK63) : vv[0].x, v1 = Q0 ? (vv[0].y & QMASK63) : vv[0].y;
+                            nonempty = (v0 | v1) != 0;
+                            // same <=> the read's allele holds the larger-or-equal sum <=> equal sums, or (allele == 1) != (v1 < v0); integer form
+                            // (sums are < 2^63, so the sign of the difference is the comparison) - hipcc turns the select form into 0/1 VGPR traffic
+                            const uint64_t d = v1 - v0;
+                            same = d == 0 || ((al ^ (uint32_t)(d >> 63)) & 1u) != 0;
+                            va = Q0 ? (al ? vv[0].y : vv[0].x) : 0;
+                        } else {
+                            uint64_t v[A];
+    #pragma unroll
+                            for (int x = 0; x < A; x += 2) { v[x] = vv[x / 2].x; v[x + 1] = vv[x / 2].y; }
+                            uint64_t mx = 0; va = 0;
+    #pragma unroll
+                            for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
+                            nonempty = mx != 0;
+                            same = (Q0 ? (va & QMASK63) : va) == mx;
+                        }
+                        ps += (nonempty && same) ? w : 0u;
+                        pd += (nonempty && !same) ? w : 0u;
+                        m += (valid && !nonempty) ? 1u : 0u;
+                        if (Q0) { const bool np = valid && !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
+                    };
+                    for (uint32_t t = 0; t < ntiles; ++t) {
+                        if (ntiles > 1) stage_tile(t);
+                        const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                        // SLAB_U independent 16-B loads in flight per lane; the loop is wave-uniform (invalid slots and idle lanes read
+                        // cell 0 of a slab with weight 0: no branches), and the next read is staged behind the first batch of loads
+                        if (act && !CODES) {
+                            for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_U * Gs) {
+                                uint32_t offs[SLAB_U], aws[SLAB_U];
+    #pragma unroll
+                                for (int u = 0; u < SLAB_U; ++u) {
+                                    const uint32_t c = c0 + u * Gs; const bool v = c < nin; const uint32_t cx = v ? c : 0;
+                                    offs[u] = (c_snp[cx] - pos0) * pos_bytes; aws[u] = v ? c_aw[cx] : 0;
+                                }
+                                ulonglong2 vv[SLAB_U][A / 2];
+    #pragma unroll
+                                for (int u = 0; u < SLAB_U; ++u) {
+                                    const char* cp = pool + (slab_off + offs[u]);
+    #pragma unroll
+                                    for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
+                                }
+                                ps = 0; pd = 0;
+    #pragma unroll
+                                for (int u = 0; u < SLAB_U; ++u) cell(vv[u], aws[u], c0 + u * Gs, c0 + u * Gs < nin);
+                                qs += ps; qd += pd;
+                            }
+                        }
+                        if (act && sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }   // cells beyond hi_rel (:45-48)
+                    }
+                    // segmented all-reduce over the Gs lanes of a slab (DPP, no LDS crossbar)
+                    qs = seg_sum_u64(qs, Gs); qd = seg_sum_u64(qd, Gs); m = seg_sum_u32(m, Gs);
+                    if (trunc) { t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs); }
+                    if (Q0) { np1 = seg_sum_u64(np1, Gs); np2 = seg_sum_u64(np2, Gs); }
+                    if (act && sub == 0) {
+                        r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m;
+                        if (trunc) { r_t1[li] = t1; r_t2[li] = t2; }
+                        if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
+                    }
+                }
+            } else {
+                // (1) positions leaving the hash window: [start_rel, first_rel) ∩ [.., hi_rel] — one step in six, 1-2 positions; Gs lanes per slab
+                if (trunc) {
+                    uint32_t Gs = 1, lgGs = 0;
+                    while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
+                    const uint32_t per = 64u >> lgGs;
+                    for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
+                        const uint32_t li = l0 + (lane >> lgGs), sub = lane & (Gs - 1);
+                        const bool act = li < nlive;
+                        const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
+                        uint64_t t1 = 0, t2 = 0;
+                        for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
+                            if (act) {
+                                uint64_t v[A], r1[A], r2[A];
+                                const char* vp = pool + (slab_off + (uint32_t)pr * pos_bytes);
+#pragma unroll
+                                for (int h = 0; h < A / 2; ++h) { const ulonglong2 w2 = *(const ulonglong2*)(vp + 16 * h); v[2 * h] = w2.x; v[2 * h + 1] = w2.y; }
+#pragma unroll
+                                for (int al = 0; al < A; ++al) { const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al); r1[al] = g.Rq1[hx]; r2[al] = g.Rq2[hx]; }
+#pragma unroll
+                                for (int al = 0; al < A; ++al) { t1 += r1[al] * v[al]; t2 += r2[al] * v[al]; }
+                            }
+                        }
+                        t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs);
+                        if (act && sub == 0) { r_t1[li] = t1; r_t2[li] = t2; }
+                    }
+                }
+                // (2) distances from the code bytes.  Gl = 64 / nlive lanes per slab (any integer, not a power of two: 6 live slabs get 10 lanes each, not 8),
+                // every lane walks ceil(nin / Gl) cells in batches of 2 / 4 / 6 / 8 independent byte loads chosen by the exact count, sums in 32 bits inside a
+                // batch, and the lanes of a slab combine through LDS atomics (3 instructions instead of a 4-stage DPP butterfly on three values)
+                for (uint32_t x = lane; x < nlive; x += 64) { r_qs[x] = 0; r_qd[x] = 0; r_m[x] = 0; }
+                const uint32_t Gl = nlive <= 64u ? div_small(64u, __builtin_amdgcn_rcpf((float)nlive)) : 1u;
+                const float rcp_gl = __builtin_amdgcn_rcpf((float)Gl);
+                for (uint32_t l0 = 0; l0 < nlive; l0 += 64u) {             // (one pass unless more than 64 slabs are live: then Gl == 1)
+                    const uint32_t lsl = div_small(lane, rcp_gl), sub = lane - lsl * Gl, li = l0 + lsl;
+                    const bool act = li < nlive;
+                    const uint8_t* const cbase = codes + (act ? (uint32_t)live_id[li] : 0u) * span_pad;
+                    uint64_t qs = 0, qd = 0;
+                    uint32_t m = 0;
+                    auto batch = [&](auto NC, uint32_t u0) {
+                        constexpr int N = decltype(NC)::value;
+                        uint32_t offs[N], aws[N], cdb[N]; bool vs[N];
+#pragma unroll
+                        for (int u = 0; u < N; ++u) {
+                            const uint32_t c = sub + (u0 + (uint32_t)u) * Gl; vs[u] = c < nin; const uint32_t cx = vs[u] ? c : 0u;
+                            offs[u] = c_snp[cx] - pos0; const uint32_t awr = c_aw[cx]; aws[u] = vs[u] ? awr : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < N; ++u) cdb[u] = cbase[offs[u]];
+                        uint32_t ps = 0, pt = 0, me = 0;
+#pragma unroll
+                        for (int u = 0; u < N; ++u) {
+                            const uint32_t w = aws[u] & 0x0fffffffu;
+                            ps += w & (uint32_t)__builtin_amdgcn_sbfe((int)cdb[u], aws[u] >> 28, 1u);      // bit `allele` of the code <=> same
+                            pt += cdb[u] ? w : 0u;                                                          // observed position
+                            me += (vs[u] && cdb[u] == 0u) ? 1u : 0u;
+                        }
+                        qs += ps; qd += pt - ps; m += me;
+                    };
+                    for (uint32_t t = 0; t < ntiles; ++t) {
+                        if (ntiles > 1) stage_tile(t);
+                        const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                        const uint32_t U = div_small(nin + Gl - 1u, rcp_gl);               // rounds of Gl cells
                         if (act) {
-                            uint64_t v[A], r1[A], r2[A], p1[A], p2[A];
-                            const char* vp = pool + (slab_off + (uint32_t)pr * pos_bytes);
-#pragma unroll
-                            for (int h = 0; h < A / 2; ++h) { const ulonglong2 w2 = *(const ulonglong2*)(vp + 16 * h); v[2 * h] = w2.x; v[2 * h + 1] = w2.y; }
-#pragma unroll
-                            for (int al = 0; al < A; ++al) {
-                                const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al);
-                                r1[al] = g.Rq1[hx]; r2[al] = g.Rq2[hx];
-                                if (Q0) { p1[al] = g.Rp1[hx]; p2[al] = g.Rp2[hx]; }
+                            for (uint32_t u0 = 0; u0 < U; u0 += 8u) {
+                                const uint32_t r = U - u0;
+                                if (r >= 7u) batch(IC<8>{}, u0); else if (r >= 5u) batch(IC<6>{}, u0); else if (r >= 3u) batch(IC<4>{}, u0); else batch(IC<2>{}, u0);
                             }
-#pragma unroll
-                            for (int al = 0; al < A; ++al) {
-                                const uint64_t qv = Q0 ? (v[al] & QMASK63) : v[al];
-                                t1 += r1[al] * qv; t2 += r2[al] * qv;
-                                if (Q0) { t1 += v[al] ? p1[al] : 0ull; t2 += v[al] ? p2[al] : 0ull; }
-                            }
+                            if (sub == 0) m += tl - nin;                        // cells beyond hi_rel (:45-48)
                         }
                     }
-                }
-                uint32_t ps = 0, pd = 0;
-                auto cell = [&](const ulonglong2* vv, uint32_t aw, uint32_t c, bool valid) {
-                    const uint32_t al = aw >> 28;
-                    const uint32_t w = aw & 0x0fffffffu;
-                    bool nonempty, same;
-                    uint64_t va;
-                    if (A == 2) {
-                        const uint64_t v0 = Q0 ? (vv[0].x & QMASK63) : vv[0].x, v1 = Q0 ? (vv[0].y & QMASK63) : vv[0].y;
-                        nonempty = (v0 | v1) != 0;
-                        // same <=> the read's allele holds the larger-or-equal sum <=> equal sums, or (allele == 1) != (v1 < v0); integer form
-                        // (sums are < 2^63, so the sign of the difference is the comparison) - hipcc turns the select form into 0/1 VGPR traffic
-                        const uint64_t d = v1 - v0;
-                        same = d == 0 || ((al ^ (uint32_t)(d >> 63)) & 1u) != 0;
-                        va = Q0 ? (al ? vv[0].y : vv[0].x) : 0;
-                    } else {
-                        uint64_t v[A];
-#pragma unroll
-                        for (int x = 0; x < A; x += 2) { v[x] = vv[x / 2].x; v[x + 1] = vv[x / 2].y; }
-                        uint64_t mx = 0; va = 0;
-#pragma unroll
-                        for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
-                        nonempty = mx != 0;
-                        same = (Q0 ? (va & QMASK63) : va) == mx;
+                    if (act) {
+                        atomicAdd((unsigned long long*)&r_qs[li], (unsigned long long)qs);
+                        atomicAdd((unsigned long long*)&r_qd[li], (unsigned long long)qd);
+                        atomicAdd(&r_m[li], m);
                     }
-                    ps += (nonempty && same) ? w : 0u;
-                    pd += (nonempty && !same) ? w : 0u;
-                    m += (valid && !nonempty) ? 1u : 0u;
-                    if (Q0) { const bool np = valid && !(va >> 63); np1 += np ? c_rp1[c] : 0ull; np2 += np ? c_rp2[c] : 0ull; }
-                };
-                for (uint32_t t = 0; t < ntiles; ++t) {
-                    if (ntiles > 1) stage_tile(t);
-                    const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
-                    // SLAB_U independent 16-B loads in flight per lane; the loop is wave-uniform (invalid slots and idle lanes read
-                    // cell 0 of a slab with weight 0: no branches), and the next read is staged behind the first batch of loads
-                    if (act && CODES) {
-                        // one code byte per (slab, cell): bit `allele` <=> same, 0 <=> empty position
-                        const uint8_t* const cbase = codes + (uint32_t)live_id[li] * span_pad;
-                        for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_CU * Gs) {
-                            uint32_t offs[SLAB_CU], aws[SLAB_CU], cd[SLAB_CU];
-#pragma unroll
-                            for (int u = 0; u < SLAB_CU; ++u) {
-                                const uint32_t c = c0 + u * Gs; const bool v = c < nin; const uint32_t cx = v ? c : 0;
-                                offs[u] = c_snp[cx] - pos0; aws[u] = v ? c_aw[cx] : 0;
-                            }
-#pragma unroll
-                            for (int u = 0; u < SLAB_CU; ++u) cd[u] = cbase[offs[u]];
-                            ps = 0; pd = 0;
-#pragma unroll
-                            for (int u = 0; u < SLAB_CU; ++u) {
-                                const uint32_t w = aws[u] & 0x0fffffffu;
-                                const bool same = ((cd[u] >> (aws[u] >> 28)) & 1u) != 0;
-                                ps += same ? w : 0u;
-                                pd += (cd[u] != 0 && !same) ? w : 0u;
-                                m += (c0 + u * Gs < nin && cd[u] == 0) ? 1u : 0u;
-                            }
-                            qs += ps; qd += pd;
-                        }
-                    }
-                    if (act && !CODES) {
-                        for (uint32_t c0 = sub; c0 < nin; c0 += SLAB_U * Gs) {
-                            uint32_t offs[SLAB_U], aws[SLAB_U];
-#pragma unroll
-                            for (int u = 0; u < SLAB_U; ++u) {
-                                const uint32_t c = c0 + u * Gs; const bool v = c < nin; const uint32_t cx = v ? c : 0;
-                                offs[u] = (c_snp[cx] - pos0) * pos_bytes; aws[u] = v ? c_aw[cx] : 0;
-                            }
-                            ulonglong2 vv[SLAB_U][A / 2];
-#pragma unroll
-                            for (int u = 0; u < SLAB_U; ++u) {
-                                const char* cp = pool + (slab_off + offs[u]);
-#pragma unroll
-                                for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
-                            }
-                            ps = 0; pd = 0;
-#pragma unroll
-                            for (int u = 0; u < SLAB_U; ++u) cell(vv[u], aws[u], c0 + u * Gs, c0 + u * Gs < nin);
-                            qs += ps; qd += pd;
-                        }
-                    }
-                    if (act && sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }   // cells beyond hi_rel (:45-48)
-                }
-                // segmented all-reduce over the Gs lanes of a slab (DPP, no LDS crossbar)
-                qs = seg_sum_u64(qs, Gs); qd = seg_sum_u64(qd, Gs); m = seg_sum_u32(m, Gs);
-                if (trunc) { t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs); }
-                if (Q0) { np1 = seg_sum_u64(np1, Gs); np2 = seg_sum_u64(np2, Gs); }
-                if (act && sub == 0) {
-                    r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m;
-                    if (trunc) { r_t1[li] = t1; r_t2[li] = t2; }
-                    if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of the next read has landed (hipcc does not track it)
@@ -723,11 +780,9 @@ void beam_slab_kernel(BeamArgs g) {
                     if (CODES) {
                         // the position's A sums come in together (one 16-B piece for biallelic data): add the read's weight, store the changed
                         // sum, and refresh the position's code byte from the new sums
-#ifndef FLORIA_SLAB_AU
-#define FLORIA_SLAB_AU 4
-#endif
-                        constexpr int AU = FLORIA_SLAB_AU;       // read-modify-writes in flight per lane and pass (a step has ~125 of them over 64 lanes)
-                        for (uint32_t x0 = 0; x0 < items; x0 += 64 * AU) {
+                        // up to 4 read-modify-writes in flight per lane and pass, exactly as many as the pass has (a step has ~105 of them over 64 lanes: 2)
+                        auto add_pass = [&](auto NC, uint32_t x0) {
+                            constexpr int AU = decltype(NC)::value;
                             uint32_t w[AU], al[AU]; uint64_t* base[AU]; uint8_t* cptr[AU];
 #pragma unroll
                             for (int u = 0; u < AU; ++u) {
@@ -766,6 +821,10 @@ void beam_slab_kernel(BeamArgs g) {
                                 }
                                 *cptr[u] = (uint8_t)code;
                             }
+                        };
+                        for (uint32_t x0 = 0; x0 < items; x0 += 256u) {
+                            const uint32_t r = items - x0;
+                            if (r > 192u) add_pass(IC<4>{}, x0); else if (r > 128u) add_pass(IC<3>{}, x0); else if (r > 64u) add_pass(IC<2>{}, x0); else add_pass(IC<1>{}, x0);
                         }
                     } else
                     for (uint32_t x0 = 0; x0 < items; x0 += 256) {
