@@ -64,6 +64,15 @@ __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
 __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return (uint32_t)(((float)x + 0.5f) * rcp_d); }
 constexpr int SLAB_NS_MAX = 512;
 template <int N> struct IC { static constexpr int value = N; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) { if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); } }
+// value of lane (segment base + J) for aligned segments of PS = 2 or 4 lanes: one DPP quad_perm move, no LDS crossbar round trip
+template <int PS, int J> __device__ __forceinline__ uint32_t seg_get(uint32_t v) {
+    if constexpr (PS == 2) return dpp_mov<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);
+    else return dpp_mov<J | (J << 2) | (J << 4) | (J << 6)>(v);
+}
+template <int PS, int J> __device__ __forceinline__ uint64_t seg_get64(uint64_t v) { return ((uint64_t)seg_get<PS, J>((uint32_t)(v >> 32)) << 32) | seg_get<PS, J>((uint32_t)v); }
+template <int PS, int J> __device__ __forceinline__ double seg_get_f64(double v) { return __longlong_as_double((long long)seg_get64<PS, J>((uint64_t)__double_as_longlong(v))); }
+template <int PS, int J> __device__ __forceinline__ float seg_get_f32(float v) { return __uint_as_float(seg_get<PS, J>(__float_as_uint(v))); }
 constexpr int SLAB_DUMMY_WORDS = 64 * FLORIA_MAX_ALLELES * 2 + 16;      // u32 words of per-slot scratch behind the traceback rows (host reserves them)
 constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
 #ifndef FLORIA_SLAB_U
@@ -166,12 +175,18 @@ void beam_slab_kernel(BeamArgs g) {
     uint8_t* const dummy_code = (uint8_t*)(dummy + 64 * A);
     const uint64_t lane_lt = (1ull << lane) - 1;
 
-    const uint32_t S = 64 / p;
+    // phase B: lane = (state, partition).  The instances with a compile-time ploidy of 2..4 give a state an aligned group of PS = 2 / 4 / 4 lanes
+    // (ploidy 3: every fourth lane idles), so that the sums and maxima over a state's partitions are DPP quad permutes instead of LDS shuffles
+    constexpr bool DPPSEG = TP >= 2 && TP <= 4;
+    constexpr uint32_t PSC = TP == 2 ? 2 : 4;
+    const uint32_t psl = DPPSEG ? PSC : p;
+    const uint32_t S = 64 / psl;
     const float rcp_p = __builtin_amdgcn_rcpf((float)p);
-    const uint32_t my_sl = lane / p, my_k = lane % p;
-    const bool lane_pair = my_sl < S;
+    const uint32_t my_sl = lane / psl, my_k = lane % psl;
+    const bool lane_pair = my_sl < S && my_k < p;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint64_t rk1 = c_rk1[my_k], rk2 = c_rk2[my_k];
-    const int seg0 = (int)(my_sl * p);
+    const int seg0 = (int)(my_sl * psl);
     double min_margin = 1e300;
     uint32_t n_fallback = 0;
 #ifdef FLORIA_PROF
@@ -210,7 +225,7 @@ void beam_slab_kernel(BeamArgs g) {
         if (lane < p) ST_sl(0)[lane] = 0;
         int32_t hi_rel = -1;
         uint32_t start_rel = 0;
-        RegHeap H; H.hp_s = 0; H.hp_id = 0; H.len = 0;
+        RegHeap H; H.hp_hi = 0; H.hp_lo = 0; H.hp_id = 0; H.len = 0;
         // software pipeline over reads (every request is issued in the shadow of phase A's slab loads):
         //   step i top:   LDS buffer i&1 holds read i's cells (raw snp / attribute words, written by LDS-DMA during step i-1),
         //                 SGPRs hold cell metadata (offset, length) of reads i, i+1 and step metadata of reads i, i+1
@@ -537,11 +552,16 @@ void beam_slab_kernel(BeamArgs g) {
                 }
                 double mx = 0.0;
                 uint64_t ts1 = 0, ts2 = 0;
+                if constexpr (DPPSEG) {
+                    static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; const double o = seg_get_f64<PSC, j>(pv); mx = (j == 0) ? o : (o > mx ? o : mx); });
+                    if (trunc) static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; ts1 += seg_get64<PSC, j>(t1); ts2 += seg_get64<PSC, j>(t2); });
+                } else {
                 for (uint32_t j = 0; j < p; ++j) {
                     const double o = shfl_f64(pv, seg0 + (int)j);
                     mx = (j == 0) ? o : (o > mx ? o : mx);
                 }
                 if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
+                }
                 // Pruning test (pv - lse) > ln 0.01 and its margin.  Screen with hardware f32 exp2/log2 (error of the screened
                 // value < 2e-5): a decision further than PRUNE_SCREEN from the threshold AND from the wave's running
                 // minimum margin has the same outcome and cannot lower the minimum, so the f64 exp/log (identical to the generic
@@ -549,7 +569,8 @@ void beam_slab_kernel(BeamArgs g) {
                 const double dx = pv - mx;
                 const float ef = __builtin_amdgcn_exp2f((float)dx * 1.44269504088896341f);
                 float sumf = 0.f;
-                for (uint32_t j = 0; j < p; ++j) sumf += __shfl(ef, seg0 + (int)j);
+                if constexpr (DPPSEG) static_for<0, TP>([&](auto J) { sumf += seg_get_f32<PSC, decltype(J)::value>(ef); });
+                else for (uint32_t j = 0; j < p; ++j) sumf += __shfl(ef, seg0 + (int)j);
                 const double dscr = (dx - (double)(__builtin_amdgcn_logf(sumf) * 0.693147180559945309f)) - g.cutoff;
                 const double ascr = fabs(dscr);
                 const bool far_enough = ascr >= PRUNE_SCREEN && ascr - PRUNE_SCREEN >= min_margin;     // false for NaN
@@ -583,12 +604,16 @@ void beam_slab_kernel(BeamArgs g) {
                 if (a0 == 0 && nstates <= S) {
                     const uint32_t npass = (uint32_t)__popcll(passmask);
                     if (npass != 0 && npass <= limit) {
-                        volatile uint8_t* tab = (volatile uint8_t*)s_pk;     // 256 B, free until phase M; volatile: other LANES write the slot too,
-                                                                             // the compiler must not forward this lane's store to its load
+                        // the table is the 256 B of s_pk, free until phase M.  Explicit DS instructions: other LANES write the slot too, so the compiler must
+                        // not forward this lane's store to its load (a volatile C++ access would do that as well, but hipcc turns it into FLAT
+                        // operations that also wait for every outstanding global request).  LDS requests of a wave are served in order.
                         // (no clearing needed: every passing lane overwrites its own slot, so it reads back its own id or another PASSING lane's)
                         const uint32_t slot = (uint32_t)(ch1 ^ (ch1 >> 31) ^ (ch2 >> 17)) & 255u;
-                        if (pass) tab[slot] = (uint8_t)lane;
-                        const bool coll = pass && tab[slot] != (uint8_t)lane;
+                        const uint32_t tab_addr = lds_base + LY.off_pk + slot;
+                        if (pass) asm volatile("ds_write_b8 %0, %1" :: "v"(tab_addr), "v"(lane) : "memory");
+                        uint32_t slot_owner;
+                        asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot_owner) : "v"(tab_addr) : "memory");
+                        const bool coll = pass && slot_owner != lane;
                         if (!__any(coll)) {
                             bulk = true;
                             b_h1 = ch1; b_h2 = ch2;
@@ -596,7 +621,7 @@ void beam_slab_kernel(BeamArgs g) {
                             while (passmask) {
                                 const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
                                 passmask &= passmask - 1;
-                                wl32(src_map, src, r);
+                                wlane(src_map, src, r);
                                 H.push(rl64(cs, src), r);
                                 ++r;
                             }

@@ -22,64 +22,52 @@ template <class T> __device__ __forceinline__ T sload(const T* p) {
     return *(const __attribute__((address_space(4))) T*)(uintptr_t)p;
 }
 
+// v_writelane_b32: lane l of v := x (x and l wave-uniform, in SGPRs): one instruction per dword instead of move + compare + select.
+// gfx9 allows one SGPR operand per VALU instruction, so the lane select travels in M0 (set inside the asm; hipcc re-materialises M0 before its
+// own uses, i.e. the LDS-DMA).  The LANE operand must come from scalar arithmetic, not straight from a v_readlane / v_cmp: the s_mov
+// in between is the only separation the hardware gets ("VALU writes SGPR -> lane select" wants wait states that the assembler cannot see here).
+__device__ __forceinline__ void wlane(uint32_t& v, uint32_t x, uint32_t l) { asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0"); }
+__device__ __forceinline__ void wlane3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t xa, uint32_t xb, uint32_t xc, uint32_t l) {
+    asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0" : "+v"(a), "+v"(b), "+v"(c) : "s"(xa), "s"(xb), "s"(xc), "s"(l) : "m0");
+}
+
 // Scores are non-negative f64 (sums of non-negative terms), so their IEEE bit patterns order like the values:
-// the heap compares u64 bit patterns.  Heap slot j lives in lane j: (hp_s, hp_id).
+// the heap compares u64 bit patterns.  Heap slot j lives in lane j: (hp_hi, hp_lo, hp_id) — the two halves of the score in separate
+// registers, so that a comparison of two readlane results is three scalar instructions (gfx9 has no ordered 64-bit scalar compare and
+// hipcc would bounce the operands through the vector unit).
 struct RegHeap {
-    uint64_t hp_s; uint32_t hp_id;     // per-lane
+    uint32_t hp_hi, hp_lo, hp_id;      // per-lane
     uint32_t len;                       // uniform
-    __device__ __forceinline__ void sift_up(uint32_t pos, uint64_t xs, uint32_t xid) {
+    static __device__ __forceinline__ bool le(uint32_t ah, uint32_t al, uint32_t bh, uint32_t bl) { return ah < bh || (ah == bh && al <= bl); }   // a <= b
+    __device__ __forceinline__ void sift_up(uint32_t pos, uint32_t xh, uint32_t xl, uint32_t xid) {
         while (pos > 0) {
             const uint32_t par = (pos - 1) >> 1;
-            const uint64_t ps = rl64(hp_s, par);
-            if (xs <= ps) break;
+            const uint32_t ph = rl32(hp_hi, par), pl = rl32(hp_lo, par);
+            if (le(xh, xl, ph, pl)) break;
             const uint32_t pid = rl32(hp_id, par);
-            wl64(hp_s, ps, pos); wl32(hp_id, pid, pos);
+            wlane3(hp_hi, hp_lo, hp_id, ph, pl, pid, pos);
             pos = par;
         }
-        wl64(hp_s, xs, pos); wl32(hp_id, xid, pos);
+        wlane3(hp_hi, hp_lo, hp_id, xh, xl, xid, pos);
     }
-#ifndef FLORIA_HEAP_PARALLEL_PUSH
-    __device__ __forceinline__ void push(uint64_t xs, uint32_t xid) { const uint32_t pos = len++; sift_up(pos, xs, xid); }
-#else
-    // push = sift_up(0, old_len) of libstd's BinaryHeap, all levels at once: the ancestors of the new slot hold non-increasing values
-    // towards the leaf, the new element stops below the DEEPEST ancestor whose value is >= its own (`if x <= parent break`), and the
-    // ancestors below that one move down a level.  One ballot finds the stopping ancestor, one permute (each slot reads its parent)
-    // moves the chain: no loop, no scalar round trips.  Same final array as the level-by-level loop.  MEASURED SLOWER (beam 137.5 vs 132.5 ms per
-    // config-4 step, scripts/ab.sh): most pushes stop at the first comparison, which the scalar loop does in ~6 instructions.  Kept as a variant.
-    __device__ __forceinline__ void push(uint64_t xs, uint32_t xid) {
-        const uint32_t pos = len++;
-        const uint32_t lane = threadIdx.x;
-        const uint32_t pj = lane + 1, pp = pos + 1;
-        const int dl = (int)__clz(pj) - (int)__clz(pp);                       // level(pos) - level(lane)
-        const bool anc = dl >= 1 && (pp >> dl) == pj;
-        const uint64_t m = __ballot(anc && hp_s >= xs);
-        const int stop = m ? 63 - (int)__clzll((long long)m) : -1;
-        const uint32_t par = (lane - 1) >> 1;                                  // (lane 0: unused)
-        const uint64_t ps = shfl_u64(hp_s, (int)par);
-        const uint32_t pid = __shfl(hp_id, (int)par);
-        const bool on_chain = anc || lane == pos;
-        const bool take = on_chain && lane > 0 && (int)par > stop;
-        const bool land = on_chain && (lane == 0 ? stop < 0 : (int)par == stop);
-        hp_s = land ? xs : (take ? ps : hp_s);
-        hp_id = land ? xid : (take ? pid : hp_id);
-    }
-#endif
+    __device__ __forceinline__ void push(uint64_t xs, uint32_t xid) { const uint32_t pos = len++; sift_up(pos, (uint32_t)(xs >> 32), (uint32_t)xs, xid); }
+    __device__ __forceinline__ void move(uint32_t from, uint32_t to) { wlane3(hp_hi, hp_lo, hp_id, rl32(hp_hi, from), rl32(hp_lo, from), rl32(hp_id, from), to); }
+    __device__ __forceinline__ bool slot_le(uint32_t a, uint32_t b) const { return le(rl32(hp_hi, a), rl32(hp_lo, a), rl32(hp_hi, b), rl32(hp_lo, b)); }   // data[a] <= data[b]
     __device__ __forceinline__ uint32_t pop() {                    // returns the evicted (max) entry id
         --len;
-        const uint64_t xs = rl64(hp_s, len);
-        const uint32_t xid = rl32(hp_id, len);
+        const uint32_t xh = rl32(hp_hi, len), xl = rl32(hp_lo, len), xid = rl32(hp_id, len);
         if (len == 0) return xid;
         const uint32_t root = rl32(hp_id, 0);
         const uint32_t end = len, lim = end >= 2 ? end - 2 : 0;
         uint32_t pos = 0, child = 1;
         while (child <= lim) {                                     // sift_down_to_bottom(0)
-            if (rl64(hp_s, child) <= rl64(hp_s, child + 1)) child++;
-            wl64(hp_s, rl64(hp_s, child), pos); wl32(hp_id, rl32(hp_id, child), pos);
+            if (slot_le(child, child + 1)) child++;
+            move(child, pos);
             pos = child;
             child = 2 * pos + 1;
         }
-        if (child == end - 1) { wl64(hp_s, rl64(hp_s, child), pos); wl32(hp_id, rl32(hp_id, child), pos); pos = child; }
-        sift_up(pos, xs, xid);
+        if (child == end - 1) { move(child, pos); pos = child; }
+        sift_up(pos, xh, xl, xid);
         return root;
     }
     // into_sorted_vec()[0]: heap-sort in place, return the id at array position 0
@@ -87,26 +75,24 @@ struct RegHeap {
         uint32_t end = len;
         while (end > 1) {
             --end;
-            const uint64_t s0 = rl64(hp_s, 0), se = rl64(hp_s, end);
-            const uint32_t i0 = rl32(hp_id, 0), ie = rl32(hp_id, end);
-            wl64(hp_s, s0, end); wl32(hp_id, i0, end);              // swap(0, end)
-            const uint64_t hs = se; const uint32_t hid = ie;        // hole element = old data[end], now at 0
+            const uint32_t hh = rl32(hp_hi, end), hl = rl32(hp_lo, end), hid = rl32(hp_id, end);      // hole element = old data[end]
+            move(0, end);                                                                                // swap(0, end)
             uint32_t pos = 0, child = 1;
             const uint32_t lim = end >= 2 ? end - 2 : 0;
             bool placed = false;
             while (child <= lim) {                                  // sift_down_range(0, end)
-                if (rl64(hp_s, child) <= rl64(hp_s, child + 1)) child++;
-                const uint64_t cs = rl64(hp_s, child);
-                if (hs >= cs) { placed = true; break; }
-                wl64(hp_s, cs, pos); wl32(hp_id, rl32(hp_id, child), pos);
+                if (slot_le(child, child + 1)) child++;
+                const uint32_t ch = rl32(hp_hi, child), cl = rl32(hp_lo, child);
+                if (le(ch, cl, hh, hl)) { placed = true; break; }   // hole >= data[child]
+                move(child, pos);
                 pos = child;
                 child = 2 * pos + 1;
             }
             if (!placed && child == end - 1) {
-                const uint64_t cs = rl64(hp_s, child);
-                if (hs < cs) { wl64(hp_s, cs, pos); wl32(hp_id, rl32(hp_id, child), pos); pos = child; }
+                const uint32_t ch = rl32(hp_hi, child), cl = rl32(hp_lo, child);
+                if (!le(ch, cl, hh, hl)) { move(child, pos); pos = child; }      // hole < data[child]
             }
-            wl64(hp_s, hs, pos); wl32(hp_id, hid, pos);
+            wlane3(hp_hi, hp_lo, hp_id, hh, hl, hid, pos);
         }
         return rl32(hp_id, 0);
     }
