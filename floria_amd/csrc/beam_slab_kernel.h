@@ -173,7 +173,6 @@ void beam_slab_kernel(BeamArgs g) {
     uint64_t* r_t2 = r_t1 + NS;
     uint64_t* dummy = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS - SLAB_DUMMY_WORDS));      // scratch for branch-free tails: 64 lanes x A sums, then 64 code bytes
     uint8_t* const dummy_code = (uint8_t*)(dummy + 64 * A);
-    const uint64_t lane_lt = (1ull << lane) - 1;
 
     // phase B: lane = (state, partition).  The instances with a compile-time ploidy of 2..4 give a state an aligned group of PS = 2 / 4 / 4 lanes
     // (ploidy 3: every fourth lane idles), so that the sums and maxima over a state's partitions are DPP quad permutes instead of LDS shuffles
@@ -701,13 +700,13 @@ void beam_slab_kernel(BeamArgs g) {
                     const uint32_t x = x0 + lane;
                     const bool fr = x < NS && ref[x] == 0;
                     const uint64_t fm = __ballot(fr);
-                    const uint32_t pos = found + (uint32_t)__popcll(fm & lane_lt);
+                    const uint32_t pos = found + mbcnt64(fm);
                     if (fr && pos < 64) freelist[pos] = (uint16_t)x;
                     found += (uint32_t)__popcll(fm);
                 }
                 if (found < ncopy && lane == 0) atomicAdd(&g.diag[1], 1u);
                 __syncthreads();
-                if (needcopy) { const uint32_t f = freelist[__popcll(cmask & lane_lt)]; newid[u_old] = (uint16_t)f; ref[f] = 2; }
+                if (needcopy) { const uint32_t f = freelist[mbcnt64(cmask)]; newid[u_old] = (uint16_t)f; ref[f] = 2; }
                 __syncthreads();
             }
             // survivor records
@@ -753,7 +752,7 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint32_t x = x0 + lane;
                 const bool rf = x < NS && ref[x] != 0;
                 const uint64_t fm = __ballot(rf);
-                if (rf) { const uint32_t idx = nl + (uint32_t)__popcll(fm & lane_lt); live_id[idx] = (uint16_t)x; s2l[x] = (uint16_t)idx; }
+                if (rf) { const uint32_t idx = nl + mbcnt64(fm); live_id[idx] = (uint16_t)x; s2l[x] = (uint16_t)idx; }
                 nl += (uint32_t)__popcll(fm);
             }
             __syncthreads();
@@ -787,7 +786,7 @@ void beam_slab_kernel(BeamArgs g) {
                 c_nlead += nlead; c_add_items += (unsigned long long)nlead * L;
 #endif
                 // leaders' target slabs, compacted into freelist[] (reused as scratch)
-                if (lead) freelist[__popcll(lmask & lane_lt)] = newid[u_old];
+                if (lead) freelist[mbcnt64(lmask)] = newid[u_old];
                 for (uint32_t t = 0; t < ntiles; ++t) {
                     if (ntiles > 1) stage_tile(t); else __syncthreads();
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);

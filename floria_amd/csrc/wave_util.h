@@ -15,6 +15,8 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l) { return ((uint
 // select form lets the compiler handle the VALU->SGPR lane-select hazards itself)
 __device__ __forceinline__ void wl32(uint32_t& v, uint32_t x, uint32_t l) { v = (threadIdx.x == l) ? x : v; }
 __device__ __forceinline__ void wl64(uint64_t& v, uint64_t x, uint32_t l) { v = (threadIdx.x == l) ? x : v; }
+// number of set bits of a wave-uniform mask below this lane (v_mbcnt_lo + v_mbcnt_hi): the rank of the lane among the set lanes
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // scalar (SMEM) load of read-only data at a wave-uniform address: the value lands in SGPRs, costs no VGPR and is
 // tracked by lgkmcnt, so it can be requested a whole beam step before it is used
