@@ -22,6 +22,11 @@ class CPileup(C.Structure):
                 ("first", u32p), ("last", u32p), ("n_reads", C.c_uint32)]
 
 
+class CPileupPacked(C.Structure):
+    _fields_ = [("read_off", u32p), ("first", u32p), ("last", u32p), ("bit_off", u32p),
+                ("present", u8p), ("allele2", u8p), ("qual", u8p), ("n_reads", C.c_uint32)]
+
+
 class CParams(C.Structure):
     _fields_ = [("epsilon", C.c_double), ("max_ploidy", C.c_uint32), ("beam", C.c_uint32),
                 ("ploidy_sensitivity", C.c_uint32), ("stopping_heuristic", C.c_int32)]

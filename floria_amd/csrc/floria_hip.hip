@@ -857,19 +857,33 @@ struct UploadPlan {
     size_t t_cd = 0, t_rp = 0, t_st = 0;
     std::vector<fl::UploadContig> ucd;
     std::vector<fl::UploadStatus> ust;
-    std::vector<CopyRun> small_runs;                    // read_off, first, last of every contig
+    std::vector<fl::PackedContig> upk;                  // packed uploads: what expand_kernel reads / writes (device table at t_pk)
+    size_t t_pk = 0;
+    bool packed = false;
+    std::vector<CopyRun> small_runs;                    // read_off, first, last (packed: + bit_off) of every contig
     std::vector<std::vector<CopyRun>> chunk_runs;       // snp, allele, qual per chunk
     std::vector<uint32_t> chunk_first;                  // [n_chunks+1] contig boundaries
     std::vector<uint32_t> contig_chunk;                 // [n]
     bool all_pinned = false;
 };
 
-int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, uint32_t n_chunks, UploadPlan& P) {
-    P.n = n;
+// (a batch is either CSR pileups or packed ones: `pk` non-null selects the compact wire form, expanded on the device)
+int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_pileup_packed* pk, uint32_t n, uint32_t n_chunks, UploadPlan& P) {
+    P.n = n; P.packed = pk != nullptr;
     P.rp.assign(n + 1, 0); P.cp.assign(n + 1, 0);
+    std::vector<floria_pileup> views;                   // packed: the fields both forms share, so that the code below reads one type
+    if (pk) {
+        views.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const floria_pileup_packed* q = &pk[i];
+            if (q->n_reads && (!q->read_off || !q->first || !q->last || !q->bit_off || !q->present || !q->allele2 || !q->qual)) return fail(FLORIA_E_INVALID, "null pileup field");
+            views[i] = floria_pileup{q->read_off, nullptr, nullptr, q->qual, q->first, q->last, q->n_reads};
+        }
+        pileups = views.data();
+    }
     for (uint32_t i = 0; i < n; ++i) {
         const floria_pileup* p = &pileups[i];
-        if (p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last)) return fail(FLORIA_E_INVALID, "null pileup field");
+        if (!pk && p->n_reads && (!p->read_off || !p->snp || !p->allele || !p->qual || !p->first || !p->last)) return fail(FLORIA_E_INVALID, "null pileup field");
         const uint64_t nc = p->n_reads ? p->read_off[p->n_reads] : 0;
         if (nc >= (1ull << 32)) return fail(FLORIA_E_UNSUPPORTED, "more than 2^32 cells in one contig");
         P.rp[i + 1] = P.rp[i] + p->n_reads; P.cp[i + 1] = P.cp[i] + nc;
@@ -912,12 +926,23 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, u
     auto seg2 = [&](size_t bytes) { const size_t o = c2; c2 += (bytes + 255) & ~(size_t)255; return o; };
     const size_t t_al = seg2(C + 16), t_q = seg2(C + 16);
     P.t_cd = seg2(sizeof(fl::UploadContig) * n); P.t_rp = seg2(8 * (n + 1)); P.t_st = seg2(sizeof(fl::UploadStatus) * n);
+    // packed: the compact arrays are transient too (bit offsets, presence bits, 2-bit alleles), one sub-range per contig — at the offsets
+    // floria_hip_pack_pileups_batch gives them in host memory, so that a batch packed by it travels as one transfer per field and chunk
+    std::vector<uint64_t> pb(n + 1, 0);                 // presence bytes prefix
+    size_t t_bo = 0, t_pr = 0, t_a2 = 0;
+    if (pk) {
+        for (uint32_t i = 0; i < n; ++i) pb[i + 1] = pb[i] + (pk[i].n_reads ? ((uint64_t)pk[i].bit_off[pk[i].n_reads] + 7) / 8 : 0) + 1;
+        t_bo = seg2(4 * (R + n)); t_pr = seg2(pb[n] + 16); t_a2 = seg2(C / 4 + n + 16); P.t_pk = seg2(sizeof(fl::PackedContig) * n);
+    }
     if (int rc = ctx->up_tmp.ensure(c2 + 256)) { arena_put(A); P.A = nullptr; return rc; }
     char* T = P.T = ctx->up_tmp.as<char>();
     P.ucd.resize(n); P.ust.resize(n);
     auto add_run = [](std::vector<CopyRun>& runs, const void* src, char* dst, size_t bytes) {
         if (!bytes) return;
-        if (!runs.empty() && runs.back().src + runs.back().bytes == (const char*)src && runs.back().dst + runs.back().bytes == dst) runs.back().bytes += bytes;
+        // back to back on both sides — or separated by the same few padding bytes on both sides (the field-major layout of floria_hip_pack_pileups_batch
+        // pads every contig's bit arrays by a byte): one transfer
+        const ptrdiff_t gs = runs.empty() ? -1 : (const char*)src - (runs.back().src + runs.back().bytes), gd = runs.empty() ? -2 : dst - (runs.back().dst + runs.back().bytes);
+        if (gs == gd && gs >= 0 && gs <= 64) runs.back().bytes += (size_t)gs + bytes;
         else runs.push_back({(const char*)src, dst, bytes});
     };
     for (int kind = 0; kind < 3; ++kind)
@@ -929,6 +954,8 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, u
             else if (kind == 1) add_run(P.small_runs, p->first, D + o_first + 4 * P.rp[i], 4 * nr);
             else add_run(P.small_runs, p->last, D + o_last + 4 * P.rp[i], 4 * nr);
         }
+    if (pk) for (uint32_t i = 0; i < n; ++i) if (pk[i].n_reads) add_run(P.small_runs, pk[i].bit_off, T + t_bo + 4 * (P.rp[i] + i), 4 * ((size_t)pk[i].n_reads + 1));
+    auto a2_off = [&](uint32_t i) { return (size_t)(P.cp[i] / 4 + i); };       // (every contig's 2-bit array starts on its own byte)
     P.chunk_runs.assign(n_chunks, {});
     for (uint32_t g = 0; g < n_chunks; ++g)
         for (int kind = 0; kind < 3; ++kind)
@@ -936,6 +963,12 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, u
                 const floria_pileup* p = &pileups[i];
                 if (!p->n_reads) continue;
                 const uint64_t nc = P.cp[i + 1] - P.cp[i];
+                if (pk) {
+                    if (kind == 0) add_run(P.chunk_runs[g], pk[i].present, T + t_pr + pb[i], pb[i + 1] - pb[i] - 1);
+                    else if (kind == 1) add_run(P.chunk_runs[g], pk[i].allele2, T + t_a2 + a2_off(i), (nc + 3) / 4);
+                    else add_run(P.chunk_runs[g], p->qual, T + t_q + P.cp[i], nc);
+                    continue;
+                }
                 if (kind == 0) add_run(P.chunk_runs[g], p->snp, D + o_snp + 4 * P.cp[i], 4 * nc);
                 else if (kind == 1) add_run(P.chunk_runs[g], p->allele, T + t_al + P.cp[i], nc);
                 else add_run(P.chunk_runs[g], p->qual, T + t_q + P.cp[i], nc);
@@ -947,6 +980,15 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, u
         u.cell_aw = (uint32_t*)(D + o_aw + 4 * P.cp[i]); u.tw = (uint64_t*)(D + o_tw + 16 * P.rp[i]); u.meta = (uint32_t*)(D + o_meta + 32 * P.rp[i]);
         u.n_reads = pileups[i].n_reads; u.n_cells = (uint32_t)(P.cp[i + 1] - P.cp[i]);
         P.ust[i] = fl::UploadStatus{~0ull, 0, 0, 0, 0};
+    }
+    if (pk) {
+        P.upk.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            fl::PackedContig& q = P.upk[i];
+            q.bit_off = (const uint32_t*)(T + t_bo + 4 * (P.rp[i] + i)); q.present = (const uint8_t*)(T + t_pr + pb[i]); q.allele2 = (const uint8_t*)(T + t_a2 + a2_off(i));
+            q.snp = (uint32_t*)(D + o_snp + 4 * P.cp[i]); q.allele = (uint8_t*)(T + t_al + P.cp[i]);
+            q.present_bytes = pk[i].n_reads ? ((uint64_t)pk[i].bit_off[pk[i].n_reads] + 7) / 8 : 0;
+        }
     }
     P.all_pinned = true;
     auto pinned_run = [](const CopyRun& r) { return r.bytes < 4096 || (is_pinned(r.src) && is_pinned(r.src + r.bytes - 1)); };
@@ -960,6 +1002,7 @@ hipError_t issue_tables(floria_hip_ctx* ctx, UploadPlan& P, hipStream_t st) {
     hipError_t e = hipMemcpyAsync(P.T + P.t_cd, P.ucd.data(), sizeof(fl::UploadContig) * P.n, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(P.T + P.t_rp, P.rp.data(), 8 * (P.n + 1), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(P.T + P.t_st, P.ust.data(), sizeof(fl::UploadStatus) * P.n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && P.packed) e = hipMemcpyAsync(P.T + P.t_pk, P.upk.data(), sizeof(fl::PackedContig) * P.n, hipMemcpyHostToDevice, st);
     return e;
 }
 // validate + flatten the reads of chunk g (its cells and the small arrays must have arrived on `st`)
@@ -971,15 +1014,17 @@ hipError_t launch_flatten(floria_hip_ctx* ctx, UploadPlan& P, uint32_t g, hipStr
     a.contigs = (const fl::UploadContig*)(P.T + P.t_cd) + c0; a.read_prefix = (const uint64_t*)(P.T + P.t_rp) + c0; a.status = (fl::UploadStatus*)(P.T + P.t_st) + c0;
     a.w24 = ctx->d_w24.as<uint32_t>(); a.Rq1 = ctx->d_hash.as<uint64_t>(); a.Rq2 = ctx->d_hash.as<uint64_t>() + 2ull * ctx->hash_len;
     a.n_contigs = c1 - c0; a.read_base = P.rp[c0]; a.n_reads_total = nr;
+    if (P.packed) hipLaunchKernelGGL(fl::expand_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, st, a, (const fl::PackedContig*)(P.T + P.t_pk) + c0);     // compact wire form -> CSR, then as usual
     hipLaunchKernelGGL(fl::flatten_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 // status words -> error (if any), else the contig handles
-int finish_upload(floria_hip_ctx* ctx, UploadPlan& P, const floria_pileup* pileups, floria_hip_contig** out) {
+int finish_upload(floria_hip_ctx* ctx, UploadPlan& P, floria_hip_contig** out) {
     const uint32_t n = P.n;
     for (uint32_t i = 0; i < n; ++i) if (P.ust[i].err != ~0ull) {
         const std::string r = std::to_string((unsigned long long)(P.ust[i].err >> 8)), ci = n > 1 ? " (contig " + std::to_string(i) + " of the batch)" : std::string();
         switch ((uint32_t)(P.ust[i].err & 0xff)) {
+            case fl::UP_PACKED:        return fail(FLORIA_E_INVALID, "packed pileup: the presence bits of read " + r + " do not match its first / last / cell count" + ci);
             case fl::UP_NO_CELLS:      return fail(FLORIA_E_INVALID, "read " + r + " has no cells (or read_off is not monotone)" + ci);
             case fl::UP_FIRST_LAST:    return fail(FLORIA_E_INVALID, "first/last of read " + r + " do not match its cells" + ci);
             case fl::UP_ONE_BASED:     return fail(FLORIA_E_INVALID, "SNP positions are 1-based" + ci);
@@ -991,10 +1036,10 @@ int finish_upload(floria_hip_ctx* ctx, UploadPlan& P, const floria_pileup* pileu
     if (!out) return 0;
     for (uint32_t i = 0; i < n; ++i) {
         floria_hip_contig* c = new floria_hip_contig();
-        c->ctx = ctx; c->arena = P.A; c->idx = i; c->n_reads = pileups[i].n_reads; c->n_cells = P.cp[i + 1] - P.cp[i];
+        c->ctx = ctx; c->arena = P.A; c->idx = i; c->n_reads = P.ucd[i].n_reads; c->n_cells = P.cp[i + 1] - P.cp[i];
         c->max_len = P.ust[i].max_len; c->n_alleles = P.ust[i].max_allele >= 2 ? 4 : 2; c->has_q0 = P.ust[i].has_q0 != 0;
         c->dev.read_off = P.ucd[i].read_off; c->dev.first = P.ucd[i].first; c->dev.last = P.ucd[i].last; c->dev.cell_snp = P.ucd[i].snp;
-        c->dev.cell_aw = P.ucd[i].cell_aw; c->dev.tw = P.ucd[i].tw; c->dev.meta = P.ucd[i].meta; c->dev.n_reads = pileups[i].n_reads;
+        c->dev.cell_aw = P.ucd[i].cell_aw; c->dev.tw = P.ucd[i].tw; c->dev.meta = P.ucd[i].meta; c->dev.n_reads = P.ucd[i].n_reads;
         out[i] = c;
     }
     P.A->refs = n;
@@ -1007,13 +1052,13 @@ extern "C" {
 
 // Upload a batch of contigs: plan the arena, DMA the raw arrays (consecutive contigs whose arrays are back to back in host
 // memory travel as one transfer), validate + flatten on the device (upload_kernel.h), read back the per-contig status.
-int floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, floria_hip_contig** out) {
-    if (!ctx || !out || (n && !pileups)) return fail(FLORIA_E_INVALID, "null argument");
+static int upload_batch_impl(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_pileup_packed* pk, uint32_t n, floria_hip_contig** out) {
+    if (!ctx || !out || (n && !pileups && !pk)) return fail(FLORIA_E_INVALID, "null argument");
     for (uint32_t i = 0; i < n; ++i) out[i] = nullptr;
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(ctx->device));
     UploadPlan P;
-    int rc = plan_upload(ctx, pileups, n, 1, P);
+    int rc = plan_upload(ctx, pileups, pk, n, 1, P);
     if (rc) return rc;
     EventTimer Tm(ctx->stream);
     const int th = Tm.begin(K_H2D);
@@ -1027,13 +1072,92 @@ int floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     if (!rc && e == hipSuccess) e = hipMemcpyAsync(P.ust.data(), P.T + P.t_st, sizeof(fl::UploadStatus) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (!rc && e != hipSuccess) rc = fail(FLORIA_E_DEVICE, std::string("contig upload: ") + hipGetErrorString(e));
-    if (!rc) rc = finish_upload(ctx, P, pileups, out);
+    if (!rc) rc = finish_upload(ctx, P, out);
     if (rc) { sync_all(ctx); arena_put(P.A); return rc; }
     ctx->timing = floria_timing{};
     ctx->timing.h2d_ms = Tm.sum(K_H2D); ctx->timing.select_ms = Tm.sum(K_SEL); ctx->timing.total_ms = Tm.span();
     ctx->timing.upload_pinned_bytes = pinned_b; ctx->timing.upload_staged_bytes = staged_b;
     return 0;
 }
+int floria_hip_contig_upload_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n, floria_hip_contig** out) {
+    return upload_batch_impl(ctx, pileups, nullptr, n, out);
+}
+int floria_hip_contig_upload_batch_packed(floria_hip_ctx* ctx, const floria_pileup_packed* pileups, uint32_t n, floria_hip_contig** out) {
+    return upload_batch_impl(ctx, nullptr, pileups, n, out);
+}
+
+// The compact wire form of CSR pileups (include/floria_hip.h: floria_pileup_packed), host side.  A batch is laid out FIELD BY FIELD (every
+// contig's read_off, then every bit_off, ...) at exactly the per-contig offsets plan_upload gives the device copies, so that an upload of the whole
+// batch is one transfer per field (and per chunk) instead of seven per contig.
+namespace {
+struct PackLayout { std::vector<uint64_t> rp, cp, pb; size_t o_ro, o_bo, o_fi, o_la, o_pr, o_a2, o_qu, total; };
+bool pack_layout(const floria_pileup* in, uint32_t n, PackLayout& Y) {
+    Y.rp.assign(n + 1, 0); Y.cp.assign(n + 1, 0); Y.pb.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const floria_pileup* p = &in[i];
+        const uint64_t R = p->n_reads;
+        if (R && (!p->read_off || !p->first || !p->last || !p->snp || !p->allele || !p->qual)) return false;
+        uint64_t bits = 0;
+        for (uint64_t r = 0; r < R; ++r) { if (p->last[r] < p->first[r]) return false; bits += (uint64_t)p->last[r] - p->first[r] + 1; }
+        if (bits >= (1ull << 32)) return false;
+        Y.rp[i + 1] = Y.rp[i] + R; Y.cp[i + 1] = Y.cp[i] + (R ? p->read_off[R] : 0); Y.pb[i + 1] = Y.pb[i] + (bits + 7) / 8 + 1;
+    }
+    size_t cur = 0;
+    auto seg = [&](uint64_t bytes) { const size_t o = cur; cur += (size_t)((bytes + 63) & ~(uint64_t)63); return o; };
+    const uint64_t R = Y.rp[n], C = Y.cp[n];
+    Y.o_ro = seg(4 * (R + n)); Y.o_bo = seg(4 * (R + n)); Y.o_fi = seg(4 * R); Y.o_la = seg(4 * R);
+    Y.o_pr = seg(Y.pb[n] + 16); Y.o_a2 = seg(C / 4 + n + 16); Y.o_qu = seg(C + 16);
+    Y.total = cur;
+    return true;
+}
+}  // namespace
+size_t floria_hip_pack_bytes_batch(const floria_pileup* in, uint32_t n) {
+    PackLayout Y;
+    if (!in || !n || !pack_layout(in, n, Y)) return 0;
+    return Y.total;
+}
+int floria_hip_pack_pileups_batch(const floria_pileup* in, uint32_t n, void* buf, size_t buf_bytes, floria_pileup_packed* out) {
+    if ((n && (!in || !out)) || (!buf && buf_bytes)) return fail(FLORIA_E_INVALID, "null argument");
+    if (!n) return 0;
+    PackLayout Y;
+    if (!pack_layout(in, n, Y)) return fail(FLORIA_E_INVALID, "pileup cannot be packed (null field, last < first, or spans of 2^32 bits and more)");
+    if (buf_bytes < Y.total) return fail(FLORIA_E_INVALID, "pack buffer too small (floria_hip_pack_bytes_batch)");
+    char* B = (char*)buf;
+    memset(B + Y.o_pr, 0, Y.pb[n] + 16); memset(B + Y.o_a2, 0, Y.cp[n] / 4 + n + 16);
+    for (uint32_t i = 0; i < n; ++i) {
+        const floria_pileup* p = &in[i];
+        const uint64_t R = p->n_reads, C = R ? p->read_off[R] : 0;
+        uint32_t* ro = (uint32_t*)(B + Y.o_ro + 4 * (Y.rp[i] + i)); uint32_t* bo = (uint32_t*)(B + Y.o_bo + 4 * (Y.rp[i] + i));
+        uint32_t* fi = (uint32_t*)(B + Y.o_fi + 4 * Y.rp[i]);       uint32_t* la = (uint32_t*)(B + Y.o_la + 4 * Y.rp[i]);
+        uint8_t* pr = (uint8_t*)(B + Y.o_pr + Y.pb[i]); uint8_t* a2 = (uint8_t*)(B + Y.o_a2 + Y.cp[i] / 4 + i); uint8_t* qu = (uint8_t*)(B + Y.o_qu + Y.cp[i]);
+        uint64_t bit = 0;
+        for (uint64_t r = 0; r < R; ++r) {
+            ro[r] = p->read_off[r]; fi[r] = p->first[r]; la[r] = p->last[r]; bo[r] = (uint32_t)bit;
+            const uint32_t F = p->first[r], span = p->last[r] - F + 1;
+            for (uint32_t c = p->read_off[r]; c < p->read_off[r + 1]; ++c) {
+                const uint32_t sp = p->snp[c];
+                const std::string where = " (read " + std::to_string((unsigned long long)r) + (n > 1 ? ", contig " + std::to_string(i) + " of the batch)" : ")");
+                if (sp < F || sp - F >= span) return fail(FLORIA_E_INVALID, "cell outside [first, last]" + where);
+                if (p->allele[c] > 3) return fail(FLORIA_E_UNSUPPORTED, "allele index > 3" + where);
+                const uint64_t bi = bit + (sp - F);
+                pr[bi >> 3] |= (uint8_t)(1u << (bi & 7));
+                a2[c >> 2] |= (uint8_t)(p->allele[c] << (2 * (c & 3)));
+            }
+            bit += span;
+        }
+        ro[R] = (uint32_t)C; bo[R] = (uint32_t)bit;
+        if (C) memcpy(qu, p->qual, C);
+        out[i] = floria_pileup_packed{ro, fi, la, bo, pr, a2, qu, p->n_reads};
+    }
+    return 0;
+}
+size_t floria_hip_pack_bytes(const floria_pileup* in) { return floria_hip_pack_bytes_batch(in, in ? 1 : 0); }
+int floria_hip_pack_pileup(const floria_pileup* in, void* buf, size_t buf_bytes, floria_pileup_packed* out) {
+    if (!in || !out) return fail(FLORIA_E_INVALID, "null argument");
+    return floria_hip_pack_pileups_batch(in, 1, buf, buf_bytes, out);
+}
+
+
 
 int floria_hip_contig_upload(floria_hip_ctx* ctx, const floria_pileup* p, floria_hip_contig** out) {
     if (!ctx || !out || !p) return fail(FLORIA_E_INVALID, p ? "null argument" : "null pileup");
@@ -1179,6 +1303,7 @@ struct S1Contigs {
     const uint32_t* contig_chunk = nullptr;
     uint32_t n_chunks = 0;
     hipEvent_t* chunk_ev = nullptr;
+    uint32_t chunk_groups = 0;     // job groups the chunks are merged into (0 = one per chunk)
 };
 
 struct Trace {
@@ -1268,7 +1393,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     hipEvent_t group_ev[floria_hip_ctx::MAX_GROUPS] = {};
     if (chunked) {
         const uint32_t nc = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
-        G = ctx->knobs.pipe_groups ? std::min<uint32_t>(ctx->knobs.pipe_groups, nc) : nc;
+        G = ctx->knobs.pipe_groups ? std::min<uint32_t>(ctx->knobs.pipe_groups, nc) : SC.chunk_groups ? std::min<uint32_t>(SC.chunk_groups, nc) : nc;
         chunk_group.resize(SC.n_chunks);
         for (uint32_t c = 0; c < SC.n_chunks; ++c) { chunk_group[c] = std::min<uint32_t>((uint32_t)((uint64_t)std::min(c, nc - 1) * G / nc), G - 1); group_ev[chunk_group[c]] = SC.chunk_ev[std::min(c, nc - 1)]; }
     }
@@ -1464,17 +1589,18 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
 // of all but the first chunk hides behind the kernels of the earlier ones.  The launch plan is made for biallelic pileups
 // without q = 0 cells (known only once every chunk has been validated); a batch that turns out otherwise is phased again from
 // its — by then resident — contigs with the matching kernels, so results never depend on the route.
-int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n_contigs,
-                                   const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
-                                   const floria_params* prm, floria_block_result** out, floria_hip_contig** keep) {
-    if (!ctx || !out || !prm || (n_contigs && !pileups) || (n_blocks && (!blk_start || !blk_end))) return fail(FLORIA_E_INVALID, "null argument");
+static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_pileup_packed* pk, uint32_t n_contigs,
+                              const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
+                              const floria_params* prm, floria_block_result** out, floria_hip_contig** keep) {
+    if (!ctx || !out || !prm || (n_contigs && !pileups && !pk) || (n_blocks && (!blk_start || !blk_end))) return fail(FLORIA_E_INVALID, "null argument");
     *out = nullptr;
     if (keep) for (uint32_t i = 0; i < n_contigs; ++i) keep[i] = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     for (uint32_t b = 0; b < n_blocks; ++b) if ((blk_contig ? blk_contig[b] : 0) >= n_contigs) return fail(FLORIA_E_INVALID, "blk_contig out of range");
     if (n_contigs == 0) { S1Contigs SC; return s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, out); }
     uint64_t cells = 0;
-    for (uint32_t i = 0; i < n_contigs; ++i) if (pileups[i].n_reads && pileups[i].read_off) cells += pileups[i].read_off[pileups[i].n_reads];
+    auto n_reads_of = [&](uint32_t i) { return pk ? pk[i].n_reads : pileups[i].n_reads; };
+    for (uint32_t i = 0; i < n_contigs; ++i) { const uint32_t* ro = pk ? pk[i].read_off : pileups[i].read_off; if (n_reads_of(i) && ro) cells += ro[n_reads_of(i)]; }
     // auto: ~0.5 GB of host pileup per chunk, at most 5 (measured on BASELINE config 4, 2.65 GB: 5 chunks, the first one half-size, are best)
     const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (200ull << 20)));
     // (measured, config 4, H2D-inclusive: 500 contigs / 0.66 GB: 2 chunks 60.5 ms, 3-4 chunks 56.5; 1000 contigs / 1.33 GB: 2 chunks 86 ms, 4-5 chunks 77; 2000 contigs: 5 chunks)
@@ -1485,7 +1611,7 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
         if (n_blocks <= (uint32_t)ctx->n_cu * 11) chunk_cap = std::max<uint32_t>(1, 10 / prm->max_ploidy);
         else if (n_blocks <= (uint32_t)ctx->n_cu * 25 && prm->max_ploidy >= 4) chunk_cap = std::max<uint32_t>(1, 10 / std::max<uint32_t>(3, prm->max_ploidy - 3));
     }
-    int rc = plan_upload(ctx, pileups, n_contigs, std::min<uint32_t>(std::min(want_chunks, chunk_cap), floria_hip_ctx::MAX_GROUPS), UP);
+    int rc = plan_upload(ctx, pileups, pk, n_contigs, std::min<uint32_t>(std::min(want_chunks, chunk_cap), floria_hip_ctx::MAX_GROUPS), UP);
     if (rc) return rc;
     std::vector<floria_hip_contig*> handles(n_contigs, nullptr);
     auto drop = [&](int code) { sync_all(ctx); for (auto* h : handles) if (h) { h->arena = nullptr; delete h; } arena_put(UP.A); return code; };
@@ -1521,16 +1647,20 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
         for (uint32_t i = 0; i < n_contigs; ++i) {
             fl::ContigDev& d = SC.cdev[i];
             d.read_off = UP.ucd[i].read_off; d.first = UP.ucd[i].first; d.last = UP.ucd[i].last; d.cell_snp = UP.ucd[i].snp;
-            d.cell_aw = UP.ucd[i].cell_aw; d.tw = UP.ucd[i].tw; d.meta = UP.ucd[i].meta; d.n_reads = pileups[i].n_reads;
+            d.cell_aw = UP.ucd[i].cell_aw; d.tw = UP.ucd[i].tw; d.meta = UP.ucd[i].meta; d.n_reads = n_reads_of(i);
         }
         SC.len_max = BINOM_NMAX_CAP; SC.nall = 2; SC.any_q0 = false;                      // optimistic plan, verified below
         SC.contig_chunk = UP.contig_chunk.data(); SC.n_chunks = UP.n_chunks; SC.chunk_ev = ctx->ev_chunk;
+        // the compact wire form is on the device in a tenth of the step: what counts then is that the expand / flatten launches of the later chunks are
+        // not starved by persistent grids that already own every wave slot — two job groups (the first starts when the first half has landed) measured
+        // best (config 4, ms per step: 106.7 against 109.6 with a group per chunk and 109.4 with a single group)
+        if (pk) SC.chunk_groups = 2;
         rc = s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, &R);
         if (rc) return drop(rc);
         const floria_timing tm = ctx->timing;
         hipError_t e2 = hipMemcpy(UP.ust.data(), UP.T + UP.t_st, sizeof(fl::UploadStatus) * n_contigs, hipMemcpyDeviceToHost);
         if (e2 != hipSuccess) { floria_hip_block_result_free(R); return drop(fail(FLORIA_E_DEVICE, std::string("upload status: ") + hipGetErrorString(e2))); }
-        rc = finish_upload(ctx, UP, pileups, handles.data());
+        rc = finish_upload(ctx, UP, handles.data());
         if (rc) { floria_hip_block_result_free(R); for (auto*& h : handles) h = nullptr; return drop(rc); }
         bool plan_ok = true;
         for (auto* h : handles) plan_ok = plan_ok && h->n_alleles == 2 && !h->has_q0;
@@ -1541,7 +1671,7 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
         } else ctx->timing = tm;
     } else {
         arena_put(UP.A);                                                                  // (back to the cache: the plain upload takes it from there)
-        rc = floria_hip_contig_upload_batch(ctx, pileups, n_contigs, handles.data());
+        rc = upload_batch_impl(ctx, pileups, pk, n_contigs, handles.data());
         if (rc) return rc;
         pinned_b = ctx->timing.upload_pinned_bytes; staged_b = ctx->timing.upload_staged_bytes;
         rc = floria_hip_phase_blocks_batch(ctx, handles.data(), n_contigs, blk_contig, blk_start, blk_end, n_blocks, prm, &R);
@@ -1552,6 +1682,17 @@ int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pil
     else { for (auto* h : handles) floria_hip_contig_free(h); ctx->batch_token = 0; R->batch_token = 0; }     // nothing stays resident: no hap graph for this batch
     *out = R;
     return 0;
+}
+
+int floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pileups, uint32_t n_contigs,
+                                   const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
+                                   const floria_params* prm, floria_block_result** out, floria_hip_contig** keep) {
+    return phase_pileups_impl(ctx, pileups, nullptr, n_contigs, blk_contig, blk_start, blk_end, n_blocks, prm, out, keep);
+}
+int floria_hip_phase_pileups_batch_packed(floria_hip_ctx* ctx, const floria_pileup_packed* pileups, uint32_t n_contigs,
+                                          const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end, uint32_t n_blocks,
+                                          const floria_params* prm, floria_block_result** out, floria_hip_contig** keep) {
+    return phase_pileups_impl(ctx, nullptr, pileups, n_contigs, blk_contig, blk_start, blk_end, n_blocks, prm, out, keep);
 }
 
 int floria_hip_phase_blocks_resident(floria_hip_ctx* ctx, const floria_hip_contig* contig, const uint32_t* blk_start,

@@ -15,6 +15,7 @@ namespace fl {
 
 // error codes, in the order the host-side contract lists them; the smallest (read, code) pair of a contig is reported
 enum : uint32_t { UP_OK = 0, UP_NO_CELLS = 1, UP_FIRST_LAST = 2, UP_ONE_BASED = 3, UP_NOT_ASCENDING = 4, UP_ALLELE = 5, UP_ORDER = 6 };
+constexpr uint32_t UP_PACKED = 0;      // (status word only: expand_kernel's report, ahead of whatever flatten_kernel makes of the same read)
 
 struct UploadContig {              // raw inputs (device copies) and flattened outputs of one contig
     const uint32_t* read_off;      // [n_reads+1]
@@ -43,10 +44,69 @@ struct UploadArgs {
     uint64_t n_reads_total;        // reads of this launch
 };
 
+// one contig of a PACKED upload (include/floria_hip.h: floria_pileup_packed): device copies of the compact arrays and the CSR arrays expand_kernel writes
+struct PackedContig {
+    const uint32_t* bit_off;       // [n_reads+1]
+    const uint8_t*  present;
+    const uint8_t*  allele2;
+    uint32_t* snp;                 // out: [n_cells]  (= UploadContig::snp)
+    uint8_t*  allele;              // out: [n_cells]  (= UploadContig::allele)
+    uint64_t  present_bytes;
+};
+
 template <int CTRL> __device__ __forceinline__ uint64_t up_dpp64(uint64_t x) {
     const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, CTRL, 0xf, 0xf, false);
     const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, false);
     return ((uint64_t)h << 32) | l;
+}
+
+// Compact wire form -> CSR, on the device: 16 lanes per read walk the read's presence bits 16 at a time; a set bit j is cell
+// read_off[r] + (set bits before j) with SNP first + j and the 2-bit allele of that cell.  The CSR arrays land where a plain upload
+// would have put them and flatten_kernel then validates them like any other upload; this kernel only has to catch what would corrupt
+// memory or go unnoticed: presence bits that do not add up to the read's cell count (UP_PACKED), spans that disagree with first / last.
+__global__ __launch_bounds__(256) void expand_kernel(UploadArgs g, const PackedContig* pk) {
+    const uint32_t sub = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
+    const uint64_t lr = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4), gr = g.read_base + lr;
+    const bool live = lr < g.n_reads_total;
+    uint32_t lo = 0, hi = g.n_contigs;
+    while (live && hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
+    uint32_t b = 0, ncell = 0, F = 0, span = 0, r = 0;
+    uint64_t bit0 = 0;
+    UploadContig cd{};
+    PackedContig pc{};
+    bool bad = false;
+    if (live) {
+        cd = g.contigs[lo]; pc = pk[lo];
+        r = (uint32_t)(gr - g.read_prefix[lo]);
+        b = G(cd.read_off)[r];
+        const uint32_t e = G(cd.read_off)[r + 1];
+        F = G(cd.first)[r];
+        const uint32_t L = G(cd.last)[r];
+        bit0 = G(pc.bit_off)[r];
+        const uint64_t bit1 = G(pc.bit_off)[r + 1];
+        if (e <= b || e > cd.n_cells || L < F || bit1 <= bit0 || bit1 - bit0 != (uint64_t)(L - F) + 1 || (bit1 + 7) / 8 > pc.present_bytes) bad = true;   // (flatten reports e <= b as UP_NO_CELLS)
+        else { ncell = e - b; span = L - F + 1; }
+    }
+    // the four reads of a wavefront walk together: the longest span sets the trip count
+    uint32_t smax = span;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_xor(smax, o); smax = v > smax ? v : smax; }
+    uint32_t seen = 0;
+    for (uint32_t j0 = 0; j0 < smax; j0 += 16) {
+        const uint32_t j = j0 + sub;
+        bool set = false;
+        if (j < span) { const uint64_t bi = bit0 + j; set = (G(pc.present)[bi >> 3] >> (bi & 7)) & 1; }
+        const uint32_t m16 = (uint32_t)(__ballot(set) >> (16 * grp)) & 0xffffu;
+        const uint32_t rank = seen + (uint32_t)__popc(m16 & ((1u << sub) - 1u));
+        if (set && rank < ncell) {
+            const uint32_t c = b + rank;
+            pc.snp[c] = F + j;
+            pc.allele[c] = (uint8_t)((G(pc.allele2)[c >> 2] >> (2 * (c & 3))) & 3u);
+        }
+        seen += (uint32_t)__popc(m16);
+    }
+    if (live && sub == 0 && (bad ? G(cd.read_off)[r + 1] > b : seen != ncell))
+        atomicMin(&g.status[lo].err, ((unsigned long long)r << 8) | UP_PACKED);
 }
 
 __global__ __launch_bounds__(256) void flatten_kernel(UploadArgs g) {

@@ -28,6 +28,7 @@ SYMBOLS = [
     "floria_hip_hapq", "floria_hip_hapq_batch",
     "floria_hip_contig_upload_batch", "floria_hip_host_alloc", "floria_hip_host_free", "floria_hip_set_option",
     "floria_hip_contig_download", "floria_hip_phase_pileups_batch",
+    "floria_hip_pack_bytes", "floria_hip_pack_pileup", "floria_hip_pack_bytes_batch", "floria_hip_pack_pileups_batch", "floria_hip_contig_upload_batch_packed", "floria_hip_phase_pileups_batch_packed",
 ]
 
 
@@ -68,6 +69,12 @@ def load():
         L.floria_hip_host_free.restype = None
         L.floria_hip_host_free.argtypes = [C.c_void_p]
         L.floria_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.floria_hip_pack_bytes.restype = C.c_size_t
+        L.floria_hip_pack_bytes.argtypes = [C.c_void_p]
+        L.floria_hip_pack_bytes_batch.restype = C.c_size_t
+        L.floria_hip_pack_bytes_batch.argtypes = [C.c_void_p, C.c_uint32]
+        L.floria_hip_pack_pileups_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.floria_hip_pack_pileup.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -150,6 +157,33 @@ def pin_pileups(pileups):
         fields[name] = views
     out = [Pileup(fields["read_off"][i], fields["snp"][i], fields["allele"][i], fields["qual"][i], fields["first"][i], fields["last"][i]) for i in range(len(pileups))]
     return arena, out
+
+
+class _PlainArena:
+    """Pageable stand-in for PinnedArena (tests of the host-side packer on machines without a GPU)."""
+
+    def __init__(self, nbytes):
+        self._arr = np.zeros(int(nbytes) + 64, np.uint8)
+        self._p = self._arr.ctypes.data
+
+    def free(self):
+        pass
+
+
+def pack_pileups(pileups, pinned=True):
+    """The compact wire form (floria_pileup_packed) of a list of Pileups, packed by floria_hip_pack_pileup into ONE pinned arena:
+    what a host marshals its Vec<Frag> into for the PCIe link.  Returns (arena, ctypes array of floria_pileup_packed, packed bytes)."""
+    L = load()
+    n = len(pileups)
+    carr = c_pileups(pileups)
+    size = int(L.floria_hip_pack_bytes_batch(carr, C.c_uint32(n)))
+    if n and size == 0:
+        raise FloriaHipError(-1, "pileups cannot be packed (null field, last < first, or spans of 2^32 bits and more)")
+    arena = (PinnedArena if pinned else _PlainArena)(size + 128)
+    arr = (capi.CPileupPacked * n)()
+    base = arena._p + (64 - arena._p % 64) % 64
+    _check(L.floria_hip_pack_pileups_batch(carr, C.c_uint32(n), C.c_void_p(base), C.c_size_t(size), arr))
+    return arena, arr, size
 
 
 class ResidentContig:
@@ -261,6 +295,13 @@ class FloriaHip:
         _check(load().floria_hip_contig_upload_batch(self._h, carr, C.c_uint32(n), hs))
         return ContigBatch(self, hs, n)
 
+    def upload_batch_packed(self, parr, n=None):
+        """floria_hip_contig_upload_batch_packed for a ctypes floria_pileup_packed array (pack_pileups) -> ContigBatch."""
+        n = len(parr) if n is None else n
+        hs = (C.c_void_p * n)()
+        _check(load().floria_hip_contig_upload_batch_packed(self._h, parr, C.c_uint32(n), hs))
+        return ContigBatch(self, hs, n)
+
     def timing(self):
         t = capi.CTiming()
         _check(load().floria_hip_last_timing(self._h, C.byref(t)))
@@ -301,13 +342,15 @@ class FloriaHip:
         transfers pipelined with the kernels.  Returns the BlockResult, or (BlockResult, ContigBatch) with keep=True."""
         carr = pileups if isinstance(pileups, C.Array) else c_pileups(pileups)
         n = len(carr)
+        packed = isinstance(carr, C.Array) and carr._type_ is capi.CPileupPacked          # (pack_pileups: the compact wire form)
         bc = np.ascontiguousarray(blk_contig, np.uint32)
         bs = np.ascontiguousarray(blk_start, np.uint32)
         be = np.ascontiguousarray(blk_end, np.uint32)
         out = C.POINTER(capi.CBlockResult)()
         hs = (C.c_void_p * n)() if keep else None
-        _check(load().floria_hip_phase_pileups_batch(self._h, carr, C.c_uint32(n), capi.ptr(bc, C.c_uint32), capi.ptr(bs, C.c_uint32),
-                                                     capi.ptr(be, C.c_uint32), C.c_uint32(len(bs)), C.byref(params), C.byref(out), hs))
+        fn = load().floria_hip_phase_pileups_batch_packed if packed else load().floria_hip_phase_pileups_batch
+        _check(fn(self._h, carr, C.c_uint32(n), capi.ptr(bc, C.c_uint32), capi.ptr(bs, C.c_uint32),
+                  capi.ptr(be, C.c_uint32), C.c_uint32(len(bs)), C.byref(params), C.byref(out), hs))
         res = capi.BlockResult(out.contents) if copy_out else None
         load().floria_hip_block_result_free(out)
         return (res, ContigBatch(self, hs, n)) if keep else res

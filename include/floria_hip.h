@@ -60,6 +60,26 @@ typedef struct {
     uint32_t        n_reads;
 } floria_pileup;
 
+/* The same pileup in the compact wire form SURVEY.md §8(d) counts (per read: first, last; a presence bit per SNP of its span; a 2-bit
+ * allele and one quality byte per observed SNP): 1.375 B per cell + 16 B per read instead of 6 B per cell + 12 B per read — what a
+ * host marshals its `Vec<Frag>` into for the PCIe link (floria.rs:255-293); the device expands it to the CSR form above and then
+ * validates + flattens that exactly as if it had been uploaded (upload_kernel.h: expand_kernel, flatten_kernel).
+ *   present : read r owns bits [bit_off[r], bit_off[r+1]) with bit_off[r+1] - bit_off[r] == last[r] - first[r] + 1; bit j of the read
+ *             (bit (bit_off[r]+j) & 7 of byte (bit_off[r]+j) >> 3, LSB first) is set iff SNP first[r] + j carries a call; the first and
+ *             the last bit of a read are set and the number of set bits equals read_off[r+1] - read_off[r];
+ *   allele2 : cell c (global cell index of the contig, as in read_off) at bits 2 (c & 3) of byte c >> 2; allele indices 0..3;
+ *   qual    : one byte per cell. */
+typedef struct {
+    const uint32_t* read_off;  /* [n_reads+1] cell offsets                              */
+    const uint32_t* first;     /* [n_reads]   first_position                            */
+    const uint32_t* last;      /* [n_reads]   last_position                             */
+    const uint32_t* bit_off;   /* [n_reads+1] offsets into `present`, in bits (< 2^32)  */
+    const uint8_t*  present;   /* [ceil(bit_off[n_reads] / 8)]                          */
+    const uint8_t*  allele2;   /* [ceil(n_cells / 4)]                                   */
+    const uint8_t*  qual;      /* [n_cells]                                             */
+    uint32_t        n_reads;
+} floria_pileup_packed;
+
 /* The fields of `Options` (types_structs.rs:20-51) the hot path reads
  * (graph_processing.rs:111-113,198-226,234). */
 typedef struct {
@@ -206,6 +226,22 @@ int  floria_hip_phase_pileups_batch(floria_hip_ctx* ctx, const floria_pileup* pi
                                     const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
                                     uint32_t n_blocks, const floria_params* params, floria_block_result** out,
                                     floria_hip_contig** keep);
+
+/* The compact wire form: bytes a packed copy of `in` needs (0 if `in` is malformed on its face: null field, first > last), and the
+ * packing itself into caller memory (floria_hip_host_alloc memory for a DMA upload): *out receives views into buf.  Host-side, exact. */
+size_t floria_hip_pack_bytes(const floria_pileup* in);
+int    floria_hip_pack_pileup(const floria_pileup* in, void* buf, size_t buf_bytes, floria_pileup_packed* out);
+/* The same for a batch of contigs, laid out field by field (all read_off arrays back to back, then all bit_off, ...): an upload of the batch
+ * then is one transfer per field and chunk.  out[0..n) receive the views. */
+size_t floria_hip_pack_bytes_batch(const floria_pileup* in, uint32_t n);
+int    floria_hip_pack_pileups_batch(const floria_pileup* in, uint32_t n, void* buf, size_t buf_bytes, floria_pileup_packed* out);
+/* floria_hip_contig_upload_batch / floria_hip_phase_pileups_batch from the compact form: same handles, same results, a fifth of the bytes
+ * on the PCIe link. */
+int  floria_hip_contig_upload_batch_packed(floria_hip_ctx* ctx, const floria_pileup_packed* pileups, uint32_t n, floria_hip_contig** out);
+int  floria_hip_phase_pileups_batch_packed(floria_hip_ctx* ctx, const floria_pileup_packed* pileups, uint32_t n_contigs,
+                                           const uint32_t* blk_contig, const uint32_t* blk_start, const uint32_t* blk_end,
+                                           uint32_t n_blocks, const floria_params* params, floria_block_result** out,
+                                           floria_hip_contig** keep);
 
 /* S1 over MANY contigs in one launch sequence (the unit bench.py times: all blocks of all
  * contigs a rank owns are phased together so the device sees >> 256 concurrent jobs).

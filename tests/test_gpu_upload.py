@@ -315,3 +315,93 @@ def test_pipelined_upload_and_phase_equals_upload_then_phase(gpu_ctx, hip_lib, o
     finally:
         gpu_ctx.set_option("upload_chunks", 0)
     arena.free()
+
+
+def _batch_contigs(hip_lib, gpu_ctx, batch, piles):
+    return [hip_lib.ResidentContig(gpu_ctx, handle=hip_lib.C.c_void_p(batch._arr[j]), n_reads=piles[j].n_reads) for j in range(len(piles))]
+
+
+def test_packed_upload_equals_csr_upload(gpu_ctx, hip_lib):
+    # the compact wire form (floria_pileup_packed: presence bits, 2-bit alleles, quality bytes) is expanded on the device and must leave
+    # exactly the resident bytes of a CSR upload: every array of every contig, and S1 straight from packed host pileups == from CSR ones
+    rng = np.random.default_rng(404)
+    contigs = [synth.make_config_contig(4, 300 + i, 0.6) for i in range(24)]
+    piles = [random_pileup(rng, 400, 300, 3, max_len=70, alleles=4, q0_frac=0.05, qlo=0, qhi=93, drop=0.3),
+             random_pileup(rng, 1, 5, 1, max_len=1),
+             random_pileup(rng, 900, 60, 2, max_len=3, drop=0.0),                 # short reads: 1-3 cells, spans of a few bits
+             synth.make_config_contig(3, 0, 0.1).pileup] + [c.pileup for c in contigs]
+    w24 = w24_table()
+    rq = hash_tables()
+    arena, parr, nbytes = hip_lib.pack_pileups(piles)
+    csr_bytes = sum(4 * (p.n_reads + 1) + 8 * p.n_reads + 6 * p.n_cells for p in piles)
+    assert nbytes < 0.45 * csr_bytes
+    pb = gpu_ctx.upload_batch_packed(parr)
+    t = gpu_ctx.timing()
+    assert t["upload_pinned_bytes"] + t["upload_staged_bytes"] < 0.45 * csr_bytes
+    for rc, p in zip(_batch_contigs(hip_lib, gpu_ctx, pb, piles), piles):
+        check_resident(rc, p, w24, rq)
+        rc._h = None                                   # (views: the batch owns the handles)
+    # S1: one pipelined call from packed host pileups, one from the CSR arrays, and the resident batch
+    par = hip_lib.make_params(EPS)
+    bc, bs, be = [], [], []
+    for i, cg in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(cg.snp_pos, 10000)
+        bc += [4 + i] * len(s); bs += list(s); be += list(e)
+    r_res = gpu_ctx.phase_blocks_batch(pb, bc, bs, be, par)
+    r_pk = gpu_ctx.phase_pileups_batch(parr, bc, bs, be, par)
+    carena, pinned = hip_lib.pin_pileups(piles)
+    gpu_ctx.set_option("upload_chunks", 3)
+    r_pk3 = gpu_ctx.phase_pileups_batch(parr, bc, bs, be, par)
+    assert gpu_ctx.timing()["upload_chunks"] == 3
+    r_csr = gpu_ctx.phase_pileups_batch(hip_lib.c_pileups(pinned), bc, bs, be, par)
+    gpu_ctx.set_option("upload_chunks", 0)
+    assert_block_results_equal(r_res, r_pk, "resident vs packed host pileups")
+    assert_block_results_equal(r_res, r_pk3, "resident vs packed host pileups in 3 chunks")
+    assert_block_results_equal(r_res, r_csr, "resident vs CSR host pileups")
+    assert r_pk.min_prune_margin == r_csr.min_prune_margin
+    pb.free(); arena.free(); carena.free()
+
+
+def test_packed_upload_is_validated(gpu_ctx, hip_lib):
+    rng = np.random.default_rng(77)
+    good = random_pileup(rng, 40, 60, 2, max_len=20, drop=0.2)
+    par = hip_lib.make_params(EPS)
+
+    def corrupted(edit):
+        arena, parr, _ = hip_lib.pack_pileups([good, good, good])
+        q = parr[1]
+        edit(q)
+        return arena, parr
+
+    def clear_first_bit(q):                      # the first presence bit of read 3 cleared: its cells no longer add up
+        bo = capi_np(q.bit_off, q.n_reads + 1, np.uint32)
+        pr = capi_np(q.present, (int(bo[-1]) + 7) // 8, np.uint8)
+        b = int(bo[3]); pr[b >> 3] &= np.uint8(~(1 << (b & 7)) & 0xff)
+
+    def extra_bit(q):                            # a presence bit too many in read 5 (a gap position of the read set)
+        bo = capi_np(q.bit_off, q.n_reads + 1, np.uint32)
+        pr = capi_np(q.present, (int(bo[-1]) + 7) // 8, np.uint8)
+        bits = np.unpackbits(pr, bitorder="little")
+        for r in range(q.n_reads):
+            z = np.nonzero(bits[int(bo[r]):int(bo[r + 1])] == 0)[0]
+            if len(z):
+                b = int(bo[r]) + int(z[0]); pr[b >> 3] |= np.uint8(1 << (b & 7)); return
+        raise AssertionError("no gap in the test pileup")
+
+    def span_mismatch(q):                        # bit_off disagrees with last - first + 1
+        bo = capi_np(q.bit_off, q.n_reads + 1, np.uint32)
+        bo[7:] += 1
+
+    capi_np = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,))      # (a VIEW of the packed buffer: the edits land in what is uploaded)
+    for edit in (clear_first_bit, extra_bit, span_mismatch):
+        arena, parr = corrupted(edit)
+        with pytest.raises(hip_lib.FloriaHipError) as ei:
+            gpu_ctx.upload_batch_packed(parr)
+        assert ei.value.code == -1 and "contig 1" in str(ei.value), str(ei.value)
+        with pytest.raises(hip_lib.FloriaHipError):
+            gpu_ctx.phase_pileups_batch(parr, [0, 1, 2], [1, 1, 1], [60, 60, 60], par)
+        arena.free()
+    arena, parr, _ = hip_lib.pack_pileups([good])          # the context is still usable
+    r = gpu_ctx.phase_pileups_batch(parr, [0], [1], [60], par)
+    assert r.n_blocks == 1 and r.best_ploidy[0] >= 1
+    arena.free()
