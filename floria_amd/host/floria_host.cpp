@@ -140,34 +140,53 @@ void realign_queue_on_device(Session& s, RealignQueue& q) {
 
 // ---- Batch: every device stage once for MANY contigs ----------------------------------------------------------------------------------
 Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
+    // The Frags of all contigs go straight into the COMPACT wire form (floria_pileup_packed: a presence bit per SNP of a read's span, a 2-bit allele and a
+    // quality byte per call — a fifth of the CSR bytes on the PCIe link), in ONE pinned buffer laid out field by field at the offsets
+    // floria_hip_pack_pileups_batch uses, so that every field of a chunk of contigs is one DMA.  Alleles beyond the 2-bit envelope are refused here.
     const size_t n = work.size();
-    uint64_t R = 0, C = 0;
-    for (const ContigWork& w : work) { R += w.all_frags.size(); for (const Frag& f : w.all_frags) C += f.seq_dict.size(); }
-    // CSR of all contigs in ONE pinned buffer, field by field, so that every field of a chunk of contigs is one DMA
-    const size_t bytes = 4 * (R + n) + 8 * R + 6 * C + 64;
-    pinned_ = floria_hip_host_alloc(bytes);
+    std::vector<uint64_t> rp(n + 1, 0), cp(n + 1, 0), pb(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t C = 0, bits = 0;
+        for (const Frag& f : work[i].all_frags) {
+            if (f.last_position < f.first_position) throw Error(FLORIA_E_INVALID, "Frag with last_position < first_position");
+            C += f.seq_dict.size(); bits += (uint64_t)f.last_position - f.first_position + 1;
+        }
+        if (bits >= (1ull << 32) || C >= (1ull << 32)) throw Error(FLORIA_E_UNSUPPORTED, "contig too large for one pileup (2^32 cells / span bits)");
+        rp[i + 1] = rp[i] + work[i].all_frags.size(); cp[i + 1] = cp[i] + C; pb[i + 1] = pb[i] + (bits + 7) / 8 + 1;
+    }
+    const uint64_t R = rp[n], C = cp[n];
+    size_t cur = 0;
+    auto seg = [&](uint64_t bytes) { const size_t o = cur; cur += (size_t)((bytes + 63) & ~(uint64_t)63); return o; };
+    const size_t o_ro = seg(4 * (R + n)), o_bo = seg(4 * (R + n)), o_fi = seg(4 * R), o_la = seg(4 * R), o_pr = seg(pb[n] + 16), o_a2 = seg(C / 4 + n + 16), o_qu = seg(C + 16);
+    pinned_ = floria_hip_host_alloc(cur + 64);
     if (!pinned_) throw Error(FLORIA_E_NOMEM, floria_hip_last_error());
-    char* p = (char*)pinned_;
-    uint32_t* off = (uint32_t*)p; p += 4 * (R + n);
-    uint32_t* first = (uint32_t*)p; p += 4 * R;
-    uint32_t* last = (uint32_t*)p; p += 4 * R;
-    uint32_t* snp = (uint32_t*)p; p += 4 * C;
-    uint8_t* al = (uint8_t*)p; p += C;
-    uint8_t* q = (uint8_t*)p;
+    char* B = (char*)pinned_;
+    memset(B + o_pr, 0, pb[n] + 16); memset(B + o_a2, 0, C / 4 + n + 16);
     piles_.resize(n);
-    uint64_t ro = 0, rr = 0, cc = 0;
     for (size_t i = 0; i < n; ++i) {
         const std::vector<Frag>& fr = work[i].all_frags;
-        floria_pileup& pl = piles_[i];
-        pl.read_off = off + ro; pl.first = first + rr; pl.last = last + rr; pl.snp = snp + cc; pl.allele = al + cc; pl.qual = q + cc; pl.n_reads = (uint32_t)fr.size();
-        uint32_t local = 0;
-        off[ro] = 0;
+        uint32_t* ro = (uint32_t*)(B + o_ro + 4 * (rp[i] + i)); uint32_t* bo = (uint32_t*)(B + o_bo + 4 * (rp[i] + i));
+        uint32_t* fi = (uint32_t*)(B + o_fi + 4 * rp[i]);       uint32_t* la = (uint32_t*)(B + o_la + 4 * rp[i]);
+        uint8_t* pr = (uint8_t*)(B + o_pr + pb[i]); uint8_t* a2 = (uint8_t*)(B + o_a2 + cp[i] / 4 + i); uint8_t* qu = (uint8_t*)(B + o_qu + cp[i]);
+        uint32_t c = 0;
+        uint64_t bit = 0;
         for (size_t k = 0; k < fr.size(); ++k) {
-            if (fr[k].counter_id != k) throw Error(FLORIA_E_INVALID, "all_frags must be sorted with counter_id == index (floria.rs:289-293)");
-            for (const auto& kv : fr[k].seq_dict) { snp[cc + local] = kv.first; al[cc + local] = kv.second; q[cc + local] = fr[k].qual_dict.at(kv.first); ++local; }
-            off[ro + k + 1] = local; first[rr + k] = fr[k].first_position; last[rr + k] = fr[k].last_position;
+            const Frag& f = fr[k];
+            if (f.counter_id != k) throw Error(FLORIA_E_INVALID, "all_frags must be sorted with counter_id == index (floria.rs:289-293)");
+            ro[k] = c; bo[k] = (uint32_t)bit; fi[k] = f.first_position; la[k] = f.last_position;
+            for (const auto& kv : f.seq_dict) {                                   // (ascending SNP positions: a sorted map)
+                if (kv.first < f.first_position || kv.first > f.last_position) throw Error(FLORIA_E_INVALID, "Frag with a call outside [first_position, last_position]");
+                if (kv.second > 3) throw Error(FLORIA_E_UNSUPPORTED, "allele index > 3");
+                const uint64_t bi = bit + (kv.first - f.first_position);
+                pr[bi >> 3] |= (uint8_t)(1u << (bi & 7));
+                a2[c >> 2] |= (uint8_t)(kv.second << (2 * (c & 3)));
+                qu[c] = f.qual_dict.at(kv.first);
+                ++c;
+            }
+            bit += (uint64_t)f.last_position - f.first_position + 1;
         }
-        ro += fr.size() + 1; rr += fr.size(); cc += local;
+        ro[fr.size()] = c; bo[fr.size()] = (uint32_t)bit;
+        piles_[i] = floria_pileup_packed{ro, fi, la, bo, pr, a2, qu, (uint32_t)fr.size()};
     }
     handles_.assign(n, nullptr);
 }
@@ -187,7 +206,7 @@ void Batch::generate_hap_graphs(const Options& o) {
     b0.push_back((uint32_t)bs.size());
     floria_params prm{o.epsilon, (uint32_t)o.max_ploidy, (uint32_t)o.max_number_solns, o.ploidy_sensitivity, o.stopping_heuristic ? 1 : 0};
     floria_block_result* res = nullptr;
-    check(floria_hip_phase_pileups_batch(s_.ctx(), piles_.data(), (uint32_t)piles_.size(), bc.data(), bs.data(), be.data(), (uint32_t)bs.size(), &prm, &res, handles_.data()));
+    check(floria_hip_phase_pileups_batch_packed(s_.ctx(), piles_.data(), (uint32_t)piles_.size(), bc.data(), bs.data(), be.data(), (uint32_t)bs.size(), &prm, &res, handles_.data()));
     floria_hap_graph* hg = nullptr;
     int rc = floria_hip_hap_graph(s_.ctx(), res, &hg);
     if (rc) { floria_hip_block_result_free(res); check(rc); }

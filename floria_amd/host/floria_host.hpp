@@ -293,7 +293,7 @@ struct ContigWork {
 };
 class Batch {
 public:
-    Batch(Session& s, std::vector<ContigWork>& work);                  // marshals the Frags into pinned CSR buffers
+    Batch(Session& s, std::vector<ContigWork>& work);                  // marshals the Frags into the pinned compact wire form (floria_pileup_packed)
     ~Batch();
     Batch(const Batch&) = delete;
     Batch& operator=(const Batch&) = delete;
@@ -304,7 +304,7 @@ private:
     Session& s_;
     std::vector<ContigWork>& work_;
     void* pinned_ = nullptr;
-    std::vector<floria_pileup> piles_;
+    std::vector<floria_pileup_packed> piles_;
     std::vector<floria_hip_contig*> handles_;
 };
 // utils_frags::remove_monomorphic_allele (utils_frags.rs:713-772, --ignore-monomorphic): SNPs where one allele carries (almost) all of the
