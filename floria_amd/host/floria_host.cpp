@@ -138,6 +138,20 @@ void realign_queue_on_device(Session& s, RealignQueue& q) {
     q = RealignQueue();
 }
 
+std::vector<uint32_t> lpt_assign(const std::vector<double>& costs, uint32_t world) {
+    std::vector<size_t> order(costs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return costs[a] > costs[b]; });
+    std::vector<double> load(std::max<uint32_t>(1, world), 0.0);
+    std::vector<uint32_t> owner(costs.size(), 0);
+    for (size_t i : order) {
+        uint32_t r = 0;
+        for (uint32_t d = 1; d < load.size(); ++d) if (load[d] < load[r]) r = d;      // first minimum
+        owner[i] = r; load[r] += costs[i];
+    }
+    return owner;
+}
+
 // ---- Batch: every device stage once for MANY contigs ----------------------------------------------------------------------------------
 Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
     // The Frags of all contigs go straight into the COMPACT wire form (floria_pileup_packed: a presence bit per SNP of a read's span, a 2-bit allele and a

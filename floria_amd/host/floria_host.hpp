@@ -157,6 +157,11 @@ private:
     const std::vector<Frag>* frags_ = nullptr;
 };
 
+// Contigs -> devices of one node: longest-processing-time-first on an estimated cost (the rule of floria_amd/shard.py, which bench.py broadcasts over
+// RCCL): items in descending cost (ties: ascending index) go to the least loaded device (ties: the lowest).  Contigs share nothing, so the node-level
+// parallelism of the reference (one rayon pool over the blocks of a contig, graph_processing.rs:345-362) becomes contigs dealt to GPUs.
+std::vector<uint32_t> lpt_assign(const std::vector<double>& costs, uint32_t world);
+
 std::vector<std::pair<SnpPosition, SnpPosition>> get_range_with_lengths(const std::vector<GnPosition>& snp_to_genome_pos, size_t block_length,
                                                                           size_t overlap_len, double minimal_density);
 

@@ -10,12 +10,14 @@
 //
 //              [--output-reads [--gzip-reads] [--extra-trimming]] [--ignore-monomorphic]
 // Flags of the reference that are not supported and say so: the hidden -H/--hybrid, --reassign-short, --bin-by-cov (-q is accepted and
-// ignored, as in the reference).  Extras: --device N,
+// ignored, as in the reference).  Extras: --device N, --devices LIST (e.g. 0-7 or 0,2,5: the contigs of a batch are dealt to these GPUs of the node,
+// longest first; one context and one host thread per device; the files are those of a one-GPU run),
 // --batch-contigs N / --batch-cells N (size of a device batch), --debug (debug_graph.txt per contig), and for tests --dump-frags FILE,
 // --ingest-only, --no-realign, --stitch-graph FILE.
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -92,6 +94,7 @@ int main(int argc, char** argv) {
     bool ingest_only = false, no_realign = false;
     std::string stitch_graph;
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
+    std::vector<int> devices;            // --devices: the GPUs the contigs of a batch are dealt to (empty: --device alone)
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -117,6 +120,24 @@ int main(int argc, char** argv) {
             else if (a == "-q") {}
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
+            else if (a == "--devices") {                                 // "0-7", "0,2,5", "0-3,6"; a device may be named twice (two contexts on it)
+                std::stringstream ls(val());
+                std::string item;
+                while (std::getline(ls, item, ',')) {
+                    const size_t dash = item.find('-', 1);
+                    const int lo = std::stoi(item.substr(0, dash)), hi = dash == std::string::npos ? lo : std::stoi(item.substr(dash + 1));
+                    if (lo < 0 || hi < lo || hi - lo > 1024) throw Error(FLORIA_E_INVALID, "--devices: bad range " + item);
+                    for (int d = lo; d <= hi; ++d) devices.push_back(d);
+                }
+                if (devices.empty()) throw Error(FLORIA_E_INVALID, "--devices: empty list");
+            }
+            else if (a == "--lpt-assign") {                              // (tests) world cost cost ... -> the device of every item, no GPU needed
+                const uint32_t world = (uint32_t)std::stoul(val());
+                std::vector<double> costs;
+                while (i + 1 < argc) costs.push_back(std::stod(argv[++i]));
+                for (uint32_t d : lpt_assign(costs, world)) printf("%u\n", d);
+                return 0;
+            }
             else if (a == "--batch-contigs") batch_contigs = std::max<size_t>(1, std::stoul(val()));       // contigs per device batch
             else if (a == "--batch-cells") batch_cells = std::max<uint64_t>(1, std::stoull(val()));        // SNP calls per device batch
             else if (a == "--dump-frags") dump_frags = val();
@@ -195,8 +216,11 @@ int main(int argc, char** argv) {
         const std::map<std::string, std::string> fasta = get_fasta_seqs(o.reference_fasta);
         const double t_vcf = now_s() - tp;
         tp = now_s();
-        std::unique_ptr<Session> session_holder;
-        if (!ingest_only) session_holder.reset(new Session(o.device));                // throws without a usable MI355X: no CPU fallback
+        // one context per device of --devices (default: the one --device); every one throws without a usable MI355X: no CPU fallback
+        if (devices.empty()) devices.push_back(o.device);
+        std::vector<std::unique_ptr<Session>> sessions;
+        if (!ingest_only) for (int d : devices) sessions.emplace_back(new Session(d));
+        Session* const session_holder = sessions.empty() ? nullptr : sessions[0].get();
         fprintf(stderr, "Preprocessing: BAM %.3fs (%zu records), VCF + FASTA %.3fs, device %.3fs\n", t_bam, bam.records.size(), t_vcf, now_s() - tp);
 
         std::ofstream dump;
@@ -286,29 +310,46 @@ int main(int argc, char** argv) {
             t_ingest += now_s() - t0;
             if (ingest_only || work.empty()) continue;
             ++n_batches;
-            Session& session = *session_holder;
-            // ---- S1 + hap graph, every contig of the batch in one pipelined device call ----------------------------------------------
-            t0 = now_s();
-            Batch batch(session, work);
-            batch.generate_hap_graphs(o);
-            t_s1 += now_s() - t0;
-            // ---- LP + path peeling (host), one contig per task -------------------------------------------------------------------------
-            t0 = now_s();
-            parallel_for(work.size(), n_threads, [&](size_t i) {
-                ContigWork& w = work[i];
-                w.flows = solve_lp_graph(w.hap_graph);
-                auto paths = get_disjoint_paths_rewrite(w.hap_graph, w.flows, o);
-                w.path_parts = std::move(paths.first); w.path_ranges = std::move(paths.second);
-                if (debug) write_debug_graph(w);
-            });
-            t_stitch += now_s() - t0;
-            // ---- S2, then COV / ERR / HAPQ of the final haplosets -------------------------------------------------------------------
-            t0 = now_s();
-            batch.process_reads_for_final_parts(o);
-            t_s2 += now_s() - t0;
-            t0 = now_s();
-            batch.stats_and_hapq(o);
-            t_stats += now_s() - t0;
+            // the device stages of a set of contigs on one context: S1 + hap graph in one pipelined call, LP + path peeling on the host (one contig per
+            // task), S2, COV / ERR / HAPQ of the final haplosets.  `tm` receives the wall seconds of the four stages.
+            auto device_stages = [&](Session& session, std::vector<ContigWork>& part, size_t threads, double* tm) {
+                double t1 = now_s();
+                Batch batch(session, part);
+                batch.generate_hap_graphs(o);
+                tm[0] += now_s() - t1; t1 = now_s();
+                parallel_for(part.size(), threads, [&](size_t i) {
+                    ContigWork& w = part[i];
+                    w.flows = solve_lp_graph(w.hap_graph);
+                    auto paths = get_disjoint_paths_rewrite(w.hap_graph, w.flows, o);
+                    w.path_parts = std::move(paths.first); w.path_ranges = std::move(paths.second);
+                    if (debug) write_debug_graph(w);
+                });
+                tm[1] += now_s() - t1; t1 = now_s();
+                batch.process_reads_for_final_parts(o);
+                tm[2] += now_s() - t1; t1 = now_s();
+                batch.stats_and_hapq(o);
+                tm[3] += now_s() - t1;
+            };
+            double tm[4] = {0., 0., 0., 0.};
+            if (sessions.size() == 1) device_stages(*sessions[0], work, n_threads, tm);
+            else {
+                // ---- the contigs of the batch dealt to the devices (longest first, by SNP calls), one host thread per device; every contig comes back
+                // to its place, so what follows (writers, the contig table) sees the batch in contig order whatever the dealing was
+                std::vector<double> cost(work.size());
+                for (size_t i = 0; i < work.size(); ++i) { double c = 0; for (const Frag& f : work[i].all_frags) c += (double)f.seq_dict.size(); cost[i] = c; }
+                const std::vector<uint32_t> owner = lpt_assign(cost, (uint32_t)sessions.size());
+                std::vector<std::vector<ContigWork>> part(sessions.size());
+                std::vector<std::vector<size_t>> origin(sessions.size());
+                for (size_t i = 0; i < work.size(); ++i) { part[owner[i]].push_back(std::move(work[i])); origin[owner[i]].push_back(i); }
+                std::vector<std::array<double, 4>> tms(sessions.size(), std::array<double, 4>{0., 0., 0., 0.});
+                const size_t per_dev = std::max<size_t>(1, n_threads / sessions.size());
+                parallel_for(sessions.size(), sessions.size(), [&](size_t d) { if (!part[d].empty()) device_stages(*sessions[d], part[d], per_dev, tms[d].data()); });
+                for (size_t d = 0; d < sessions.size(); ++d) {
+                    for (size_t k = 0; k < part[d].size(); ++k) work[origin[d][k]] = std::move(part[d][k]);
+                    for (int q = 0; q < 4; ++q) tm[q] = std::max(tm[q], tms[d][q]);        // (the devices run side by side: the slowest one counts)
+                }
+            }
+            t_s1 += tm[0]; t_stitch += tm[1]; t_s2 += tm[2]; t_stats += tm[3];
             // ---- writers, one contig per task; the contig table in contig order ----------------------------------------------------
             t0 = now_s();
             std::vector<std::string> rows(work.size());
@@ -328,7 +369,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Total time taken is %.3fs\n", now_s() - t_all);
         // everything is written and closed: leave without tearing down the records, maps and sequences one by one (seconds for a large BAM)
         if (dump.is_open()) dump.close();
-        session_holder.reset();
+        sessions.clear();
         fflush(nullptr);
         std::_Exit(0);
     } catch (const Error& e) {

@@ -238,3 +238,27 @@ def test_batches_of_contigs_write_the_files_of_the_per_contig_flow(floria_hip, o
         assert sorted(tree) == names
         for n in names:
             assert tree[n] == trees[0][1][n], (n_b, n)
+
+
+def test_contigs_dealt_to_several_device_contexts_write_the_same_files(floria_hip, tmp_path):
+    # --devices: one context and one host thread per listed GPU, the contigs of a batch dealt to them longest first (the node-level parallelism
+    # of the reference, graph_processing.rs:345-362 / parse_cmd_line.rs:153-156).  This box has one GPU: every context sits on device 0, which runs
+    # the whole N-context path (dealing, concurrent pipelined calls on separate contexts, merging in contig order).  Trees must be byte-identical.
+    cs = [synth.make_config_contig(4, 40 + i, 0.2 + 0.03 * i, keep_layout=True) for i in range(9)]
+    cs += [synth.make_config_contig(3, 6, 0.2, keep_layout=True)]
+    prefix = str(tmp_path / "data")
+    synth_bam.write_dataset(prefix, cs, seed=11)
+    base = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-e", str(EPS), "-l", "5000", "--debug", "--snp-count-filter", "50", "-t", "6"]
+    trees = []
+    for k, extra in enumerate(([], ["--devices", "0,0,0"], ["--devices", "0-0,0", "--batch-contigs", "4"], ["--devices", "0,0,0,0,0,0,0,0"])):
+        out = str(tmp_path / f"o{k}")
+        r = subprocess.run(base + ["-o", out] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        trees.append(tree_bytes(out))
+    names = sorted(trees[0])
+    assert len([n for n in names if n.endswith(".vartigs")]) == 10
+    for t in trees[1:]:
+        assert sorted(t) == names
+        for n in names:
+            if n != "cmd.log":                                   # (the command line itself differs)
+                assert t[n] == trees[0][n], n

@@ -378,3 +378,24 @@ def test_flatmap_behaves_like_std_map():
     subprocess.check_call(["make", "-C", cpp, "-B", "flatmap_test"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(cpp, "flatmap_test")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
+
+
+def test_lpt_dealing_of_contigs_to_devices_matches_the_bench_queue(floria_hip):
+    floria_hip_bin = floria_hip
+    # floria-hip --devices deals the contigs of a batch with the rule bench.py broadcasts over RCCL (floria_amd/shard.py: longest first, least
+    # loaded device, first minimum on ties); every item gets exactly one device and the loads are balanced to within the largest item
+    import subprocess
+    from floria_amd import shard
+    rng = np.random.default_rng(3)
+    for world, n in ((1, 5), (2, 7), (8, 100), (8, 3), (3, 0), (5, 64)):
+        costs = rng.integers(1, 50, size=n).astype(float)
+        if n > 10:
+            costs[::7] = costs[0]                               # ties
+        r = subprocess.run([floria_hip_bin, "--lpt-assign", str(world)] + [repr(float(c)) for c in costs], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.array([int(x) for x in r.stdout.split()], np.int32)
+        want = shard.lpt_assign(costs, world)
+        assert np.array_equal(got, want), (world, n)
+        if n:
+            load = np.bincount(got, weights=costs, minlength=world)
+            assert load.max() - load.min() <= costs.max() + 1e-9 or n < world
