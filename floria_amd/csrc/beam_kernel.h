@@ -51,6 +51,7 @@ struct BeamArgs {
     uint32_t* diag;                // [0] = count of binom evaluations beyond the table, [1] = free-list underflow
     unsigned long long* steps_done;
     unsigned long long* prof;      // [32] phase cycle counters (-DFLORIA_PROF)
+    uint32_t  no_bulk;             // (tests) beam_slab_kernel: no bulk-insert shortcut, every child through the entry table and the duplicate test
 };
 
 __host__ __device__ inline uint32_t beam_hist_off(uint32_t i, uint32_t LM, uint32_t B) {

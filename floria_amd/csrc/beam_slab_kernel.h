@@ -25,10 +25,7 @@
 
 namespace fl {
 
-#ifndef FLORIA_SLAB_TILE
-#define FLORIA_SLAB_TILE 256
-#endif
-constexpr int SLAB_TILE = FLORIA_SLAB_TILE;      // cells of a read staged per pass (x2 arrays x2 buffers x4 B of LDS)
+constexpr int SLAB_TILE = 256;      // cells of a read staged per pass (x2 arrays x2 buffers x4 B of LDS)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
@@ -63,6 +60,8 @@ __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
 // at least 0.5/d away from every integer, while the float error (1-ulp reciprocal, one product) is < 4e-7 * x/d < 0.42/d
 __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return (uint32_t)(((float)x + 0.5f) * rcp_d); }
 constexpr int SLAB_NS_MAX = 512;
+constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
+constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
 template <int N> struct IC { static constexpr int value = N; };
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) { if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); } }
 // value of lane (segment base + J) for aligned segments of PS = 2 or 4 lanes: one DPP quad_perm move, no LDS crossbar round trip
@@ -75,14 +74,7 @@ template <int PS, int J> __device__ __forceinline__ double seg_get_f64(double v)
 template <int PS, int J> __device__ __forceinline__ float seg_get_f32(float v) { return __uint_as_float(seg_get<PS, J>(__float_as_uint(v))); }
 constexpr int SLAB_DUMMY_WORDS = 64 * FLORIA_MAX_ALLELES * 2 + 16;      // u32 words of per-slot scratch behind the traceback rows (host reserves them)
 constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
-#ifndef FLORIA_SLAB_U
-#define FLORIA_SLAB_U 6
-#endif
-constexpr int SLAB_U = FLORIA_SLAB_U;      // 16-B slab loads in flight per lane (q = 0 pileups: classification from the sums)
-#ifndef FLORIA_SLAB_CU
-#define FLORIA_SLAB_CU 8
-#endif
-constexpr int SLAB_CU = FLORIA_SLAB_CU;    // code-byte loads in flight per lane (<= 8: a batch's weights are summed in 32 bits, 8 * 2^28)
+constexpr int SLAB_U = 6;      // 16-B slab loads in flight per lane (q = 0 pileups: classification from the sums)
 
 struct SlabLds {
     uint32_t off_coff, off_caw, off_crp1, off_crp2;
@@ -129,13 +121,9 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 // per-partition loops unroll and divisions by p turn into multiplications; the host picks TP = p, TB = 10 for the CLI's default beam.
 // SPEC: the launch belongs to a speculative stage (stop_at is set): only that instance carries the checks that drop a job whose ploidy turned out not to be needed
 template <int A, bool Q0, int TP = 0, int TB = 0, bool SPEC = false>
-#ifndef FLORIA_SLAB_LOW_P_MAX
-#define FLORIA_SLAB_LOW_P_MAX 3
-#endif
-#ifndef FLORIA_SLAB_WAVES_LOW_P
-#define FLORIA_SLAB_WAVES_LOW_P 4      // ploidy 2 and 3 instances: 126-128 VGPRs and < 10 KB of LDS per wave -> 4 waves per SIMD
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TP >= 2 && TP <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES, (TP >= 2 && TP <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES)))
+// waves per SIMD: four for the ploidy 2 and 3 instances (126-128 VGPRs, < 10 KB of LDS per wave), SLAB_WAVES = 3 where LDS limits (ploidy >= 4, runtime-parameter
+// instances).  Measured and left alone: five waves spill 17-29 VGPRs and starve the co-running optimise kernels.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(slab_waves(TP), slab_waves(TP))))
 void beam_slab_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
@@ -161,11 +149,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t pos_bytes = A * 8;
     const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
     char* pool = (char*)g.state_pool + (uint64_t)blockIdx.x * g.state_stride;      // [NS slabs][span_max][A] u64, then [NS][span_pad] code bytes
-#ifdef FLORIA_SLAB_NO_CODES
-    constexpr bool CODES = false;         // (A/B switch: classify from the sums everywhere)
-#else
     constexpr bool CODES = !Q0;
-#endif
     const uint32_t span_pad = (g.span_max + 15u) & ~15u;
     uint8_t* const codes = (uint8_t*)(pool + (uint64_t)NS * slab_bytes);
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
@@ -600,7 +584,7 @@ void beam_slab_kernel(BeamArgs g) {
                 // collision only sends the step down the general path).  Then every child is inserted, nothing is evicted, entry id =
                 // rank among the passing lanes: the entry table is skipped (the survivors gather straight from the child lanes in M)
                 // and only the std::BinaryHeap pushes remain.
-                if (a0 == 0 && nstates <= S) {
+                if (a0 == 0 && nstates <= S && !g.no_bulk) {
                     const uint32_t npass = (uint32_t)__popcll(passmask);
                     if (npass != 0 && npass <= limit) {
                         // the table is the 256 B of s_pk, free until phase M.  Explicit DS instructions: other LANES write the slot too, so the compiler must

@@ -141,22 +141,19 @@ struct Knobs {
     uint32_t no_p1_shortcut = 0;  // run the beam kernel for ploidy 1 too
     uint32_t opt_threads = 0;     // 0 auto | 128 | 512 | 1024
     uint32_t opt_global = 0;      // optimise histogram in HBM
-    int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P} | 3 {1..P-1} then {P}
+    int32_t  speculate = -1;      // ploidy stages: -1 auto | 0 one ploidy per stage | 1 all ploidies at once | 2 {1,2,3} then {4..P}
     uint32_t upload_chunks = 0;   // floria_hip_phase_pileups_batch: chunks the cell arrays travel in (0 = auto by size, <= 8)
-    uint32_t upload_split = 2;    // chunk sizes: 0 even | 1 half-size first and last | 2 half-size first | 3 ramp 1:2:3:..
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
-    uint32_t spec_desc = 0;       // speculative stage: launch the highest ploidy first
-    uint32_t pipe_groups = 0;     // floria_hip_phase_pileups_batch: job groups of a chunked call (0 = one per chunk)
-    uint32_t spec_gate_p = 2;     // speculative stages: the ploidy whose finished beam search opens the gate for ploidies >= 4
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
-    bool spec_flat = false;       // (A/B) speculative stages without stream priorities and without the early stop-rule flags
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
+    uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
 };
 
 struct Arena;
 
 struct floria_hip_ctx {
     int device = 0;
+    uint32_t hw_queues = 0;                   // streams that really run side by side on this device (probe_hw_queues at create)
     hipStream_t stream = nullptr;
     uint32_t user_slots = 0;
     Knobs knobs;
@@ -167,7 +164,6 @@ struct floria_hip_ctx {
     hipStream_t gstream[MAX_LANES] = {};
     hipStream_t gstream_low[MAX_LANES] = {};      // speculative stages: the lanes of ploidy >= 4 (dispatched after the ploidies every block needs)
     hipEvent_t ev_fork[MAX_LANES] = {}, ev_join[MAX_LANES] = {};
-    hipEvent_t ev_chain[MAX_GROUPS][FLORIA_MAX_PLOIDY + 2] = {};   // speculate = 4: the beam search of (group, ploidy) has finished (ploidy + 1 starts behind it)
     hipEvent_t ev_gate[MAX_GROUPS] = {};       // speculative stages: the beam search of ploidy 2 of group g has finished (ploidies >= 4 start behind it)
     hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
     hipEvent_t ev_rids = nullptr;
@@ -388,7 +384,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.LY = fl::beam_lds_layout(LM);
         q.beam_spec = A == 2 && !any_q0 && B == 10 && p >= 2 && p <= 5 && !K.no_specialized;
         const uint32_t by_lds = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.SL.total + 256)));
-        const uint32_t waves_per_simd = (q.beam_spec && p <= FLORIA_SLAB_LOW_P_MAX) ? FLORIA_SLAB_WAVES_LOW_P : FLORIA_FAST_WAVES;
+        const uint32_t waves_per_simd = (uint32_t)fl::slab_waves(q.beam_spec ? (int)p : 0);
         q.beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * waves_per_simd, by_lds);
         q.beam_slots = std::min(q.beam_slots, nj_max);
         const uint64_t slab_code_bytes = (uint64_t)LM * p * ((span_max + 15u) & ~15u);              // beam_slab_kernel: one code byte per (slab, position)
@@ -461,7 +457,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
     hipStream_t ls[floria_hip_ctx::MAX_LANES];
     for (uint32_t l = 0; l < n_lanes; ++l) {
         if (l == 0) { ls[0] = ctx->stream; continue; }
-        if (W > 1 && (l % W) >= 3 && !K.spec_flat) {        // a speculative stage's lanes of ploidy >= 4: lowest dispatch priority, so that the ploidies every
+        if (W > 1 && (l % W) >= 3) {        // a speculative stage's lanes of ploidy >= 4: lowest dispatch priority, so that the ploidies every
                                                             // block needs get the wave slots first and the stop rule is known before most of these jobs start
             if (!ctx->gstream_low[l]) {
                 int least = 0, greatest = 0;
@@ -502,7 +498,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                 for (uint32_t j = 1; j < stage.size(); ++j) HIPCHK(hipStreamWaitEvent(ls[g * W + j], ctx->ev_fork[g * W], 0));
             }
             for (uint32_t jj = 0; jj < stage.size(); ++jj) {
-                const uint32_t j = K.spec_desc ? (uint32_t)stage.size() - 1 - jj : jj;     // launch order inside a stage (the lane of ploidy stage[j] stays j)
+                const uint32_t j = jj;
                 const uint32_t p = stage[j], lane = g * W + j;
                 const PloidyPlan& q = plan[p];
                 hipStream_t st = ls[lane];
@@ -514,7 +510,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     const uint32_t slots_full = std::min(q.beam_slots, nj);
                     fl::BeamArgs a{};
                     a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
-                    a.queue_head = gqueue; a.blk_done = d_done; a.stop_at = (stage.size() > 1 && !K.spec_flat) ? d_stop : nullptr;
+                    a.queue_head = gqueue; a.blk_done = d_done; a.stop_at = stage.size() > 1 ? d_stop : nullptr;
                     a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane); a.state_stride = q.state_bytes;
                     a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
                     a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
@@ -522,12 +518,11 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
                     a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
                     a.prof = (unsigned long long*)(d_diag + 4);
+                    a.no_bulk = K.no_bulk;
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
-                    const bool chained = K.speculate == 4 && stage.size() > 1;      // every ploidy >= 3 behind the beam search of the one below, pruned by the stop flags
-                    if (chained && p >= 3 && ctx->ev_chain[g][p - 1]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_chain[g][p - 1], 0));
-                    const bool gated = !chained && stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p >= 4;
+                    const bool gated = stage.size() > 1 && stage[0] <= 2 && p >= 4;
                     // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
                     // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
                     const uint32_t slots = gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
@@ -561,11 +556,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     T.end(t);
                     HIPCHK(hipGetLastError());
                     ctx->timing.beam_launches++;
-                    if (chained && p >= 2) {
-                        if (!ctx->ev_chain[g][p]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_chain[g][p], hipEventDisableTiming));
-                        HIPCHK(hipEventRecord(ctx->ev_chain[g][p], st));
-                    }
-                    if (!chained && stage.size() > 1 && !K.spec_flat && !K.spec_desc && stage[0] <= 2 && p == K.spec_gate_p) {
+                    if (stage.size() > 1 && stage[0] <= 2 && p == 2) {          // (the beam search of ploidy 2 opens the gate; ploidy 3 measured worse)
                         if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
                         HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
                     }
@@ -587,7 +578,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.fuse_select = stage.size() == 1 ? 1 : 0;
                     a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
                     a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
-                    if (stage.size() > 1 && !K.spec_flat) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
+                    if (stage.size() > 1) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
                     int t = T.begin(K_OPT, st);
                     auto launch = [&](auto kern) -> hipError_t {
                         if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
@@ -639,6 +630,50 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
 extern "C" {
 
 const char* floria_hip_last_error(void) { return g_err.c_str(); }
+
+}  // extern "C"
+
+namespace {
+// How many streams of this process really execute side by side?  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
+// said otherwise BEFORE the runtime initialised — a host that touched HIP earlier cannot fix it afterwards), and streams that share a queue run one
+// after the other.  The launch plans of s1_core put job groups and the ploidies of a speculative stage on separate streams that WAIT ON EACH OTHER'S
+// EVENTS; with fewer queues than lanes they serialise (measured: 3-8x slower) instead of failing.  So the context measures it once: one wave that spins
+// for ~150 us, alone and then on 12 fresh streams at once; 12 x (time alone) / (time together) is the number of lanes that ran concurrently.
+__global__ void spin_kernel(unsigned long long ticks, unsigned* sink) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (sink && threadIdx.x == 1234567) *sink = 1;
+}
+uint32_t probe_hw_queues(floria_hip_ctx* c) {
+    constexpr int NS = 12;
+    hipStream_t st[NS] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint32_t result = 0;
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    for (int i = 0; i < NS && ok; ++i) ok = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) == hipSuccess;
+    const unsigned long long ticks = 15000;          // 150 us of the 100 MHz wall clock
+    auto timed = [&](int n) -> float {
+        float ms = 0.f;
+        if (hipEventRecord(e0, c->stream) != hipSuccess) return -1.f;
+        for (int i = 0; i < n; ++i) { (void)hipStreamWaitEvent(st[i], e0, 0); hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[i], ticks, (unsigned*)nullptr); }
+        for (int i = 0; i < n; ++i) { (void)hipEventRecord(e1, st[i]); (void)hipStreamWaitEvent(c->stream, e1, 0); }
+        if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+        return ms;
+    };
+    if (ok) {
+        (void)timed(1);                              // (first launch: code object load)
+        const float t1 = timed(1), tn = timed(NS);
+        if (t1 > 0.f && tn > 0.f) result = (uint32_t)std::max(1.0f, std::min((float)NS, (float)NS * t1 / tn + 0.35f));
+    }
+    for (int i = 0; i < NS; ++i) if (st[i]) (void)hipStreamDestroy(st[i]);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    return result ? result : 4;                      // (probe failed: assume the runtime's default)
+}
+}  // namespace
+
+extern "C" {
 const char* floria_hip_version(void) { return "floria_hip 0.1.0 (gfx950)"; }
 
 int floria_hip_create(int device, floria_hip_ctx** out) {
@@ -680,17 +715,18 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
-        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(4, atoi(v)));
-        if (const char* v = getenv("FLORIA_HIP_UPLOAD_SPLIT")) K.upload_split = (uint32_t)std::max(0, std::min(4, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(2, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
-        K.spec_desc = getenv("FLORIA_HIP_SPEC_DESC") != nullptr;
-        K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
-        if (const char* v = getenv("FLORIA_HIP_PIPE_GROUPS")) K.pipe_groups = (uint32_t)std::max(0, std::min<int>(atoi(v), floria_hip_ctx::MAX_GROUPS));
-        if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_P")) K.spec_gate_p = atoi(v) == 3 ? 3 : 2;
         if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_DIV")) K.spec_gate_div = (uint32_t)std::max(1, std::min(16, atoi(v)));
-        K.spec_flat = getenv("FLORIA_HIP_SPEC_FLAT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
         else c->stage_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    }
+    c->hw_queues = probe_hw_queues(c);
+    if (c->hw_queues < 8) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "floria_hip: only %u streams of this process run concurrently on device %d (GPU_MAX_HW_QUEUES was not set to 12 before HIP initialised?): "
+                            "speculative ploidy stages are off and calls use at most two job groups; small batches will be slower.\n", c->hw_queues, device);
     }
     *out = c;
     return 0;
@@ -707,7 +743,6 @@ void floria_hip_destroy(floria_hip_ctx* c) {
         if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
         if (c->gstream_low[g]) (void)hipStreamDestroy(c->gstream_low[g]);
         if (g < floria_hip_ctx::MAX_GROUPS && c->ev_gate[g]) (void)hipEventDestroy(c->ev_gate[g]);
-        if (g < floria_hip_ctx::MAX_GROUPS) for (hipEvent_t e2 : c->ev_chain[g]) if (e2) (void)hipEventDestroy(e2);
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
         if (c->ev_fork[g]) (void)hipEventDestroy(c->ev_fork[g]);
     }
@@ -736,12 +771,11 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
     else if (k == "opt_global") K.opt_global = value != 0;
-    else if (k == "pipe_groups") K.pipe_groups = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
-    else if (k == "spec_flat") K.spec_flat = value != 0;
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
-    else if (k == "speculate") { if (value < -1 || value > 4) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3 | 4"); K.speculate = (int32_t)value; }
+    else if (k == "speculate") { if (value < -1 || value > 2) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2"); K.speculate = (int32_t)value; }
+    else if (k == "no_bulk") K.no_bulk = value != 0;
+    else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
-    else if (k == "upload_split") K.upload_split = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 4));
     else if (k == "trace") K.trace = value != 0;
     else if (k == "reassign_path") { if (value < 0 || value > 2) return fail(FLORIA_E_INVALID, "reassign_path: 0 auto | 1 parallel | 2 chain"); K.reassign_path = (uint32_t)value; }
     else if (k == "slots") ctx->user_slots = (uint32_t)std::max<int64_t>(0, value);
@@ -898,11 +932,7 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_
         // chunk weights: a small first chunk puts the GPU to work early, a small last chunk keeps the chain that starts last short
         std::vector<double> cum(n_chunks + 1, 0.0);
         for (uint32_t g = 0; g < n_chunks; ++g) {
-            double w = 1.0;
-            if (ctx->knobs.upload_split == 1 && n_chunks >= 3) w = (g == 0 || g + 1 == n_chunks) ? 0.5 : 1.0;
-            else if (ctx->knobs.upload_split == 4 && n_chunks >= 3) w = g == 0 ? 0.25 : (g == 1 ? 0.75 : 1.0);
-            else if (ctx->knobs.upload_split == 2 && n_chunks >= 2) w = g == 0 ? 0.5 : 1.0;
-            else if (ctx->knobs.upload_split == 3 && n_chunks >= 2) w = 1.0 + g;
+            const double w = (n_chunks >= 2 && g == 0) ? 0.5 : 1.0;          // (a half-size first chunk measured best)
             cum[g + 1] = cum[g] + w;
         }
         uint32_t g = 0;
@@ -1388,12 +1418,14 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms)
     uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 48 ? 2 : 1);
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
-    // chunked: consecutive chunks may share a job group (knob pipe_groups), which then starts when its LAST chunk has landed
+    if (ctx->hw_queues < 8 && !ctx->knobs.groups) G = std::min<uint32_t>(G, 2);
+    // chunked: consecutive chunks may share a job group (SC.chunk_groups), which then starts when its LAST chunk has landed
     std::vector<uint32_t> chunk_group;
     hipEvent_t group_ev[floria_hip_ctx::MAX_GROUPS] = {};
     if (chunked) {
         const uint32_t nc = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
-        G = ctx->knobs.pipe_groups ? std::min<uint32_t>(ctx->knobs.pipe_groups, nc) : SC.chunk_groups ? std::min<uint32_t>(SC.chunk_groups, nc) : nc;
+        G = SC.chunk_groups ? std::min<uint32_t>(SC.chunk_groups, nc) : nc;
+        if (ctx->hw_queues < 8) G = std::min<uint32_t>(G, 2);          // (groups on shared hardware queues serialise: two at most)
         chunk_group.resize(SC.n_chunks);
         for (uint32_t c = 0; c < SC.n_chunks; ++c) { chunk_group[c] = std::min<uint32_t>((uint32_t)((uint64_t)std::min(c, nc - 1) * G / nc), G - 1); group_ev[chunk_group[c]] = SC.chunk_ev[std::min(c, nc - 1)]; }
     }
@@ -1420,11 +1452,12 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
         // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
-        if (ctx->knobs.speculate < 0 && spec) { const uint32_t w = spec == 1 ? P : std::max<uint32_t>(std::min(3u, P), P > 3 ? P - 3 : 0); if (w * G > 10) spec = 0; }
-        if (spec == 1 || spec == 4) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
+        // (floria_hip_create measured how many streams really run side by side: hw_queues; main, copy and flatten streams take up to three of them)
+        const uint32_t lanes_ok = ctx->hw_queues > 3 ? ctx->hw_queues - 2 : 1;
+        if (ctx->knobs.speculate < 0 && spec) { const uint32_t w = spec == 1 ? P : std::max<uint32_t>(std::min(3u, P), P > 3 ? P - 3 : 0); if (w * G > std::min(10u, lanes_ok)) spec = 0; }
+        if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
                               if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
-        else if (spec == 3) { stages.emplace_back(); for (uint32_t p = 1; p < P; ++p) stages.back().push_back(p); stages.push_back({P}); }
         else for (uint32_t p = 1; p <= P; ++p) stages.push_back({p});
     }
     uint32_t stage_w = 1;

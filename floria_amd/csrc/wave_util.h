@@ -5,9 +5,7 @@
 
 namespace fl {
 
-#ifndef FLORIA_FAST_WAVES
-#define FLORIA_FAST_WAVES 3      // waves per SIMD of the beam_slab_kernel instances that are LDS-limited (ploidy >= 4, runtime-parameter instances)
-#endif
+constexpr int SLAB_WAVES = 3;    // waves per SIMD of the beam_slab_kernel instances that are LDS-limited (ploidy >= 4, runtime-parameter instances)
 
 __device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l) { return ((uint64_t)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l); }

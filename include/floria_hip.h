@@ -318,12 +318,13 @@ int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */
 int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
 
-/* Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy
- * stages: -1 auto, 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}, 3 {1..P-1} then {P}, 4 chained: measured, not used by auto), "spec_flat" (1: speculative stages without
- * the gate / priorities / early stop-rule flags), "spec_gate_div" (grid divisor of the gated ploidies, default 2), "beam_path" (0 auto,
- * 1 generic, 2 slab, 3 wide), "no_specialized", "no_p1_shortcut", "opt_threads" (0|128|512|1024), "opt_global",
- * "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload), "upload_chunks" (chunks of
- * floria_hip_phase_pileups_batch, 0 = auto), "pipe_groups" (job groups of a chunked call, 0 = one per chunk: measured best). */
+/* Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy stages: -1 auto,
+ * 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}), "spec_gate_div" (grid divisor of the gated ploidies of a
+ * speculative stage, default 2), "beam_path" (0 auto, 1 generic, 2 slab, 3 wide), "no_specialized", "no_p1_shortcut", "opt_threads"
+ * (0|128|512|1024), "opt_global", "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload),
+ * "upload_chunks" (chunks of floria_hip_phase_pileups_batch, 0 = auto), "reassign_path", "no_bulk" (tests: every beam step through the general
+ * insert path with its duplicate test), "hw_queues" (tests: override the number of
+ * concurrently running streams floria_hip_create measured; below 8 the launch plans stay within two job groups and do not speculate). */
 int  floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -17,16 +17,20 @@ pytestmark = pytest.mark.gpu
 EPS = 0.03125
 
 
-def phase_config(gpu_ctx, hip_lib, cfg, n_contigs, first=0):
+def phase_config(gpu_ctx, hip_lib, cfg, n_contigs, first=0, packed=False):
     C = synth.CONFIGS[cfg]
     contigs = [synth.make_config_contig(cfg, first + i) for i in range(n_contigs)]
     bc, bs, be = [], [], []
     for i, c in enumerate(contigs):
         s, e = hip_lib.get_range_with_lengths(c.snp_pos, C["block_length"])
         bc += [i] * len(s); bs += list(s); be += list(e)
-    arena, pinned = hip_lib.pin_pileups([c.pileup for c in contigs])
     par = hip_lib.make_params(EPS, C["max_ploidy"], C["beam"])
-    r = gpu_ctx.phase_pileups_batch(pinned, bc, bs, be, par)          # the bench's path: pipelined upload + S1
+    if packed:                                                         # the bench's path: compact wire form, pipelined upload + expansion + S1
+        arena, parr, _ = hip_lib.pack_pileups([c.pileup for c in contigs])
+        r = gpu_ctx.phase_pileups_batch(parr, bc, bs, be, par)
+    else:                                                              # the same from CSR arrays in pinned memory
+        arena, pinned = hip_lib.pin_pileups([c.pileup for c in contigs])
+        r = gpu_ctx.phase_pileups_batch(pinned, bc, bs, be, par)
     arena.free()
     return C, contigs, np.array(bc), np.array(bs), np.array(be), r
 
@@ -104,3 +108,13 @@ def test_config5_full_size_wide_beam(gpu_ctx, hip_lib, oracle_mod):
     rng = np.random.default_rng(5)
     check_properties(r, contigs, bc, bs, be, C, 64, rng)
     check_sample_vs_oracle(oracle_mod, r, contigs, bc, bs, be, C, rng.choice(r.n_blocks, size=64, replace=False))
+
+
+def test_config4_full_size_2000_contigs(gpu_ctx, hip_lib, oracle_mod):
+    # THE headline workload at full size, through the call bench.py times (floria_hip_phase_pileups_batch_packed: 2000 contigs, 1M SNPs, 5M long
+    # reads, ~14.5k blocks, 2.65 GB of CSR pileup travelling as 0.68 GB): properties on every block, 256 random blocks against the oracle bit for bit
+    C, contigs, bc, bs, be, r = phase_config(gpu_ctx, hip_lib, 4, 2000, packed=True)
+    assert 14000 < r.n_blocks < 15000
+    rng = np.random.default_rng(44)
+    check_properties(r, contigs, bc, bs, be, C, 256, rng)
+    check_sample_vs_oracle(oracle_mod, r, contigs, bc, bs, be, C, rng.choice(r.n_blocks, size=256, replace=False))

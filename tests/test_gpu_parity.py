@@ -607,3 +607,59 @@ def test_realign_kernel_equals_the_exact_affine_dp(gpu_ctx):
     assert len(gpu_ctx.realign(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8), np.zeros((0, 4), np.uint8), np.zeros(0, np.uint8))) == 0
     with pytest.raises(Exception):
         gpu_ctx.realign(q[:1], r[:1], al[:1], np.array([5], np.uint8))
+
+
+def _cloned_reads_pileup(rng, n_patterns, copies, n_snps, ploidy, qual=20):
+    """Many byte-identical reads: children of mirrored states then carry identical truncated histograms AND identical scores, i.e. the
+    duplicate test of global_clustering.rs:123-127 fires all the time and the heap is full of exact ties."""
+    hap = rng.integers(0, 2, size=(ploidy, n_snps))
+    reads = []
+    for _ in range(n_patterns):
+        L = int(rng.integers(3, 14)); s = int(rng.integers(1, n_snps - L + 1))
+        snps = np.arange(s, s + L); st = int(rng.integers(0, ploidy))
+        al = hap[st, snps - 1].copy()
+        flip = rng.random(L) < 0.05
+        al[flip] ^= 1
+        for _ in range(int(rng.integers(copies // 2, copies + 1))):
+            reads.append((snps, al, np.full(L, qual)))
+    return Pileup.from_reads(reads)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_general_insert_path_duplicates_and_ties(gpu_ctx, hip_lib, oracle_mod, seed):
+    # The duplicate suppression (`node.1 == new_block && node.0.score >= new_node.score`) compares 128-bit linear hashes of the truncated histograms
+    # instead of the histograms.  The bulk-insert shortcut of the slab kernel skips it whenever a 256-slot screen sees no two children alike; "no_bulk"
+    # sends EVERY step through the general path (entry table, lane-parallel duplicate test, evictions).  On pileups of cloned reads — duplicates
+    # with equal scores in almost every step — both routes, with sequential and speculative stages, must reproduce the oracle's deep comparison.
+    rng = np.random.default_rng(8800 + seed)
+    ploidy = 2 + seed % 3
+    pile = _cloned_reads_pileup(rng, 40 + 10 * (seed % 4), 12, 60, ploidy)
+    S = int(pile.last.max())
+    s = np.array([1, S // 2]); e = np.array([S, S])
+    P, B = 5, [10, 10, 4, 7][seed % 4]
+    ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(EPS, P, B), threads=4)
+    try:
+        for nb in (1, 0):
+            gpu_ctx.set_option("no_bulk", nb)
+            for spec in (0, 1):
+                gpu_ctx.set_option("speculate", spec)
+                rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(EPS, P, B))
+                assert_block_results_equal(ro, rg, f"seed {seed} no_bulk {nb} speculate {spec}")
+                assert rg.min_prune_margin == ro.min_prune_margin
+    finally:
+        gpu_ctx.set_option("no_bulk", 0); gpu_ctx.set_option("speculate", -1)
+
+
+def test_p16_n40_takes_the_generic_kernel(gpu_ctx, hip_lib, oracle_mod):
+    # `floria-hip -p 16 -n 40` — a legal command line of the reference (parse_cmd_line.rs: no upper bound on either) — needs 640 states and 10 240
+    # partition slabs per job: more than the shared-slab kernels' tables hold (beam_slab_kernel 512, beam_wide_kernel 8192), so it is the one
+    # case that runs beam_kernel.h (per-state slabs, LDS heap).  Same results as the oracle, also at -p 9 -n 7 (wide kernel by slab count).
+    rng = np.random.default_rng(1640)
+    pile = random_pileup(rng, 220, 50, 4, max_len=25, err=0.05)
+    S = int(pile.last.max())
+    s = np.array([1]); e = np.array([S])
+    for P, B in ((16, 40), (9, 7)):
+        ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(EPS, P, B), threads=4)
+        rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(EPS, P, B))
+        assert_block_results_equal(ro, rg, f"-p {P} -n {B}")
+        assert rg.min_prune_margin == ro.min_prune_margin

@@ -230,14 +230,24 @@ def test_ploidy_stages_do_not_change_results(gpu_ctx, hip_lib, oracle_mod, cfg, 
     # block is known and are dropped, others are dropped in mid-run), with the pruning switched off, and with full-size gated grids
     try:
         gpu_ctx.set_option("speculate", 1)
-        for slots, flat, div in ((48, 0, 2), (48, 1, 2), (16, 0, 1), (0, 0, 4)):
-            gpu_ctx.set_option("slots", slots); gpu_ctx.set_option("spec_flat", flat); gpu_ctx.set_option("spec_gate_div", div)
+        for slots, div in ((48, 2), (16, 1), (0, 4)):
+            gpu_ctx.set_option("slots", slots); gpu_ctx.set_option("spec_gate_div", div)
             for rep in range(2):
                 r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
-                assert_block_results_equal(out[0], r, f"speculate 1, slots {slots}, flat {flat}, gate_div {div}, rep {rep}")
+                assert_block_results_equal(out[0], r, f"speculate 1, slots {slots}, gate_div {div}, rep {rep}")
                 assert out[0].min_prune_margin == r.min_prune_margin
     finally:
-        gpu_ctx.set_option("speculate", -1); gpu_ctx.set_option("slots", 0); gpu_ctx.set_option("spec_flat", 0); gpu_ctx.set_option("spec_gate_div", 2)
+        gpu_ctx.set_option("speculate", -1); gpu_ctx.set_option("slots", 0); gpu_ctx.set_option("spec_gate_div", 2)
+    # a host that initialised HIP with the default 4 hardware queues: the plan must stay within two job groups and one ploidy per stage
+    # (lanes that share a queue and wait on each other's events serialise), and give the same results
+    try:
+        gpu_ctx.set_option("hw_queues", 4)
+        r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+        t = gpu_ctx.timing()
+        assert t["stage_width"] == 1 and t["streams"] <= 2
+        assert_block_results_equal(out[0], r, "plan for 4 hardware queues")
+    finally:
+        gpu_ctx.set_option("hw_queues", 12)
     n0 = bc.count(0)
     ro = oracle_mod.phase_blocks(contigs[0].pileup, bs[:n0], be[:n0], oracle_mod.make_params(EPS, C["max_ploidy"], C["beam"]), threads=8)
     assert np.array_equal(ro.mec.view(np.uint64), out[1].mec[:n0].view(np.uint64)) and np.array_equal(ro.ploidies_tried, out[1].ploidies_tried[:n0])
@@ -405,3 +415,35 @@ def test_packed_upload_is_validated(gpu_ctx, hip_lib):
     r = gpu_ctx.phase_pileups_batch(parr, [0], [1], [60], par)
     assert r.n_blocks == 1 and r.best_ploidy[0] >= 1
     arena.free()
+
+
+def test_speculative_stages_under_stress(gpu_ctx, hip_lib):
+    # race hunter for the speculative ploidy stages (the path every multi-GPU shard takes): a 250-contig config-4 shard — the per-GPU share of the
+    # 8-GPU job — phased again and again with all ploidies at once / {1,2,3}{4,5}, few and many wave slots (over-subscription: jobs are dropped at dequeue
+    # and in mid-run by stop flags that other workgroups publish meanwhile) and 1-3 job groups; EVERY field of EVERY call must equal the sequential stages'
+    contigs = [synth.make_config_contig(4, 700 + i) for i in range(250)]
+    C = synth.CONFIGS[4]
+    res = gpu_ctx.upload_batch([c.pileup for c in contigs])
+    par = hip_lib.make_params(EPS, C["max_ploidy"], C["beam"])
+    bc, bs, be = [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, C["block_length"])
+        bc += [i] * len(s); bs += list(s); be += list(e)
+    try:
+        gpu_ctx.set_option("speculate", 0)
+        ref = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+        n_calls = 0
+        for spec in (1, 2):
+            for slots in (37, 96, 512):
+                for groups in (1, 2, 3):
+                    gpu_ctx.set_option("speculate", spec); gpu_ctx.set_option("slots", slots); gpu_ctx.set_option("groups", groups)
+                    for rep in range(4 if slots == 37 else 6):
+                        r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+                        assert_block_results_equal(ref, r, f"speculate {spec}, slots {slots}, groups {groups}, rep {rep}")
+                        assert r.min_prune_margin == ref.min_prune_margin
+                        n_calls += 1
+        assert n_calls >= 90
+    finally:
+        gpu_ctx.set_option("speculate", -1); gpu_ctx.set_option("slots", 0); gpu_ctx.set_option("groups", 0)
+        for r in res:
+            r.free()
