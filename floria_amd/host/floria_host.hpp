@@ -191,7 +191,8 @@ void write_outputs(Session& s, const std::vector<std::vector<const Frag*>>& part
                    const std::string& out_bam_part_dir, const std::string& prefix, const std::string& contig, const std::vector<GnPosition>& snp_pos_to_genome_pos,
                    const Options& options, const std::vector<const Frag*>& snpless_frags, size_t contig_len);
 // parse_cmd_line.rs:116-135: create the output directory (it must not exist unless --overwrite), cmd.log, contig_ploidy_info.tsv header
-void write_run_files(const Options& options, int argc, char** argv);
+void prepare_contig_dir(const std::string& contig_out_dir, const Options& options);       // --overwrite: remove_dir_all of an existing contig directory (floria.rs:271-281)
+void write_run_files(const Options& options, int argc, char** argv, const std::string& note = std::string());    // note: a second line of cmd.log
 
 // ---- ingest (file_reader.rs) ---------------------------------------------------------------------------------------------------
 struct VcfProfile {          // types_structs.rs:53-58, per contig; plus get_genotypes_from_vcf_hts' position vectors (:113-175)

@@ -369,7 +369,31 @@ BamFile read_bam(const std::string& path, size_t threads) {
             d.need((size_t)4 * n_cigar); r.cigar = BamCigarView{raw.data() + d.o, n_cigar}; d.o += (size_t)4 * n_cigar;
             d.need((size_t)(l_seq + 1) / 2 + l_seq);
             r.seq = BamSeqView{raw.data() + d.o, l_seq}; d.o += (l_seq + 1) / 2;
-            r.qual = BamBytesView{raw.data() + d.o, l_seq};                         // (auxiliary tags are not needed)
+            r.qual = BamBytesView{raw.data() + d.o, l_seq}; d.o += l_seq;
+            // An alignment with more than 65 535 CIGAR operations keeps its real CIGAR in the CG:B,I tag and a placeholder `<l_seq>S<ref_len>N` in the
+            // CIGAR field (SAM spec 4.2.2); htslib's bam_read1 puts the real one back (bam_tag2cigar), so the reference sees it.  The other tags are skipped.
+            if (n_cigar == 2 && (r.cigar[0] & 15u) == 4u && (r.cigar[0] >> 4) == l_seq && (r.cigar[1] & 15u) == 3u) {
+                const size_t end = rec_off[i + 1] - 4;
+                while (d.o + 3 <= end) {
+                    const unsigned char t0c = raw[d.o], t1c = raw[d.o + 1], ty = raw[d.o + 2];
+                    d.o += 3;
+                    size_t len = 0;
+                    if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+                    else if (ty == 's' || ty == 'S') len = 2;
+                    else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+                    else if (ty == 'Z' || ty == 'H') { while (d.o + len < end && raw[d.o + len]) ++len; ++len; }
+                    else if (ty == 'B') {
+                        d.need(5);
+                        const unsigned char sub = raw[d.o];
+                        uint32_t cnt; memcpy(&cnt, raw.data() + d.o + 1, 4);
+                        const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                        if (t0c == 'C' && t1c == 'G' && sub == 'I') { d.o += 5; d.need((size_t)4 * cnt); r.cigar = BamCigarView{raw.data() + d.o, cnt}; break; }
+                        len = 5 + es * cnt;
+                    } else break;                                                    // unknown type: stop looking (the placeholder CIGAR stays)
+                    if (d.o + len > end) break;
+                    d.o += len;
+                }
+            }
         }
     });
     for (size_t i = 0; i < bam.records.size(); ++i) {

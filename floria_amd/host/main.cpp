@@ -20,6 +20,7 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,8 @@ int main(int argc, char** argv) {
     std::string stitch_graph;
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
     std::vector<int> devices;            // --devices: the GPUs the contigs of a batch are dealt to (empty: --device alone)
+    bool eps_as_estimated = false;       // --epsilon-as-estimated: use the auto-estimated -e as it comes (default: rounded to a multiple of 2^-10, see below)
+    std::string run_note;                // second line of cmd.log
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -120,6 +123,7 @@ int main(int argc, char** argv) {
             else if (a == "-q") {}
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
+            else if (a == "--epsilon-as-estimated") eps_as_estimated = true;
             else if (a == "--devices") {                                 // "0-7", "0,2,5", "0-3,6"; a device may be named twice (two contexts on it)
                 std::stringstream ls(val());
                 std::string item;
@@ -130,6 +134,18 @@ int main(int argc, char** argv) {
                     for (int d = lo; d <= hi; ++d) devices.push_back(d);
                 }
                 if (devices.empty()) throw Error(FLORIA_E_INVALID, "--devices: empty list");
+            }
+            else if (a == "--vcf-profile") {                             // (tests) FILE contig ... -> "contig n_snps" and one "pos alleles" line per SNP, no GPU needed
+                const std::string vcf = val();
+                std::vector<std::string> names;
+                while (i + 1 < argc) names.push_back(argv[++i]);
+                const VcfProfile vp = get_vcf_profile(vcf, names);
+                for (const auto& kv : vp.snp_to_genome_pos) {
+                    printf("#%s\t%zu\n", kv.first.c_str(), kv.second.size());
+                    const auto& pam = vp.vcf_pos_allele_map.at(kv.first);
+                    for (GnPosition g : kv.second) { printf("%zu\t", (size_t)g); for (Genotype x : pam.at(g)) putchar((char)x); putchar('\n'); }
+                }
+                return 0;
             }
             else if (a == "--lpt-assign") {                              // (tests) world cost cost ... -> the device of every item, no GPU needed
                 const uint32_t world = (uint32_t)std::stoul(val());
@@ -203,13 +219,32 @@ int main(int argc, char** argv) {
         double tp = now_s();
         const BamFile bam = read_bam(o.bam_file, std::max<size_t>(1, o.num_threads));
         const double t_bam = now_s() - tp;
+        // ---- the epsilon policy (DESIGN.md "Arithmetic").  Every weighted sum of the phasing path is an exact multiple of 2^-24; the only inexact
+        // terms of the reference are its running `+= epsilon` additions, whose rounding depends on hash-map iteration order unless epsilon is dyadic.
+        // For an epsilon that is a multiple of 2^-10 every one of those sums is exact in f64 in ANY order, so the function this library computes IS the
+        // reference's function.  Hence: an auto-estimated epsilon (parse_cmd_line.rs:72-90) is rounded to the nearest multiple of 2^-10 (a change of at
+        // most 0.0005 to an estimate that is itself a coverage-sampled average) and cmd.log says so; an explicit -e is used as given, with one warning
+        // when it is not such a multiple (results are then an equally good solution, but may differ from the Rust binary's in tie-breaking).
+        auto dyadic10 = [](double e) { const double k = e * 1024.0; return k == std::floor(k); };
         if (!have_e || !have_l) {                                                     // parse_cmd_line.rs:72-90
             const auto est = l_epsilon_auto_detect(bam);
             if (!have_l) o.block_length = est.first;
-            if (!have_e) o.epsilon = est.second;
-            fprintf(stderr, "Estimated -l %zu, -e %g (used where not given)\n", est.first, est.second);
+            if (!have_e) {
+                o.epsilon = est.second;
+                if (!eps_as_estimated) {
+                    o.epsilon = std::max(1.0, std::floor(est.second * 1024.0 + 0.5)) / 1024.0;
+                    char buf[256];
+                    snprintf(buf, sizeof buf, "# floria-hip: -e estimated %.17g, used %.10g (rounded to a multiple of 2^-10: every sum of the phasing path is then exact in f64; "
+                                              "--epsilon-as-estimated or an explicit -e override this)", est.second, o.epsilon);
+                    run_note = buf;
+                }
+            }
+            fprintf(stderr, "Estimated -l %zu, -e %g (used where not given: -l %zu, -e %.10g)\n", est.first, est.second, o.block_length, o.epsilon);
         }
-        if (!ingest_only) write_run_files(o, argc, argv);
+        if (!dyadic10(o.epsilon))
+            fprintf(stderr, "floria-hip: warning: -e %.17g is not a multiple of 2^-10; sums of epsilon terms are then rounded once here and term by term (in hash-map order) in floria, "
+                            "so haplosets can differ from floria's in exact ties (e.g. -e %.10g avoids that)\n", o.epsilon, std::max(1.0, std::floor(o.epsilon * 1024.0 + 0.5)) / 1024.0);
+        if (!ingest_only) write_run_files(o, argc, argv, run_note);
         const std::vector<std::string> contigs = get_contigs_to_phase(bam);
         tp = now_s();
         const VcfProfile vp = get_vcf_profile(o.vcf_file, contigs);
@@ -277,6 +312,7 @@ int main(int argc, char** argv) {
                     const std::string& contig = todo[done + i];
                     ContigWork& w = got[i];
                     w.name = contig; w.out_dir = o.out_dir + "/" + contig;
+                    if (!ingest_only) prepare_contig_dir(w.out_dir, o);
                     const auto fa = fasta.find(contig);
                     auto fr = ing[i]->finish();
                     ing[i].reset();

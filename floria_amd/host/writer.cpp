@@ -12,6 +12,7 @@
 
 #include <zlib.h>
 
+#include <ftw.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -58,13 +59,14 @@ void allele_order(const uint32_t* cnt, int* order, int* n) {
 
 }  // namespace
 
-void write_run_files(const Options& o, int argc, char** argv) {
+void write_run_files(const Options& o, int argc, char** argv, const std::string& note) {
     struct stat st;
     if (stat(o.out_dir.c_str(), &st) == 0 && !o.overwrite)
         throw Error(FLORIA_E_INVALID, "Output directory exists; output directory must not be an existing directory. Use --overwrite to overwrite existing directory.");
     mkdir_p(o.out_dir);
     std::ofstream cmd(o.out_dir + "/cmd.log", std::ios::trunc);
     for (int i = 0; i < argc; ++i) cmd << argv[i] << " ";
+    if (!note.empty()) cmd << "\n" << note << "\n";              // (the first line is the reference's; what this build decided beyond the command line follows)
     std::ofstream pl(o.out_dir + "/contig_ploidy_info.tsv", std::ios::trunc);                      // constants.rs:24
     pl << "contig\taverage_straincount\twhole_contig_multiplicity\tapproximate_coverage_ignoring_indels\ttotal_vartig_bases_covered\t"
           "average_straincount_min15hapq\taverage_straincount_min30hapq\taverage_straincount_min45hapq\tavg_err\n";
@@ -284,6 +286,14 @@ void write_reads(const std::vector<std::vector<const Frag*>>& part, const std::v
     }
 }
 
+// floria.rs:271-281: with --overwrite an existing contig directory is removed (remove_dir_all) before anything of the contig is written, so that
+// nothing of an earlier run survives in it (read directories of --output-reads, debug dumps); without --overwrite the run has already refused an
+// existing output directory
+void prepare_contig_dir(const std::string& dir, const Options& o) {
+    struct stat st;
+    if (o.overwrite && stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode))
+        nftw(dir.c_str(), [](const char* p, const struct stat*, int, struct FTW*) -> int { return remove(p); }, 32, FTW_DEPTH | FTW_PHYS);
+}
 std::string write_contig_files(const ContigWork& w, const Options& o) {
     std::string row = write_contig_files(w.final_parts, w.final_ranges, w.out_dir, w.name, w.name, *w.snp_to_genome_pos, w.snpless, w.contig_len, w.hq, w.stats);
     if (o.output_reads) {                                                                   // file_writer.rs:68-84

@@ -199,9 +199,24 @@ def test_auto_estimated_parameters(floria_hip, tmp_path):
     out = str(tmp_path / "o3")
     r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+)", r.stderr)
+    m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+) \(used where not given: -l (\d+), -e ([0-9.eE+-]+)\)", r.stderr)
     assert m and 0.01 <= float(m.group(2)) < 0.2 and int(m.group(1)) >= 500
+    # the epsilon policy: the estimate is rounded to a multiple of 2^-10 (there every sum of the path is exact and the product's function is the
+    # reference's), cmd.log records it on a second line, and no "not a multiple" warning is printed
+    used = float(m.group(4))
+    assert used * 1024 == int(used * 1024) and abs(used - float(m.group(2))) <= 0.5 / 1024 + 1e-12
+    lines = open(os.path.join(out, "cmd.log")).read().split("\n")
+    assert lines[1].startswith("# floria-hip: -e estimated") and f"used {used:.10g}" in lines[1]
+    assert "not a multiple of 2^-10" not in r.stderr
     assert os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))
+    # an explicit non-dyadic -e is used as given, with one warning; --overwrite removes what an earlier run left in the contig directory
+    stale = os.path.join(out, c.name, "long_reads")
+    os.makedirs(stale); open(os.path.join(stale, "0_part.fastq"), "w").write("stale")
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", "0.04", "-l", "10000", "--overwrite"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("not a multiple of 2^-10") == 1 and "0.0400390625" in r.stderr
+    assert not os.path.exists(stale) and os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))
+    assert len(open(os.path.join(out, "cmd.log")).read().strip().split("\n")) == 1
 
 
 def tree_bytes(root):

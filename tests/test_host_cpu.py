@@ -399,3 +399,148 @@ def test_lpt_dealing_of_contigs_to_devices_matches_the_bench_queue(floria_hip):
         if n:
             load = np.bincount(got, weights=costs, minlength=world)
             assert load.max() - load.min() <= costs.max() + 1e-9 or n < world
+
+
+def test_vcf_parser_on_the_reference_fixture(floria_hip, hip_lib):
+    # tests/golden/test.vcf is the reference's own tests/test.vcf (Longshot 0.4.0 output for NZ_CP081897.1, long INFO fields, FORMAT/sample columns): a file
+    # this repository did not write.  The C++ reader (ingest.cpp: get_vcf_profile, file_reader.rs:239-314) must find its 954 SNPs at the positions an
+    # independent parse of the text gives (0-based, as rust-htslib's record.pos()), with REF + ALT as the allele list, and get_range_with_lengths must cut
+    # them into 17 / 33 / 176 blocks at -l 10000 / 5000 / 500.
+    import subprocess
+    vcf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test.vcf")
+    r = subprocess.run([floria_hip, "--vcf-profile", vcf, "NZ_CP081897.1", "some_other_contig"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "#NZ_CP081897.1\t954" and len(lines) == 955
+    got_pos = np.array([int(l.split("\t")[0]) for l in lines[1:]], np.int64)
+    got_al = [l.split("\t")[1] for l in lines[1:]]
+    want_pos, want_al = [], []
+    for l in open(vcf):
+        if l.startswith("#"):
+            continue
+        f = l.rstrip("\n").split("\t")
+        alts = f[4].split(",")
+        if len(f[3]) == 1 and all(len(a) == 1 and a in "ACGT" for a in alts) and f[3] in "ACGT":          # the SNP filter of file_reader.rs:290-300
+            want_pos.append(int(f[1]) - 1); want_al.append(f[3] + "".join(alts))
+    assert np.array_equal(got_pos, np.array(want_pos)) and got_al == want_al
+    assert np.array_equal(got_pos + 1, np.load(os.path.join(os.path.dirname(vcf), "test_vcf_positions.npy")))      # (the .npy holds the 1-based POS column)
+    assert [len(hip_lib.get_range_with_lengths(got_pos, L)[0]) for L in (10000, 5000, 500)] == [17, 33, 176]
+
+
+# ---- a BAM written byte by byte from the SAM/BAM specification (SAMv1 §4.1 BGZF, §4.2 BAM), by nothing of floria_amd/synth_bam.py -----------------------
+def _bgzf_member(payload, level=6):
+    import struct, zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    cdata = co.compress(payload) + co.flush()
+    bsize = 12 + 6 + len(cdata) + 8 - 1                                     # total block size minus 1
+    assert bsize < 65536
+    return (b"\x1f\x8b\x08\x04" + struct.pack("<IBBH", 0, 0, 255, 6) + b"BC" + struct.pack("<HH", 2, bsize) + cdata
+            + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
+
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")        # the 28-byte EOF marker of the specification
+
+
+def _bam_record(ref_id, pos, name, flag, mapq, cigar, seq, qual, tags=b"", real_cigar_in_cg=False):
+    import struct
+    ops = "MIDNSHP=X"
+    enc = lambda cg: b"".join(struct.pack("<I", (n << 4) | ops.index(op)) for op, n in cg)
+    l_seq = len(seq)
+    ref_len = sum(n for op, n in cigar if op in "MDN=X")
+    field_cigar = cigar
+    if real_cigar_in_cg:                                                     # > 65535 operations: placeholder in the field, the real CIGAR in CG:B,I
+        field_cigar = [("S", l_seq), ("N", ref_len)]
+        tags = tags + b"CGBI" + struct.pack("<I", len(cigar)) + enc(cigar)
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    nib = [code[c] for c in seq] + ([0] if l_seq % 2 else [])
+    packed = bytes((nib[i] << 4) | nib[i + 1] for i in range(0, len(nib), 2))
+    end = pos + max(ref_len, 1)
+    def reg2bin(b, e):                                                       # SAMv1 §5.3
+        e -= 1
+        for sh, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if b >> sh == e >> sh:
+                return off + (b >> sh)
+        return 0
+    body = struct.pack("<iiBBHHHIiii", ref_id, pos, len(name) + 1, mapq, reg2bin(max(pos, 0), max(end, 1)) if ref_id >= 0 else 4680, len(field_cigar), flag, l_seq, -1, -1, 0)
+    body += name.encode() + b"\0" + enc(field_cigar) + packed + bytes(qual) + tags
+    return struct.pack("<I", len(body)) + body
+
+
+def test_bam_assembled_byte_by_byte_from_the_specification(floria_hip, tmp_path):
+    """The ingest faces a file nothing of this repository's BAM writer produced: BGZF members cut at arbitrary places (inside the header, inside a
+    record, a stored level-0 member, an EMPTY member in mid-file, the EOF marker), header text and two references, records with auxiliary tags (A, i,
+    Z, B arrays) behind the qualities, the operations = X N P D I S H, an unmapped and a secondary record, an N base on a SNP, and an alignment with
+    70 000 CIGAR operations (placeholder CIGAR + CG:B,I tag, SAMv1 §4.2.2).  Expectations are derived by hand from file_reader.rs:184-235, 661-736."""
+    import struct
+    L1, L2 = 120000, 3000
+    rng = np.random.default_rng(77)
+    ref1 = "".join("ACGT"[i] for i in rng.integers(0, 4, size=L1)); ref2 = "".join("ACGT"[i] for i in rng.integers(0, 4, size=L2))
+    nxt = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    snps1 = [1000 + 400 * i for i in range(110)]                             # 0-based positions on c1: SNP k+1 at snps1[k] (1000 .. 44600)
+    snps2 = [100 + 50 * i for i in range(40)]
+    prefix = str(tmp_path / "spec")
+    open(prefix + ".fa", "w").write(f">c1\n{ref1}\n>c2\n{ref2}\n")
+    with open(prefix + ".vcf", "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for q in snps1:
+            f.write(f"c1\t{q + 1}\t.\t{ref1[q]}\t{nxt[ref1[q]]}\t50\tPASS\tDP=10\n")
+        for q in snps2:
+            f.write(f"c2\t{q + 1}\t.\t{ref2[q]}\t{nxt[ref2[q]]}\t50\tPASS\tDP=10\n")
+
+    def with_alt(ref, beg, end, alt_positions):
+        s = list(ref[beg:end])
+        for q in alt_positions:
+            s[q - beg] = nxt[ref[q]]
+        return "".join(s)
+    tags = b"NMC\x03" + b"XAAx" + b"MDZ10A5\0" + b"ZBBs" + struct.pack("<Ihh", 2, -3, 7) + b"ASi" + struct.pack("<i", 1234)
+    recs = []
+    # R1  5S 150= 1X 100= 3P 200M : reference 900..1351; SNP 1 (1000) sits in the `=` run with the ALT base (the op letter is not what decides), SNP 2 (1400) not reached
+    s1 = "ACGTA" + with_alt(ref1, 900, 1351, [1000])
+    recs.append(_bam_record(0, 900, "R1_eqxp", 0, 60, [("S", 5), ("=", 150), ("X", 1), ("=", 100), ("P", 3), ("M", 200)], s1, [30] * len(s1), tags))
+    # R2  300M 1200N 300M : 1300..1599 aligned (SNP 2 at 1400, REF), 1600..2799 skipped (SNPs 3..5), 2800..3099 aligned (SNP 6 at 3000, ALT)
+    s2 = with_alt(ref1, 1300, 1600, []) + with_alt(ref1, 2800, 3100, [3000])
+    recs.append(_bam_record(0, 1300, "R2_skip", 16, 60, [("M", 300), ("N", 1200), ("M", 300)], s2, [30] * len(s2)))
+    # R3  deletion over SNP 8 (3800), insertion of 2 before SNP 9 (4200): 3700..4399; calls at SNP 9 only... and SNP 8 lost
+    body = with_alt(ref1, 3700, 4400, [4200])
+    s3 = body[:100] + body[101:300] + "GG" + body[300:]                       # D at offset 100 (= 3800), I after offset 300
+    recs.append(_bam_record(0, 3700, "R3_indel", 0, 60, [("M", 100), ("D", 1), ("M", 199), ("I", 2), ("M", 400)], s3, [30] * len(s3), b"NMC\x03"))
+    # R4  an N base on SNP 10 (4600) -> no call there; SNP 11 (5000) ALT
+    s4 = list(with_alt(ref1, 4500, 5100, [5000])); s4[100] = "N"
+    recs.append(_bam_record(0, 4500, "R4_nbase", 0, 60, [("M", 600)], "".join(s4), [30] * 600))
+    # R5  secondary (filtered), R6 MAPQ 3 (filtered)
+    recs.append(_bam_record(0, 4500, "R5_secondary", 256, 60, [("M", 600)], with_alt(ref1, 4500, 5100, [4600]), [30] * 600))
+    recs.append(_bam_record(0, 4500, "R6_lowq", 0, 3, [("M", 600)], with_alt(ref1, 4500, 5100, [4600]), [30] * 600))
+    # R7  70 000 operations: 35 000 x (1M 1I) from 9000: reference 9000..43999, read base of reference position p at offset 2 (p - 9000); ALT at SNPs 21 (9000) .. 108 (43800),
+    #     every fourth one REF
+    alt_at = [q for k, q in enumerate(snps1) if 9000 <= q < 44000 and k % 4]
+    r7 = with_alt(ref1, 9000, 44000, alt_at)
+    s7 = "".join(b + "T" for b in r7)
+    recs.append(_bam_record(0, 9000, "R7_longcigar", 0, 60, [("M", 1), ("I", 1)] * 35000, s7, [30] * len(s7), b"NMC\x01", real_cigar_in_cg=True))
+    # R8  on the second reference: SNPs 1..4 of c2 (100, 150, 200, 250), ALT at 150
+    recs.append(_bam_record(1, 90, "R8_c2", 0, 60, [("M", 200)], with_alt(ref2, 90, 290, [150]), [30] * 200))
+    # R9  unmapped (flag 4, no reference)
+    recs.append(_bam_record(-1, -1, "R9_unmapped", 4, 0, [], "ACGTACGT", [20] * 8))
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:%d\n@SQ\tSN:c2\tLN:%d\n@PG\tID:byhand\n" % (L1, L2)
+    stream = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 2)
+    for nm, ln in ((b"c1", L1), (b"c2", L2)):
+        stream += struct.pack("<I", len(nm) + 1) + nm + b"\0" + struct.pack("<I", ln)
+    stream += b"".join(recs)
+    cuts = [0, 3, 61, 200, 200, 5000, 5003, 60000, 120000, len(stream)]       # inside the magic, the header text, records; an empty member (200, 200)
+    with open(prefix + ".bam", "wb") as f:
+        for k in range(len(cuts) - 1):
+            f.write(_bgzf_member(stream[cuts[k]:cuts[k + 1]], level=0 if k == 2 else 6))
+        f.write(_BGZF_EOF)
+    got, err = ingest(floria_hip, prefix, tmp_path, extra=("--snp-count-filter", "10", "--no-realign", "-t", "3"))
+    c1 = {g["name"]: g for g in got["c1"]["reads"]}
+    c2 = {g["name"]: g for g in got["c2"]["reads"]}
+    cells = lambda g: [(c[0], c[1]) for c in g["cells"]]
+    assert sorted(c1) == ["R1_eqxp", "R2_skip", "R3_indel", "R4_nbase", "R7_longcigar"] and sorted(c2) == ["R8_c2"]
+    assert cells(c1["R1_eqxp"]) == [(1, 1)]
+    assert cells(c1["R2_skip"]) == [(2, 0), (6, 1)]
+    assert cells(c1["R3_indel"]) == [(9, 1)]
+    assert cells(c1["R4_nbase"]) == [(11, 1)]
+    want7 = [(k + 1, 1 if k % 4 else 0) for k, q in enumerate(snps1) if 9000 <= q < 44000]
+    assert cells(c1["R7_longcigar"]) == want7 and len(want7) == 88
+    assert c1["R7_longcigar"]["span"][0] == 9000
+    assert cells(c2["R8_c2"]) == [(1, 0), (2, 1), (3, 0), (4, 0)]
+    assert all(c[2] == 30 for g in list(c1.values()) + list(c2.values()) for c in g["cells"])
