@@ -235,11 +235,31 @@ struct BamFile {
     std::vector<uint64_t> target_len;
     std::vector<BamRecord> records;    // file order
     std::vector<std::vector<uint32_t>> by_tid;     // record indices per target, file order (what an indexed fetch() of the contig yields)
+    int32_t tid_begin = 0, tid_end = 0;            // BamStream segments: the targets [tid_begin, tid_end) are COMPLETE in this segment (read_bam: all of them)
     BamFile() = default;
     BamFile(BamFile&&) = default;
     BamFile& operator=(BamFile&&) = default;
     BamFile(const BamFile&) = delete;
     BamFile& operator=(const BamFile&) = delete;
+};
+// A coordinate-sorted BAM in bounded memory: the file is mapped, its BGZF members are indexed from their headers (no inflation), and next() inflates
+// (in parallel) just enough members to return the records of the next run of COMPLETE targets — at least `min_bytes` of inflated records, more only when one
+// target alone is larger.  The reference reaches the same records through the .bai index, one contig at a time (file_reader.rs:389-436); no index is
+// needed here because targets come in header order in a sorted file.  A file that is not sorted by target is refused, a gzip file without BGZF members
+// is read whole (one segment).
+class BamStream {
+public:
+    BamStream(const std::string& path, size_t threads = 1);
+    ~BamStream();
+    BamStream(const BamStream&) = delete;
+    BamStream& operator=(const BamStream&) = delete;
+    const std::vector<std::string>& target_names() const;
+    bool next(BamFile& segment, size_t min_bytes);     // false: end of file (every target has been handed out)
+    void rewind();
+    size_t peak_buffer_bytes() const;                  // largest inflated buffer so far (what "bounded" means for this file)
+private:
+    struct Impl;
+    std::unique_ptr<Impl> p_;
 };
 BamFile read_bam(const std::string& path, size_t threads = 1);                         // BGZF + BAM, whole file (no index needed); members and records decode in parallel
 std::vector<std::string> get_contigs_to_phase(const BamFile& bam);                     // file_reader.rs:738-746
@@ -272,6 +292,19 @@ private:
     std::unique_ptr<Impl> p_;
 };
 std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam);                   // :749-826
+// The same fed segment by segment (complete targets in header order, as BamStream::next yields them): done() once 1000 columns have been sampled,
+// which is where the reference's pileup loop breaks as well.
+class EpsilonEstimator {
+public:
+    EpsilonEstimator();
+    ~EpsilonEstimator();
+    void feed(const BamFile& segment);
+    bool done() const;
+    std::pair<size_t, double> result();                // (block length, epsilon)
+private:
+    struct Impl;
+    std::unique_ptr<Impl> p_;
+};
 
 // part_block_manip.rs:517-616: (hapqs, rel_err per haploset, avg_err) — the HAPQ / REL_ERR header fields and the contig table's avg_err.
 struct HapqResult { std::vector<uint8_t> hapqs; std::vector<double> rel_err; double avg_err = 0.0; };

@@ -20,6 +20,10 @@
 // record's index among the contig's records, as with the reference's fetch().
 #include "floria_host.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -73,7 +77,8 @@ template <class F> void parallel_tasks(size_t n, size_t threads, F&& f) {
 // BGZF members carry their compressed size (extra subfield 'B','C') and end with ISIZE, so their places in the output are known
 // before any is inflated: -> false if `in` is not made of BGZF members only (plain gzip: the serial path takes it)
 struct BgzfBlock { size_t in_off, in_len, out_off, out_len; };
-bool bgzf_index(const std::vector<unsigned char>& in, std::vector<BgzfBlock>& blocks) {
+struct ByteSpan { const unsigned char* p; size_t n; size_t size() const { return n; } const unsigned char& operator[](size_t i) const { return p[i]; } };
+bool bgzf_index(const ByteSpan& in, std::vector<BgzfBlock>& blocks) {
     size_t o = 0, out = 0;
     while (o < in.size()) {
         if (o + 18 > in.size() || in[o] != 0x1f || in[o + 1] != 0x8b || in[o + 2] != 8 || !(in[o + 3] & 4)) return false;
@@ -97,7 +102,7 @@ bool bgzf_index(const std::vector<unsigned char>& in, std::vector<BgzfBlock>& bl
 std::vector<unsigned char> bgzf_inflate_all(const std::vector<unsigned char>& in, const std::string& what, size_t threads) {
     std::vector<unsigned char> out;
     std::vector<BgzfBlock> blocks;
-    if (threads > 1 && bgzf_index(in, blocks)) {
+    if (threads > 1 && bgzf_index(ByteSpan{in.data(), in.size()}, blocks)) {
         out.resize(blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_len);
         const size_t per = 64;                                                     // members per task
         parallel_tasks((blocks.size() + per - 1) / per, threads, [&](size_t t) {
@@ -321,40 +326,18 @@ void realign(const std::string& ref_gn, Frag& frag, const BamSeqView& read_seq, 
     }
 }
 
-}  // namespace
-
-BamFile read_bam(const std::string& path, size_t threads) {
-    const bool trace = getenv("FLORIA_HOST_TRACE") != nullptr;
-    const auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now();
-    const std::vector<unsigned char> packed = slurp(path);
-    if (trace) fprintf(stderr, "[read_bam] file %.3fs (%zu MiB)\n", now() - t0, packed.size() >> 20);
-    t0 = now();
-    BamFile bam;
-    bam.raw = bgzf_inflate_all(packed, path, threads);
-    const std::vector<unsigned char>& raw = bam.raw;
-    if (trace) fprintf(stderr, "[read_bam] inflate %.3fs (%zu MiB)\n", now() - t0, raw.size() >> 20);
-    t0 = now();
-    Cursor c{raw.data(), raw.size(), 0, path};
-    c.need(4);
-    if (memcmp(raw.data(), "BAM\1", 4) != 0) throw Error(FLORIA_E_INVALID, path + " is not a BAM file");
-    c.o = 4;
-    const uint32_t l_text = c.u32(); c.need(l_text); c.o += l_text;
-    const uint32_t n_ref = c.u32();
-    for (uint32_t i = 0; i < n_ref; ++i) {
-        const uint32_t l_name = c.u32(); c.need(l_name);
-        bam.target_names.emplace_back((const char*)raw.data() + c.o, l_name ? l_name - 1 : 0); c.o += l_name;
-        bam.target_len.push_back(c.u32());
-    }
-    bam.by_tid.resize(bam.target_names.size());
+// the records of bam.raw[begin, end) (whole records) -> bam.records (views into bam.raw) and bam.by_tid
+void decode_records(BamFile& bam, size_t begin, size_t end, const std::string& path, size_t threads) {
     // record boundaries first (a walk over the block_size fields), then the records are decoded independently
+    const std::vector<unsigned char>& raw = bam.raw;
+    Cursor c{raw.data(), end, begin, path};
     std::vector<size_t> rec_off;
-    while (c.o < raw.size()) {
+    while (c.o < end) {
         const uint32_t block_size = c.u32(); c.need(block_size);
         rec_off.push_back(c.o);
         c.o += block_size;
     }
-    rec_off.push_back(raw.size() + 4);
+    rec_off.push_back(end + 4);
     bam.records.resize(rec_off.size() - 1);
     const size_t per = 256;
     parallel_tasks((bam.records.size() + per - 1) / per, threads, [&](size_t t) {
@@ -400,8 +383,210 @@ BamFile read_bam(const std::string& path, size_t threads) {
         const int32_t tid = bam.records[i].tid;
         if (tid >= 0 && (size_t)tid < bam.by_tid.size()) bam.by_tid[tid].push_back((uint32_t)i);
     }
+}
+
+}  // namespace
+
+BamFile read_bam(const std::string& path, size_t threads) {
+    const bool trace = getenv("FLORIA_HOST_TRACE") != nullptr;
+    const auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    const std::vector<unsigned char> packed = slurp(path);
+    if (trace) fprintf(stderr, "[read_bam] file %.3fs (%zu MiB)\n", now() - t0, packed.size() >> 20);
+    t0 = now();
+    BamFile bam;
+    bam.raw = bgzf_inflate_all(packed, path, threads);
+    const std::vector<unsigned char>& raw = bam.raw;
+    if (trace) fprintf(stderr, "[read_bam] inflate %.3fs (%zu MiB)\n", now() - t0, raw.size() >> 20);
+    t0 = now();
+    Cursor c{raw.data(), raw.size(), 0, path};
+    c.need(4);
+    if (memcmp(raw.data(), "BAM\1", 4) != 0) throw Error(FLORIA_E_INVALID, path + " is not a BAM file");
+    c.o = 4;
+    const uint32_t l_text = c.u32(); c.need(l_text); c.o += l_text;
+    const uint32_t n_ref = c.u32();
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        const uint32_t l_name = c.u32(); c.need(l_name);
+        bam.target_names.emplace_back((const char*)raw.data() + c.o, l_name ? l_name - 1 : 0); c.o += l_name;
+        bam.target_len.push_back(c.u32());
+    }
+    bam.by_tid.resize(bam.target_names.size());
+    decode_records(bam, c.o, raw.size(), path, threads);
     if (trace) fprintf(stderr, "[read_bam] records %.3fs\n", now() - t0);
     return bam;
+}
+
+// ---- BamStream -------------------------------------------------------------------------------------------------------------------------
+struct BamStream::Impl {
+    std::string path;
+    size_t threads = 1;
+    int fd = -1;
+    const unsigned char* map = nullptr;
+    size_t map_len = 0;
+    std::vector<BgzfBlock> blocks;            // BGZF members (empty: not a BGZF file -> `whole`)
+    bool bgzf = false;
+    BamFile whole;                            // fallback: the file read at once
+    bool whole_given = false;
+    std::vector<std::string> names;
+    std::vector<uint64_t> lens;
+    size_t first_block = 0, first_skip = 0;   // where the records begin: member index and offset inside its inflated bytes
+    // position
+    size_t bi = 0;                            // next member to inflate
+    std::vector<unsigned char> carry;         // inflated bytes not handed out yet (starts at a record boundary)
+    int32_t done_upto = 0;                    // targets < done_upto have been handed out
+    int32_t last_tid_seen = 0;
+    bool eof = false;
+    size_t peak = 0;
+
+    void inflate_range(size_t b0, size_t b1, unsigned char* dst) const {          // members [b0, b1) -> dst (contiguous)
+        const size_t base = blocks[b0].out_off;
+        const size_t per = 32;
+        parallel_tasks((b1 - b0 + per - 1) / per, threads, [&](size_t t) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) throw Error(FLORIA_E_NOMEM, "inflateInit2 failed");
+            for (size_t b = b0 + t * per; b < std::min(b1, b0 + (t + 1) * per); ++b) {
+                const BgzfBlock& k = blocks[b];
+                zs.next_in = const_cast<unsigned char*>(map) + k.in_off; zs.avail_in = (uInt)k.in_len;
+                unsigned char dummy;
+                zs.next_out = k.out_len ? dst + (k.out_off - base) : &dummy; zs.avail_out = (uInt)k.out_len;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw Error(FLORIA_E_INVALID, path + " is not a valid BGZF/gzip file"); }
+                inflateReset(&zs);
+            }
+            inflateEnd(&zs);
+        });
+    }
+};
+
+BamStream::BamStream(const std::string& path, size_t threads) : p_(new Impl) {
+    Impl& I = *p_;
+    I.path = path; I.threads = std::max<size_t>(1, threads);
+    I.fd = open(path.c_str(), O_RDONLY);
+    if (I.fd < 0) throw Error(FLORIA_E_INVALID, "cannot open " + path);
+    struct stat st;
+    if (fstat(I.fd, &st) != 0 || st.st_size <= 0) throw Error(FLORIA_E_INVALID, path + " is empty or unreadable");
+    I.map_len = (size_t)st.st_size;
+    void* m = mmap(nullptr, I.map_len, PROT_READ, MAP_PRIVATE, I.fd, 0);
+    if (m == MAP_FAILED) throw Error(FLORIA_E_INVALID, "cannot map " + path);
+    I.map = (const unsigned char*)m;
+    I.bgzf = bgzf_index(ByteSpan{I.map, I.map_len}, I.blocks) && !I.blocks.empty();
+    if (!I.bgzf) {                                   // plain gzip (or anything else zlib understands): no member index, the file is read whole
+        I.whole = read_bam(path, threads);
+        I.names = I.whole.target_names; I.lens = I.whole.target_len;
+        I.whole.tid_begin = 0; I.whole.tid_end = (int32_t)I.names.size();
+        return;
+    }
+    // the header: inflate members until magic, text and reference list are complete
+    std::vector<unsigned char> head;
+    size_t b1 = 0;
+    auto have = [&](size_t need) {
+        while (head.size() < need && b1 < I.blocks.size()) {
+            const size_t o = head.size();
+            head.resize(o + I.blocks[b1].out_len);
+            if (I.blocks[b1].out_len) { std::vector<unsigned char> tmp(I.blocks[b1].out_len); I.inflate_range(b1, b1 + 1, tmp.data()); memcpy(head.data() + o, tmp.data(), tmp.size()); }
+            ++b1;
+        }
+        if (head.size() < need) throw Error(FLORIA_E_INVALID, path + " is truncated");
+    };
+    have(12);
+    if (memcmp(head.data(), "BAM\1", 4) != 0) throw Error(FLORIA_E_INVALID, path + " is not a BAM file");
+    uint32_t l_text; memcpy(&l_text, head.data() + 4, 4);
+    size_t o = 8 + (size_t)l_text;
+    have(o + 4);
+    uint32_t n_ref; memcpy(&n_ref, head.data() + o, 4); o += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        have(o + 4);
+        uint32_t l_name; memcpy(&l_name, head.data() + o, 4); o += 4;
+        have(o + l_name + 4);
+        I.names.emplace_back((const char*)head.data() + o, l_name ? l_name - 1 : 0); o += l_name;
+        uint32_t ln; memcpy(&ln, head.data() + o, 4); o += 4;
+        I.lens.push_back(ln);
+    }
+    // the records start at inflated offset o: find its member
+    size_t b = 0;
+    while (b < I.blocks.size() && I.blocks[b].out_off + I.blocks[b].out_len <= o) ++b;
+    I.first_block = b; I.first_skip = b < I.blocks.size() ? o - I.blocks[b].out_off : 0;
+    rewind();
+}
+BamStream::~BamStream() {
+    if (p_->map) munmap(const_cast<unsigned char*>(p_->map), p_->map_len);
+    if (p_->fd >= 0) close(p_->fd);
+}
+const std::vector<std::string>& BamStream::target_names() const { return p_->names; }
+size_t BamStream::peak_buffer_bytes() const { return p_->peak; }
+void BamStream::rewind() {
+    Impl& I = *p_;
+    if (!I.bgzf) { if (I.whole_given) { I.whole = read_bam(I.path, I.threads); I.whole.tid_begin = 0; I.whole.tid_end = (int32_t)I.names.size(); } I.whole_given = false; return; }
+    I.bi = I.first_block; I.carry.clear(); I.done_upto = 0; I.last_tid_seen = 0; I.eof = false;
+    if (I.bgzf && I.first_block < I.blocks.size() && I.first_skip) {       // the rest of the member the header ends in
+        std::vector<unsigned char> tmp(I.blocks[I.first_block].out_len);
+        I.inflate_range(I.first_block, I.first_block + 1, tmp.data());
+        I.carry.assign(tmp.begin() + (ptrdiff_t)I.first_skip, tmp.end());
+        I.bi = I.first_block + 1;
+    }
+}
+bool BamStream::next(BamFile& seg, size_t min_bytes) {
+    Impl& I = *p_;
+    const int32_t n_targets = (int32_t)I.names.size();
+    if (!I.bgzf) {
+        if (I.whole_given) return false;
+        I.whole_given = true;
+        seg = std::move(I.whole);             // (a rewind() after this would need the file again: the whole-file fallback is single-pass unless re-read)
+        I.whole = BamFile();
+        I.peak = std::max(I.peak, seg.raw.size());
+        return true;
+    }
+    if (I.eof && I.done_upto >= n_targets) return false;
+    std::vector<unsigned char> buf;
+    size_t want = std::max<size_t>(min_bytes, 1 << 16);
+    for (;;) {
+        // ---- inflate members until the buffer holds `want` bytes (or the file ends)
+        size_t b1 = I.bi, add = 0;
+        while (b1 < I.blocks.size() && I.carry.size() + buf.size() + add < want) add += I.blocks[b1++].out_len;
+        if (buf.empty()) { buf.swap(I.carry); I.carry.clear(); }
+        if (b1 > I.bi) {
+            const size_t o = buf.size();
+            buf.resize(o + add);
+            I.inflate_range(I.bi, b1, buf.data() + o);
+            I.bi = b1;
+        }
+        const bool at_end = I.bi >= I.blocks.size();
+        // ---- walk the records: [0, cut) = whole records of targets that are certainly complete
+        size_t o = 0, last_start_of_tid = 0, whole_end = 0;
+        int32_t cur_tid = INT32_MIN, prev = I.last_tid_seen;
+        bool saw_unmapped = false;
+        while (o + 4 <= buf.size()) {
+            uint32_t bs; memcpy(&bs, buf.data() + o, 4);
+            if (bs < 32) throw Error(FLORIA_E_INVALID, I.path + ": malformed BAM record");
+            if (o + 4 + (size_t)bs > buf.size()) break;
+            int32_t tid; memcpy(&tid, buf.data() + o + 4, 4);
+            if (tid < 0) { if (!saw_unmapped) { saw_unmapped = true; last_start_of_tid = o; cur_tid = n_targets; } }      // unplaced reads close the file: every target is complete
+            else if (saw_unmapped || tid < prev) throw Error(FLORIA_E_INVALID, I.path + " is not sorted by reference sequence (floria needs a coordinate-sorted, indexed BAM; so does this reader)");
+            else if (tid != cur_tid) { cur_tid = tid; last_start_of_tid = o; prev = tid; }
+            o += 4 + (size_t)bs;
+            whole_end = o;
+        }
+        if (at_end && whole_end != buf.size()) throw Error(FLORIA_E_INVALID, I.path + " is truncated");
+        size_t cut; int32_t complete_upto;
+        if (at_end) { cut = saw_unmapped ? last_start_of_tid : whole_end; complete_upto = n_targets; }
+        else { cut = last_start_of_tid; complete_upto = cur_tid == INT32_MIN ? I.done_upto : std::min(cur_tid, n_targets); }      // the target of the last record may continue
+        if (!at_end && (cut == 0 || complete_upto <= I.done_upto) && !(cur_tid == n_targets)) { want = std::max(want * 2, buf.size() * 2); continue; }   // one target fills the buffer: read on
+        // ---- hand out
+        seg = BamFile();
+        seg.target_names = I.names; seg.target_len = I.lens;
+        seg.by_tid.resize(I.names.size());
+        I.carry.assign(buf.begin() + (ptrdiff_t)cut, buf.begin() + (ptrdiff_t)(at_end ? cut : buf.size()));
+        buf.resize(cut);
+        seg.raw = std::move(buf);
+        I.peak = std::max(I.peak, seg.raw.size() + I.carry.size());
+        decode_records(seg, 0, seg.raw.size(), I.path, I.threads);
+        seg.tid_begin = I.done_upto; seg.tid_end = complete_upto;
+        I.done_upto = complete_upto;
+        I.last_tid_seen = std::max(I.last_tid_seen, std::min(prev, n_targets));
+        if (at_end) { I.eof = true; I.carry.clear(); }
+        return true;
+    }
 }
 
 std::vector<std::string> get_contigs_to_phase(const BamFile& bam) { return bam.target_names; }
@@ -586,18 +771,28 @@ void RealignQueue::append(RealignQueue&& o) {
 
 // file_reader.rs:749-826.  The htslib pileup engine visits every reference position covered by at least one alignment that
 // passes its default mask (unmapped | secondary | qc-fail | duplicate are dropped), contig by contig in coordinate order.
-std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam) {
+struct EpsilonEstimator::Impl {
+    size_t count = 0;
+    std::vector<double> err_vec;
+    std::vector<size_t> read_lengths;
+    bool done = false;
+};
+EpsilonEstimator::EpsilonEstimator() : p_(new Impl) {}
+EpsilonEstimator::~EpsilonEstimator() = default;
+bool EpsilonEstimator::done() const { return p_->done; }
+void EpsilonEstimator::feed(const BamFile& bam) {
+    size_t& count = p_->count;
+    std::vector<double>& err_vec = p_->err_vec;
+    std::vector<size_t>& read_lengths = p_->read_lengths;
+    bool& done = p_->done;
+    if (done) return;
     struct Aln { const BamRecord* r; int64_t beg, end; };
     std::vector<std::vector<Aln>> by_tid(bam.target_names.size());
     for (const BamRecord& r : bam.records) {
         if (r.tid < 0 || (size_t)r.tid >= by_tid.size() || (r.flags & F_ERRORS) || r.cigar.empty()) continue;
         by_tid[r.tid].push_back({&r, r.pos, reference_end(r)});
     }
-    size_t count = 0;
-    std::vector<double> err_vec;
-    std::vector<size_t> read_lengths;
     const size_t stop = 1000;
-    bool done = false;
     auto base_at = [](const BamRecord& r, int64_t pos, char* base) -> bool {          // false: deletion / refskip / not aligned here
         size_t q = 0; int64_t ref = r.pos;
         for (size_t ck = 0; ck < r.cigar.size(); ++ck) {
@@ -655,12 +850,22 @@ std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam) {
             ++count;
         }
     }
+}
+std::pair<size_t, double> EpsilonEstimator::result() {
+    std::vector<size_t>& read_lengths = p_->read_lengths;
+    std::vector<double>& err_vec = p_->err_vec;
     std::sort(read_lengths.begin(), read_lengths.end());
     if (read_lengths.empty()) return {500, 0.01};
     const size_t q_66 = read_lengths[read_lengths.size() * 66 / 100];
     std::sort(err_vec.begin(), err_vec.end());
     const double med66 = err_vec.empty() ? 0.0 : err_vec[err_vec.size() * 66 / 100];
     return {std::max<size_t>(q_66, 500), std::max(med66, 0.01)};             // constants::MINIMUM_BLOCK_SIZE = 500
+}
+
+std::pair<size_t, double> l_epsilon_auto_detect(const BamFile& bam) {
+    EpsilonEstimator e;
+    e.feed(bam);
+    return e.result();
 }
 
 }  // namespace floria

@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
     std::string stitch_graph;
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
     std::vector<int> devices;            // --devices: the GPUs the contigs of a batch are dealt to (empty: --device alone)
+    size_t bam_window = (size_t)512 << 20;   // --bam-window-mb: inflated BAM bytes held at a time (more only when one contig alone is larger)
     bool eps_as_estimated = false;       // --epsilon-as-estimated: use the auto-estimated -e as it comes (default: rounded to a multiple of 2^-10, see below)
     std::string run_note;                // second line of cmd.log
     try {
@@ -124,6 +125,8 @@ int main(int argc, char** argv) {
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
             else if (a == "--epsilon-as-estimated") eps_as_estimated = true;
+            else if (a == "--bam-window-mb") bam_window = std::max<size_t>(1, std::stoul(val())) << 20;
+            else if (a == "--bam-window-kb") bam_window = std::max<size_t>(1, std::stoul(val())) << 10;       // (tests: many segments on a small file)
             else if (a == "--devices") {                                 // "0-7", "0,2,5", "0-3,6"; a device may be named twice (two contexts on it)
                 std::stringstream ls(val());
                 std::string item;
@@ -217,8 +220,9 @@ int main(int argc, char** argv) {
         const double t_all = now_s();
         fprintf(stderr, "Preprocessing VCF/Reference\n");
         double tp = now_s();
-        const BamFile bam = read_bam(o.bam_file, std::max<size_t>(1, o.num_threads));
-        const double t_bam = now_s() - tp;
+        // the BAM is streamed: the records of a run of complete contigs at a time (about --bam-window-mb of inflated records), never the whole file
+        BamStream stream(o.bam_file, std::max<size_t>(1, o.num_threads));
+        double t_bam = now_s() - tp;
         // ---- the epsilon policy (DESIGN.md "Arithmetic").  Every weighted sum of the phasing path is an exact multiple of 2^-24; the only inexact
         // terms of the reference are its running `+= epsilon` additions, whose rounding depends on hash-map iteration order unless epsilon is dyadic.
         // For an epsilon that is a multiple of 2^-10 every one of those sums is exact in f64 in ANY order, so the function this library computes IS the
@@ -227,7 +231,12 @@ int main(int argc, char** argv) {
         // when it is not such a multiple (results are then an equally good solution, but may differ from the Rust binary's in tie-breaking).
         auto dyadic10 = [](double e) { const double k = e * 1024.0; return k == std::floor(k); };
         if (!have_e || !have_l) {                                                     // parse_cmd_line.rs:72-90
-            const auto est = l_epsilon_auto_detect(bam);
+            tp = now_s();
+            EpsilonEstimator estimator;                                               // (a first pass over as much of the file as 1000 sampled columns need)
+            { BamFile seg; while (!estimator.done() && stream.next(seg, bam_window)) estimator.feed(seg); }
+            stream.rewind();
+            const auto est = estimator.result();
+            t_bam += now_s() - tp;
             if (!have_l) o.block_length = est.first;
             if (!have_e) {
                 o.epsilon = est.second;
@@ -245,7 +254,7 @@ int main(int argc, char** argv) {
             fprintf(stderr, "floria-hip: warning: -e %.17g is not a multiple of 2^-10; sums of epsilon terms are then rounded once here and term by term (in hash-map order) in floria, "
                             "so haplosets can differ from floria's in exact ties (e.g. -e %.10g avoids that)\n", o.epsilon, std::max(1.0, std::floor(o.epsilon * 1024.0 + 0.5)) / 1024.0);
         if (!ingest_only) write_run_files(o, argc, argv, run_note);
-        const std::vector<std::string> contigs = get_contigs_to_phase(bam);
+        const std::vector<std::string> contigs = stream.target_names();                 // get_contigs_to_phase (file_reader.rs:738-746)
         tp = now_s();
         const VcfProfile vp = get_vcf_profile(o.vcf_file, contigs);
         const std::map<std::string, std::string> fasta = get_fasta_seqs(o.reference_fasta);
@@ -256,14 +265,22 @@ int main(int argc, char** argv) {
         std::vector<std::unique_ptr<Session>> sessions;
         if (!ingest_only) for (int d : devices) sessions.emplace_back(new Session(d));
         Session* const session_holder = sessions.empty() ? nullptr : sessions[0].get();
-        fprintf(stderr, "Preprocessing: BAM %.3fs (%zu records), VCF + FASTA %.3fs, device %.3fs\n", t_bam, bam.records.size(), t_vcf, now_s() - tp);
+        fprintf(stderr, "Preprocessing: BAM header%s %.3fs, VCF + FASTA %.3fs, device %.3fs\n", (!have_e || !have_l) ? " + parameter estimate" : "", t_bam, t_vcf, now_s() - tp);
 
         std::ofstream dump;
         if (!dump_frags.empty()) dump.open(dump_frags, std::ios::trunc);
         // ---- which contigs (floria.rs:229-262) -------------------------------------------------------------------------------------
         bool warn_first_length = true;
+        const size_t n_threads = std::max<size_t>(1, o.num_threads);
+        double t_ingest = 0., t_s1 = 0., t_stitch = 0., t_s2 = 0., t_stats = 0., t_write = 0., t_realign = 0., t_stream = 0.;
+        size_t n_realign_device = 0, n_batches = 0, n_records = 0, n_segments = 0;
+        BamFile bam;                                  // the current segment: every record of the contigs [tid_begin, tid_end)
+        for (;;) {
+        { const double ts = now_s(); const bool more = stream.next(bam, bam_window); t_stream += now_s() - ts; if (!more) break; }
+        ++n_segments; n_records += bam.records.size();
         std::vector<std::string> todo;
-        for (const std::string& contig : contigs) {
+        for (int32_t tid = bam.tid_begin; tid < bam.tid_end; ++tid) {
+            const std::string& contig = contigs[(size_t)tid];
             if (!o.list_to_phase.empty() && std::find(o.list_to_phase.begin(), o.list_to_phase.end(), contig) == o.list_to_phase.end()) continue;
             const auto pam = vp.vcf_pos_allele_map.find(contig);
             if (pam == vp.vcf_pos_allele_map.end() || pam->second.size() < o.snp_count_filter) {
@@ -275,13 +292,10 @@ int main(int argc, char** argv) {
             }
             todo.push_back(contig);
         }
-        const size_t n_threads = std::max<size_t>(1, o.num_threads);
         // The contigs go through the stages in batches (floria_host.hpp, "many contigs at once"): the host stages of a batch run on -t
         // threads, one contig per task; the device stages once per batch.  A batch is closed at batch_contigs contigs or batch_cells
         // SNP calls, whichever comes first (the pinned staging buffer holds 6 bytes per call).
-        double t_ingest = 0., t_s1 = 0., t_stitch = 0., t_s2 = 0., t_stats = 0., t_write = 0., t_realign = 0.;
-        size_t n_realign_device = 0;
-        size_t done = 0, n_batches = 0;
+        size_t done = 0;
         while (done < todo.size()) {
             // ---- ingest (floria.rs:264-293), one contig per task ----------------------------------------------------------------------
             double t0 = now_s();
@@ -399,6 +413,8 @@ int main(int argc, char** argv) {
             // the Frags of a batch are millions of small objects: freeing them goes to a thread of its own, the next batch's ingest does not wait for it
             std::thread([w = std::make_shared<std::vector<ContigWork>>(std::move(work))]() mutable { w.reset(); }).detach();
         }
+        }       // (next segment of the BAM)
+        fprintf(stderr, "BAM: %zu records in %zu segments, %.3fs of inflate + decode, largest inflated buffer %zu MiB\n", n_records, n_segments, t_stream, stream.peak_buffer_bytes() >> 20);
         fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);

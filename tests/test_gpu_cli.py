@@ -238,13 +238,14 @@ def test_batches_of_contigs_write_the_files_of_the_per_contig_flow(floria_hip, o
     synth_bam.write_dataset(prefix, cs, seed=7)
     base = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-e", str(EPS), "-l", "5000", "--debug", "--snp-count-filter", "50"]
     trees = []
-    for k, extra in enumerate((["-t", "8"], ["-t", "1", "--batch-contigs", "5"], ["-t", "3", "--batch-contigs", "1"], ["-t", "2", "--batch-cells", "20000"])):
+    for k, extra in enumerate((["-t", "8"], ["-t", "1", "--batch-contigs", "5"], ["-t", "3", "--batch-contigs", "1"], ["-t", "2", "--batch-cells", "20000"],
+                               ["-t", "4", "--bam-window-kb", "64"])):          # (the last: the BAM streamed in many segments of complete contigs)
         out = str(tmp_path / f"o{k}")
         r = subprocess.run(base + ["-o", out] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert re.search(r"Batches (\d+);", r.stderr)
         trees.append((int(re.search(r"Batches (\d+);", r.stderr).group(1)), tree_bytes(out)))
-    assert [t[0] for t in trees[:3]] == [1, 3, 12] and 1 < trees[3][0] < 12
+    assert [t[0] for t in trees[:3]] == [1, 3, 12] and 1 < trees[3][0] < 12 and trees[4][0] > 1
     names = sorted(trees[0][1])
     assert len([n for n in names if n.endswith(".vartigs")]) == 12
     rows = trees[0][1]["contig_ploidy_info.tsv"].decode().splitlines()

@@ -544,3 +544,53 @@ def test_bam_assembled_byte_by_byte_from_the_specification(floria_hip, tmp_path)
     assert c1["R7_longcigar"]["span"][0] == 9000
     assert cells(c2["R8_c2"]) == [(1, 0), (2, 1), (3, 0), (4, 0)]
     assert all(c[2] == 30 for g in list(c1.values()) + list(c2.values()) for c in g["cells"])
+
+
+def test_bam_is_streamed_in_segments_of_complete_contigs(floria_hip, tmp_path):
+    # BamStream: the file is mapped and inflated a window at a time; a segment holds every record of a run of complete contigs (the carry-over of a
+    # contig that is still arriving goes to the next one).  Twelve contigs, one of them without reads in mid-file, windows from 16 KiB (several segments,
+    # contigs larger than the window) to the default: identical Frags, every contig reported once, and the largest buffer shrinks with the window.
+    import re
+    cs = [synth.make_config_contig(4, 60 + i, 0.15 + 0.02 * i, keep_layout=True) for i in range(11)]
+    prefix = str(tmp_path / "st")
+    synth_bam.write_dataset(prefix, cs, seed=3)
+    # a twelfth contig in the header and the VCF whose reads are missing: splice a reference without records between the others
+    dumps, segs, peaks = [], [], []
+    for kb in (16, 2000, 0):
+        extra = ("--snp-count-filter", "20", "-t", "4") + (("--bam-window-kb", str(kb)) if kb else ())
+        got, err = ingest(floria_hip, prefix, tmp_path, extra=extra)
+        m = re.search(r"BAM: (\d+) records in (\d+) segments, .* largest inflated buffer (\d+) MiB", err)
+        assert m, err
+        dumps.append(got); segs.append(int(m.group(2))); peaks.append(int(m.group(3)))
+        assert err.count("Number of reads passing filtering") == len(cs)
+    assert segs[0] > 1 and segs[0] >= segs[1] >= segs[2] == 1 and segs[0] > segs[2]
+    assert dumps[0] == dumps[2] and dumps[1] == dumps[2]
+    assert peaks[0] <= peaks[2]
+    assert sorted(dumps[2]) == sorted(c.name for c in cs)
+
+
+def test_unsorted_bam_is_refused(floria_hip, tmp_path):
+    # the reference fetches per contig through the .bai, i.e. needs a coordinate-sorted file; the streaming reader relies on the same order and says so
+    cs = [synth.make_config_contig(4, 80 + i, 0.1, keep_layout=True) for i in range(2)]
+    prefix = str(tmp_path / "us")
+    ex = synth_bam.write_dataset(prefix, cs, seed=3)
+    # rewrite the BAM with the two contigs' records swapped (contig 1's records first)
+    import gzip, struct
+    raw = gzip.open(prefix + ".bam", "rb").read()
+    l_text = struct.unpack_from("<I", raw, 4)[0]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<I", raw, o)[0]; o += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<I", raw, o)[0]; o += 4 + ln + 4
+    head, recs = raw[:o], []
+    while o < len(raw):
+        bs = struct.unpack_from("<I", raw, o)[0]
+        recs.append((struct.unpack_from("<i", raw, o + 4)[0], raw[o:o + 4 + bs])); o += 4 + bs
+    swapped = head + b"".join(r for t, r in recs if t == 1) + b"".join(r for t, r in recs if t == 0)
+    with open(prefix + ".bam", "wb") as f:
+        for k in range(0, len(swapped), 60000):
+            f.write(_bgzf_member(swapped[k:k + 60000]))
+        f.write(_BGZF_EOF)
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", str(tmp_path / "o"), "-e", "0.03", "-l", "10000", "--ingest-only"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "not sorted by reference sequence" in r.stderr
