@@ -36,6 +36,7 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 
 namespace floria {
@@ -312,7 +313,9 @@ void realign(const std::string& ref_gn, Frag& frag, const BamSeqView& read_seq, 
             for (size_t i = 0; i < 2 * flank; ++i) { queue->read_windows.push_back(q[i]); queue->ref_windows.push_back(up(r[i])); }
             for (size_t a = 0; a < FLORIA_MAX_ALLELES; ++a) queue->alleles.push_back(a < alleles.size() ? up(alleles[a]) : 0);
             queue->n_alleles.push_back((uint8_t)alleles.size());
-            queue->dst.push_back(&kv.second);                                   // (a map node: stays where it is when the Frag moves)
+            // (the entry lives in the FlatMap's heap storage: it stays where it is when the Frag or the vector holding it MOVES — Frag is nothrow-movable,
+            // asserted below — and nothing is inserted into seq_dict between here and realign_queue_on_device; copying a Frag would invalidate it)
+            queue->dst.push_back(&kv.second);
             continue;
         }
         int best_score = INT32_MIN;
@@ -415,6 +418,9 @@ BamFile read_bam(const std::string& path, size_t threads) {
     if (trace) fprintf(stderr, "[read_bam] records %.3fs\n", now() - t0);
     return bam;
 }
+
+static_assert(std::is_nothrow_move_constructible<Frag>::value && std::is_nothrow_move_assignable<Frag>::value,
+              "RealignQueue::dst points into Frag::seq_dict: a vector of Frags must MOVE its elements when it grows");
 
 // ---- BamStream -------------------------------------------------------------------------------------------------------------------------
 struct BamStream::Impl {

@@ -99,6 +99,8 @@ int main(int argc, char** argv) {
     size_t bam_window = (size_t)512 << 20;   // --bam-window-mb: inflated BAM bytes held at a time (more only when one contig alone is larger)
     bool eps_as_estimated = false;       // --epsilon-as-estimated: use the auto-estimated -e as it comes (default: rounded to a multiple of 2^-10, see below)
     std::string run_note;                // second line of cmd.log
+    std::thread freer;                   // frees the Frags of the previous batch while the next one is ingested; joined before the process leaves main
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } freer_guard{freer};
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -274,6 +276,14 @@ int main(int argc, char** argv) {
         const size_t n_threads = std::max<size_t>(1, o.num_threads);
         double t_ingest = 0., t_s1 = 0., t_stitch = 0., t_s2 = 0., t_stats = 0., t_write = 0., t_realign = 0., t_stream = 0.;
         size_t n_realign_device = 0, n_batches = 0, n_records = 0, n_segments = 0;
+        // every contig that will be phased must be in the reference FASTA: said before anything is written, not when its batch comes up
+        if (!ingest_only)
+            for (const std::string& contig : contigs) {
+                if (!o.list_to_phase.empty() && std::find(o.list_to_phase.begin(), o.list_to_phase.end(), contig) == o.list_to_phase.end()) continue;
+                const auto pam = vp.vcf_pos_allele_map.find(contig);
+                if (pam == vp.vcf_pos_allele_map.end() || pam->second.size() < o.snp_count_filter) continue;
+                if (fasta.find(contig) == fasta.end()) throw Error(FLORIA_E_INVALID, "contig " + contig + " is not in the reference fasta");
+            }
         BamFile bam;                                  // the current segment: every record of the contigs [tid_begin, tid_end)
         for (;;) {
         { const double ts = now_s(); const bool more = stream.next(bam, bam_window); t_stream += now_s() - ts; if (!more) break; }
@@ -411,7 +421,8 @@ int main(int argc, char** argv) {
             for (const std::string& r : rows) append_contig_ploidy_row(o, r);
             t_write += now_s() - t0;
             // the Frags of a batch are millions of small objects: freeing them goes to a thread of its own, the next batch's ingest does not wait for it
-            std::thread([w = std::make_shared<std::vector<ContigWork>>(std::move(work))]() mutable { w.reset(); }).detach();
+            if (freer.joinable()) freer.join();
+            freer = std::thread([w = std::make_shared<std::vector<ContigWork>>(std::move(work))]() mutable { w.reset(); });
         }
         }       // (next segment of the BAM)
         fprintf(stderr, "BAM: %zu records in %zu segments, %.3fs of inflate + decode, largest inflated buffer %zu MiB\n", n_records, n_segments, t_stream, stream.peak_buffer_bytes() >> 20);
@@ -422,7 +433,11 @@ int main(int argc, char** argv) {
         // everything is written and closed: leave without tearing down the records, maps and sequences one by one (seconds for a large BAM)
         if (dump.is_open()) dump.close();
         sessions.clear();
+        // every output stream of this run was scoped to the function that wrote it and is closed; stdio is flushed here.  What is left are the records,
+        // maps and sequences of the inputs, whose node-by-node teardown takes seconds for a large run: the process leaves without it (the freer of the
+        // last batch is abandoned with it, on the success path only).
         fflush(nullptr);
+        if (freer.joinable()) freer.detach();
         std::_Exit(0);
     } catch (const Error& e) {
         fprintf(stderr, "floria-hip: error: %s\n", e.what());
