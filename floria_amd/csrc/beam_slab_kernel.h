@@ -59,6 +59,9 @@ __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, uint32_t Gs) {
 // x / d for 0 <= x < 2^20 without an integer division (a u32 division costs ~30 VALU instructions): the exact quotient of x + 0.5 is
 // at least 0.5/d away from every integer, while the float error (1-ulp reciprocal, one product) is < 4e-7 * x/d < 0.42/d
 __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return (uint32_t)(((float)x + 0.5f) * rcp_d); }
+// cache policy of the read-once / write-once streams of a job (the next read's cells, its record, the traceback rows): nt, so that they do not push the slabs'
+// lines out of L2 (measured: 91.8 against 92.8 ms per resident step, twice)
+constexpr int FLORIA_NT_AUX = 2;
 constexpr int SLAB_NS_MAX = 512;
 constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
 constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
@@ -219,7 +222,7 @@ void beam_slab_kernel(BeamArgs g) {
         // read ids come 64 at a time (lane j = reads[base + j]).
         struct CellMeta { uint32_t cbeg, L; };
         struct StepMeta { uint32_t first, last; uint64_t tw1, tw2; };
-        auto load_rec = [&](uint32_t r) -> uint32_t { return lane < 8 ? G(cd.meta)[8 * (uint64_t)r + lane] : 0u; };
+        auto load_rec = [&](uint32_t r) -> uint32_t { return lane < 8 ? (FLORIA_NT_AUX ? __builtin_nontemporal_load(G(cd.meta) + 8 * (uint64_t)r + lane) : G(cd.meta)[8 * (uint64_t)r + lane]) : 0u; };
         auto rec_cm = [&](uint32_t v) { CellMeta m; m.cbeg = rl32(v, 0); m.L = rl32(v, 1); return m; };
         auto rec_sm = [&](uint32_t v) { StepMeta m; m.first = rl32(v, 2); m.last = rl32(v, 3);
                                         m.tw1 = ((uint64_t)rl32(v, 5) << 32) | rl32(v, 4); m.tw2 = ((uint64_t)rl32(v, 7) << 32) | rl32(v, 6); return m; };
@@ -227,8 +230,8 @@ void beam_slab_kernel(BeamArgs g) {
         // 3 cells past the read (the next read's cells or the arrays' 16-B tail padding, see floria_hip_contig_upload); never used.
         auto dma_cells = [&](uint32_t w, const CellMeta& m) {
             if (m.L <= (uint32_t)SLAB_TILE && 4 * lane < m.L) {
-                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_snp) + m.cbeg + 4 * lane), (lds_void*)(c_snp_base + w * SLAB_TILE), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_aw) + m.cbeg + 4 * lane), (lds_void*)(c_aw_base + w * SLAB_TILE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_snp) + m.cbeg + 4 * lane), (lds_void*)(c_snp_base + w * SLAB_TILE), 16, 0, FLORIA_NT_AUX);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_aw) + m.cbeg + 4 * lane), (lds_void*)(c_aw_base + w * SLAB_TILE), 16, 0, FLORIA_NT_AUX);
             }
         };
         uint64_t rpb1 = 0, rpb2 = 0;
@@ -697,7 +700,8 @@ void beam_slab_kernel(BeamArgs g) {
             if (surv) {
                 nx_q[lane] = n_q; nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; nx_m[lane] = n_m;
                 nx_sl[lane * p + kj] = newid[u_old];
-                slot_hist[beam_hist_off(i, LM, B) + lane] = pj | (kj << 16);
+                if (FLORIA_NT_AUX) __builtin_nontemporal_store(pj | (kj << 16), slot_hist + beam_hist_off(i, LM, B) + lane);
+                else slot_hist[beam_hist_off(i, LM, B) + lane] = pj | (kj << 16);
             }
             BEAM_TICK(3);
             // copies of the written window [first_rel, hi_rel] for the new versions that could not go in place

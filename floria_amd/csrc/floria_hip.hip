@@ -522,7 +522,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
-                    const bool gated = stage.size() > 1 && stage[0] <= 2 && p >= 4;
+                    const bool gated = stage.size() > 1 && stage[0] <= 2 && p >= 4;      // (ungated ploidy 4 / 5 measured worse: 24.3 against 22.5 ms for the 250-contig shard)
                     // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
                     // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
                     const uint32_t slots = gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
