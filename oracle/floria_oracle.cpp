@@ -1073,6 +1073,22 @@ int floria_oracle_one_ploidy(const floria_pileup* pileup, uint32_t start, uint32
     return 0;
 }
 
+// optimize_clustering (local_clustering.rs:71-130) on a GIVEN partition of the block's reads (test hook: the hand-traced opt_iterate KAT)
+int floria_oracle_optimize_given(const floria_pileup* pileup, const uint32_t* read_id, const uint8_t* part_in, uint32_t n, uint32_t ploidy, double epsilon,
+                                 uint8_t* part_out, int* iters) {
+    int rc = validate(pileup);
+    if (rc) return rc;
+    Pile P{pileup};
+    std::vector<uint32_t> cell_order_;
+    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    std::vector<std::vector<uint32_t>> part(ploidy);
+    for (uint32_t i = 0; i < n; ++i) { if (part_in[i] >= ploidy) return -1; part[part_in[i]].push_back(read_id[i]); }
+    auto opt = optimize_clustering(P, part, epsilon, NUM_ITER_OPTIMIZE, iters);
+    for (int k = 0; k < (int)opt.size(); ++k)
+        for (uint32_t r : opt[k]) for (uint32_t i = 0; i < n; ++i) if (read_id[i] == r) part_out[i] = (uint8_t)k;
+    return 0;
+}
+
 // S2
 int floria_oracle_reassign_ordered(const floria_pileup* pileup, const uint64_t* grp_off, const uint32_t* grp_read,
                                    const uint32_t* grp_range, uint32_t n_groups, const uint32_t* read_order, uint32_t n_order,

@@ -97,6 +97,18 @@ def one_ploidy(pileup, start, end, ploidy, epsilon, beam=10):
     return rid[:k].copy(), pb[:k].copy(), po[:k].copy(), mec.value, na.value, it.value
 
 
+def optimize_given(pileup, read_ids, part, ploidy, epsilon):
+    """optimize_clustering on a given partition of `read_ids` -> (part_after, successful iterations)."""
+    cp = pileup.as_c()
+    rid = np.ascontiguousarray(read_ids, np.uint32)
+    pi = np.ascontiguousarray(part, np.uint8)
+    po = np.zeros(len(rid), np.uint8)
+    it = C.c_int(0)
+    _check(lib().floria_oracle_optimize_given(C.byref(cp), capi.ptr(rid, C.c_uint32), capi.ptr(pi, C.c_uint8), C.c_uint32(len(rid)), C.c_uint32(ploidy),
+                                              C.c_double(epsilon), capi.ptr(po, C.c_uint8), C.byref(it)))
+    return po, it.value
+
+
 def reassign(pileup, groups, ranges, epsilon, read_order=None):
     """groups: list of read-id arrays; ranges: [(start,end)] -> (list of arrays, [(start,end)])"""
     cp = pileup.as_c()

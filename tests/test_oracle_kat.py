@@ -187,3 +187,52 @@ def test_kat6_hapq_by_hand(oracle_mod):
     # errors: H1 has one minority cell (SNP 3), H3 one (the tie: support 2, max 1); coverage 8 + 12 + 2 + 4 + 4 = 30
     assert avg == 2.0 / 30.0
     assert rel[0] == 0.0 and rel[1] == (1.0 / 12.0) / avg and rel[3] == (1.0 / 4.0) / avg and rel[4] == 0.0
+
+
+def test_kat7_ploidy3_three_way_ties_through_the_heap(oracle_mod):
+    """Hand trace of global_clustering.rs:49-150 with std::BinaryHeap (SURVEY.md Appendix A) at ploidy 3, -n 1 (limit = ploidy * 1 = 3 for the first 25
+    reads), two SNPs, q = 20 (w = 0.99), eps = 2^-5.  Reads: r0 = (0,0), r1 = (1,1), r2 = (0,0).
+      read 0: the three partitions are empty: (same, diff) = (0, 2 eps) each, n = (0.0625) as usize = 0 -> p-value 0 for all, nothing pruned; three children
+              c0, c1, c2 (r0 in partition 0 / 1 / 2) tie at MEC 2 eps; pushes of equal elements never swap (`x <= parent` breaks): heap [c0, c1, c2].
+      read 1: in every state the partition holding r0 gives diff = 2w = 1.98 -> (n, k) = (1, 1) -> -13.86, the empty ones 0 -> pruned (-13.86 - lse < ln 0.01);
+              six children A=(c0,1) B=(c0,2) C=(c1,0) D=(c1,2) E=(c2,0) F=(c2,1), all at MEC 4 eps, pairwise different blocks.  Capacity 3: push D -> [A,B,C,D],
+              pop: D to the root, A leaves, sift_down_to_bottom takes the RIGHT child on a tie (`data[child] <= data[child+1]`) -> [C,B,D]; push E, pop -> C
+              leaves -> [D,B,E]; push F, pop -> D leaves -> [E,B,F].
+      two reads only: into_sorted_vec of the tied [E,B,F]: swap(0,2) -> [F,B,E], nothing sifts; swap(0,1) -> [B,F,E]: the best state is B = (c0, 2):
+              r0 in partition 0, r1 in partition 2.
+      read 2 (states visited in array order E, B, F): the partition holding r0 gives same = 1.98 -> (1, 0) -> +0.127, the one holding r1 -13.86 (pruned), the
+              empty one 0; children a=(E,1) .1875, b=(E,2) .125, c=(B,0) .125, d=(B,1) .1875, e=(F,0) .1875, f=(F,2) .125.  push a,b,c -> [a,b,c]; push d: sifts
+              above b (d > b) and stops at a (d <= a) -> [a,d,c,b]; pop: b to the root, a leaves, the larger child d moves up -> [d,b,c]; push e -> [d,e,c,b],
+              pop -> d leaves -> [e,b,c]; push f (f <= b stays) -> [e,b,c,f], pop: f to the root, e leaves, tie b <= c takes the right child c -> [c,b,f].
+              into_sorted_vec of the tied [c,b,f] -> [b,f,c]: best = b = (E, 2): r2 joins r0 in partition 2, r1 sits in partition 0."""
+    reads = [([1, 2], [0, 0], [20, 20]), ([1, 2], [1, 1], [20, 20]), ([1, 2], [0, 0], [20, 20])]
+    rid, pb, po, mec, na, it = oracle_mod.one_ploidy(Pileup.from_reads(reads[:2]), 1, 2, 3, EPS, beam=1)
+    assert list(rid) == [0, 1] and list(pb) == [0, 2]
+    rid, pb, po, mec, na, it = oracle_mod.one_ploidy(Pileup.from_reads(reads), 1, 2, 3, EPS, beam=1)
+    assert list(rid) == [0, 1, 2] and list(pb) == [2, 0, 2]
+    # opt_iterate: only partition 2 has more than one read; moving r0 or r2 anywhere loses (own diff 0 against 2 eps / 2 w): no candidate, the first
+    # round's score does not improve on itself (`new_score > prev_score` is false for equal scores) -> returned as it came
+    assert list(po) == [2, 0, 2]
+    # unit-weight MEC of that partition (local_clustering.rs:187-215): partition 0 = {r1}: every site has max count 1 <= 1 -> eps each; partition 2: none
+    assert mec == 2 * EPS
+
+
+def test_kat8_opt_iterate_equal_gains(oracle_mod):
+    """Hand trace of local_clustering.rs:71-130, 292-358 at ploidy 2, two SNPs, q = 20.  Given partition: P0 = seven reads (0,0) [ids 0..6] and five reads (1,1)
+    [ids 7..11], P1 = two reads (1,1) [ids 12, 13].
+      round 1: in P0 allele 0 leads 7w : 5w; each (1,1) read of P0 has own diff 2w, diff 0 against P1 -> five candidates with the SAME gain 1.98 (no other read
+               gains); stable sort keeps the enumeration order (ascending id here, the documented canonical order); number_of_moves = 5/10 = 0 -> 5/3 + 1 = 2; the
+               loop breaks AFTER the move with mv_num = 3 > 2: reads 7, 8, 9, 10 move, read 11 stays.  Score -10w -> -2w: accepted.
+      round 2: read 11 is the only candidate (gain 1.98); number_of_moves = 0 -> 1; it moves.  Score -2w -> -0: accepted.
+      round 3: no candidate; -0 > -0 is false -> the partition of round 2 is returned.  Three rounds entered, two accepted."""
+    reads = [([1, 2], [0, 0], [20, 20])] * 7 + [([1, 2], [1, 1], [20, 20])] * 7
+    p = Pileup.from_reads(reads)                                  # ids follow the list order (equal spans: ties keep the input order)
+    part = [0] * 7 + [0] * 5 + [1] * 2
+    po, iters = oracle_mod.optimize_given(p, list(range(14)), part, 2, EPS)
+    assert list(po) == [0] * 7 + [1] * 7
+    assert iters in (2, 3)                                        # (how the restatement counts rounds is its own business; the partition is the known answer)
+    # one round only: with 20 iterations capped at the first we cannot observe the intermediate state from outside, but a partition that needs just
+    # the first round pins the `mv_num > number_of_moves` cut: four candidates -> number_of_moves 2 -> all four moved in ONE accepted round
+    part4 = [0] * 7 + [0] * 4 + [1] * 3
+    po4, it4 = oracle_mod.optimize_given(p, list(range(14)), part4, 2, EPS)
+    assert list(po4) == [0] * 7 + [1] * 7 and it4 <= iters
