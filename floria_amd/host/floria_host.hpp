@@ -179,7 +179,11 @@ std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPositi
 // solve_flow.rs: FlowUpVec = Vec<((column, row), (column, row), flow)>
 struct FlowUpdate { std::pair<size_t, size_t> n1, n2; double flow; };
 typedef std::vector<FlowUpdate> FlowUpVec;
-FlowUpVec solve_lp_graph(const std::vector<std::vector<HapNode>>& hap_graph);
+// The LP's optimum is usually not unique (stitch.cpp).  LpTie picks which optimal vertex the flow solver returns (the two extremes of its
+// tie-breaking); LpInfo reports the optimal value and how many edges carry a different flow in some other optimal solution.
+enum class LpTie { First, Last };
+struct LpInfo { int64_t cost = 0; size_t movable_edges = 0; };
+FlowUpVec solve_lp_graph(const std::vector<std::vector<HapNode>>& hap_graph, LpTie tie = LpTie::First, LpInfo* info = nullptr);
 std::pair<std::vector<std::vector<const Frag*>>, std::vector<std::pair<SnpPosition, SnpPosition>>> get_disjoint_paths_rewrite(
     std::vector<std::vector<HapNode>>& hap_graph, const FlowUpVec& flow_update_vec, const Options& options);
 std::vector<const Frag*> get_frags_in_snpless_gaps(const std::vector<std::pair<SnpPosition, SnpPosition>>& path_parts, const std::vector<GnPosition>& snp_to_gn_pos,

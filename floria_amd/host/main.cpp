@@ -12,7 +12,8 @@
 // Flags of the reference that are not supported and say so: the hidden -H/--hybrid, --reassign-short, --bin-by-cov (-q is accepted and
 // ignored, as in the reference).  Extras: --device N, --devices LIST (e.g. 0-7 or 0,2,5: the contigs of a batch are dealt to these GPUs of the node,
 // longest first; one context and one host thread per device; the files are those of a one-GPU run),
-// --batch-contigs N / --batch-cells N (size of a device batch), --debug (debug_graph.txt per contig), and for tests --dump-frags FILE,
+// --batch-contigs N / --batch-cells N (size of a device batch), --debug (debug_graph.txt per contig), --lp-tie first|last (which optimal vertex of the
+// stitching LP is used where the optimum is not unique; the run reports how many contigs that concerns), and for tests --dump-frags FILE,
 // --ingest-only, --no-realign, --stitch-graph FILE.
 #include <sys/stat.h>
 
@@ -94,6 +95,8 @@ int main(int argc, char** argv) {
     uint64_t batch_cells = 256ull << 20; // --batch-cells (1.5 GB of pinned staging)
     bool ingest_only = false, no_realign = false;
     std::string stitch_graph;
+    LpTie lp_tie = LpTie::First;         // --lp-tie first|last: which optimal vertex of the stitching LP is used where the optimum is not unique (stitch.cpp)
+    std::atomic<size_t> lp_contigs{0}, lp_not_unique{0}, lp_edges{0}, lp_movable{0};
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
     std::vector<int> devices;            // --devices: the GPUs the contigs of a batch are dealt to (empty: --device alone)
     size_t bam_window = (size_t)512 << 20;   // --bam-window-mb: inflated BAM bytes held at a time (more only when one contig alone is larger)
@@ -123,6 +126,7 @@ int main(int argc, char** argv) {
             else if (a == "--no-stop-heuristic") o.stopping_heuristic = false;
             else if (a == "--overwrite") o.overwrite = true;
             else if (a == "--debug" || a == "--trace") debug = true;
+            else if (a == "--lp-tie") { const std::string v = val(); if (v != "first" && v != "last") throw Error(FLORIA_E_INVALID, "--lp-tie takes first or last"); lp_tie = v == "last" ? LpTie::Last : LpTie::First; }
             else if (a == "-q") {}
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
@@ -204,9 +208,10 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < max_read; ++i) frags[i].counter_id = i;
             for (size_t c = 0; c < hg.size(); ++c) for (size_t r = 0; r < hg[c].size(); ++r) for (size_t x : node_reads[c][r]) hg[c][r].frag_set.push_back(&frags[x]);
             for (const EdgeIn& e : edges) { hg[e.c][e.r].out_edges.push_back({e.r2, e.w}); hg[e.c + 1][e.r2].in_edges.push_back({e.r, e.w}); }
-            const FlowUpVec fl = solve_lp_graph(hg);
+            LpInfo li;
+            const FlowUpVec fl = solve_lp_graph(hg, lp_tie, &li);
             auto paths = get_disjoint_paths_rewrite(hg, fl, o);
-            printf("%s", "");
+            printf("U\t%lld\t%zu\n", (long long)li.cost, li.movable_edges);
             for (const FlowUpdate& f : fl) printf("F\t%zu\t%zu\t%zu\t%.17g\n", f.n1.first, f.n1.second, f.n2.second, f.flow);
             for (size_t k = 0; k < paths.first.size(); ++k) {
                 printf("P\t%u\t%u", paths.second[k].first, paths.second[k].second);
@@ -379,7 +384,9 @@ int main(int argc, char** argv) {
                 tm[0] += now_s() - t1; t1 = now_s();
                 parallel_for(part.size(), threads, [&](size_t i) {
                     ContigWork& w = part[i];
-                    w.flows = solve_lp_graph(w.hap_graph);
+                    LpInfo li;
+                    w.flows = solve_lp_graph(w.hap_graph, lp_tie, &li);
+                    ++lp_contigs; lp_not_unique += li.movable_edges != 0; lp_edges += w.flows.size(); lp_movable += li.movable_edges;
                     auto paths = get_disjoint_paths_rewrite(w.hap_graph, w.flows, o);
                     w.path_parts = std::move(paths.first); w.path_ranges = std::move(paths.second);
                     if (debug) write_debug_graph(w);
@@ -429,6 +436,9 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
+        fprintf(stderr, "LP: the optimum is not unique for %zu of %zu contigs (%zu of %zu edge flows differ in some other optimal solution); this run used the '%s' vertex, "
+                        "rerun with --lp-tie %s to see what depends on it\n", lp_not_unique.load(), lp_contigs.load(), lp_movable.load(), lp_edges.load(),
+                lp_tie == LpTie::First ? "first" : "last", lp_tie == LpTie::First ? "last" : "first");
         fprintf(stderr, "Total time taken is %.3fs\n", now_s() - t_all);
         // everything is written and closed: leave without tearing down the records, maps and sequences one by one (seconds for a large BAM)
         if (dump.is_open()) dump.close();

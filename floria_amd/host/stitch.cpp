@@ -10,7 +10,10 @@
 //     every unconstrained node trades freely with a hub (cost 0), which takes up the difference of the totals
 // by successive shortest augmenting paths.  The optimum VALUE equals minilp's; where the optimum is not unique the reference's
 // flows are whatever vertex its simplex stops at, which cannot be reproduced without the crate (parity unpinned for such cases,
-// DESIGN.md).
+// DESIGN.md).  Non-unique optima are the norm, not the exception (a node with inflow 5 and outflow 3 can lower the one or raise the
+// other at the same cost), so the solver (a) can return either extreme of its tie-breaking (LpTie) and (b) counts the edges whose
+// flow differs in some other optimal solution (LpInfo::movable_edges), so that the dependence of the output on the choice is
+// measurable: floria-hip --lp-tie last, scripts/lp_tie_rate.py, DESIGN.md "Stitching".
 #include "floria_host.hpp"
 
 #include <algorithm>
@@ -35,8 +38,42 @@ struct Mcf {
         arcs.push_back({u, 0, -cost}); adj[v].push_back((int)arcs.size() - 1);
         return (int)arcs.size() - 2;
     }
+    // potentials pi with cost + pi[u] - pi[v] >= 0 on every residual arc (Bellman-Ford from a virtual root; an optimal flow has
+    // no negative residual cycle, so this converges)
+    std::vector<int64_t> potentials() const {
+        const int n = (int)adj.size();
+        std::vector<int64_t> pi(n, 0);
+        std::vector<char> inq(n, 1);
+        std::deque<int> q;
+        for (int v = 0; v < n; ++v) q.push_back(v);
+        while (!q.empty()) {
+            const int u = q.front(); q.pop_front(); inq[u] = 0;
+            for (int ai : adj[u]) {
+                const McfArc& a = arcs[ai];
+                if (a.cap > 0 && pi[u] + a.cost < pi[a.to]) { pi[a.to] = pi[u] + a.cost; if (!inq[a.to]) { inq[a.to] = 1; q.push_back(a.to); } }
+            }
+        }
+        return pi;
+    }
+    // is there a path to -> ... -> from over residual arcs of zero reduced cost that does not use `banned`?  Together with an arc
+    // from -> to of zero reduced cost that closes a zero-cost residual cycle: pushing one unit around it is another optimum.
+    bool zero_path(int from, int to, int banned, const std::vector<int64_t>& pi) const {
+        std::vector<char> seen(adj.size(), 0);
+        std::vector<int> stack{to};
+        seen[to] = 1;
+        while (!stack.empty()) {
+            const int u = stack.back(); stack.pop_back();
+            if (u == from) return true;
+            for (int ai : adj[u]) {
+                const McfArc& a = arcs[ai];
+                if (ai == banned || a.cap <= 0 || seen[a.to] || a.cost + pi[u] - pi[a.to] != 0) continue;
+                seen[a.to] = 1; stack.push_back(a.to);
+            }
+        }
+        return false;
+    }
     // successive shortest paths (SPFA: residual arcs carry negative costs); ties between equally short paths are broken by
-    // arc insertion order, so the result is deterministic
+    // the order of the adjacency lists (arc insertion order, or its reverse for LpTie::Last), so the result is deterministic
     void run(int S, int T) {
         const int n = (int)adj.size();
         const int64_t INF = std::numeric_limits<int64_t>::max() / 4;
@@ -132,7 +169,7 @@ struct TraceBackNode { double score = 0.; int prev_ind = -1; bool is_sink = fals
 }  // namespace
 
 // solve_flow.rs:195-290
-FlowUpVec solve_lp_graph(const std::vector<std::vector<HapNode>>& hap_graph) {
+FlowUpVec solve_lp_graph(const std::vector<std::vector<HapNode>>& hap_graph, LpTie tie, LpInfo* info) {
     // edges in the reference's order: nodes by (column, row), each node's out_edges in order (:211-226)
     struct E { size_t c1, r1, c2, r2; int64_t a; };
     std::vector<E> edges;
@@ -166,12 +203,33 @@ FlowUpVec solve_lp_graph(const std::vector<std::vector<HapNode>>& hap_graph) {
     }
     if (sup > dem) g.add(HUB, T, sup - dem, 0);
     else if (dem > sup) g.add(S, HUB, dem - sup, 0);
+    if (tie == LpTie::Last) for (auto& l : g.adj) std::reverse(l.begin(), l.end());
     g.run(S, T);
     FlowUpVec out;
     out.reserve(edges.size());
+    int64_t cost = 0;
     for (size_t i = 0; i < edges.size(); ++i) {
         const int64_t yp = g.arcs[arc_plus[i] ^ 1].cap, ym = g.arcs[arc_minus[i] ^ 1].cap;      // flow on an arc = capacity of its reverse
         out.push_back({{edges[i].c1, edges[i].r1}, {edges[i].c2, edges[i].r2}, (double)(edges[i].a + yp - ym)});
+        cost += yp + ym;
+    }
+    if (info) {
+        // x_e is not determined by optimality iff one of the four residual arcs of e (y+, y-, and their reverses) lies on a zero-cost
+        // residual cycle other than the trivial one with its own reverse.  (Two different arcs between the same pair of nodes cannot
+        // close a zero-cost 2-cycle: y+ with y- costs 2, and the two reverses are never both residual at an optimum.)
+        const std::vector<int64_t> pi = g.potentials();
+        info->cost = cost;
+        info->movable_edges = 0;
+        for (size_t i = 0; i < edges.size(); ++i) {
+            bool movable = false;
+            for (int ai : {arc_plus[i], arc_plus[i] ^ 1, arc_minus[i], arc_minus[i] ^ 1}) {
+                const McfArc& a = g.arcs[ai];
+                const int from = g.arcs[ai ^ 1].to;
+                if (a.cap <= 0 || a.cost + pi[from] - pi[a.to] != 0) continue;
+                if (g.zero_path(from, a.to, ai ^ 1, pi)) { movable = true; break; }
+            }
+            info->movable_edges += movable;
+        }
     }
     return out;
 }

@@ -142,15 +142,21 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
     return dict(quals=qual_by_name, ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
 
 
-def nw_affine_batch(Q, R, match=1, mismatch=-1, gap_open=-2, gap_extend=-1):
+def nw_affine_batch(Q, R, match=1, mismatch=-1, gap_open=-2, gap_extend=-1, band=None):
     """Global alignment scores of N sequence pairs at once (Q, R: uint8 [N, n] / [N, m]); a gap of length k costs open + (k - 1) * extend
-    (Gotoh).  The scoring of alignment::realign (alignment.rs:15-18: NW1, Gaps { open: -2, extend: -1 })."""
+    (Gotoh).  The scoring of alignment::realign (alignment.rs:15-18: NW1, Gaps { open: -2, extend: -1 }).  With `band` = b only cells with
+    |i - j| <= b are computed (a static diagonal band): NOT block-aligner's adaptive block walk, which cannot be restated without the crate, but
+    a lower bound on what any aligner confined to about 2b + 1 diagonals can find — used to measure how much the calls depend on the band at all
+    (tests/test_host_cpu.py::test_realign_calls_barely_depend_on_a_band)."""
     N, n = Q.shape
     m = R.shape[1]
     NEG = -10 ** 6
+    jj = np.arange(m + 1)
     M = np.full((N, m + 1), NEG, np.int32); X = np.full((N, m + 1), NEG, np.int32); Y = np.full((N, m + 1), NEG, np.int32)
     M[:, 0] = 0
     Y[:, 1:] = gap_open + gap_extend * np.arange(m)
+    if band is not None:
+        Y[:, jj > band] = NEG
     for i in range(1, n + 1):
         Mn = np.full((N, m + 1), NEG, np.int32); Xn = np.full((N, m + 1), NEG, np.int32); Yn = np.full((N, m + 1), NEG, np.int32)
         Xn[:, 0] = gap_open + (i - 1) * gap_extend
@@ -159,13 +165,17 @@ def nw_affine_batch(Q, R, match=1, mismatch=-1, gap_open=-2, gap_extend=-1):
         Xn[:, 1:] = np.maximum(np.maximum(M[:, 1:], Y[:, 1:]) + gap_open, X[:, 1:] + gap_extend)
         for j in range(1, m + 1):
             Yn[:, j] = np.maximum(np.maximum(Mn[:, j - 1], Xn[:, j - 1]) + gap_open, Yn[:, j - 1] + gap_extend)
+            if band is not None and abs(i - j) > band:
+                Mn[:, j] = NEG; Xn[:, j] = NEG; Yn[:, j] = NEG
+        if band is not None and i > band:
+            Xn[:, 0] = NEG
         M, X, Y = Mn, Xn, Yn
     return np.maximum(np.maximum(M[:, m], X[:, m]), Y[:, m])
 
 
-def realign_dataset(d, flank=16):
-    """What alignment::realign (alignment.rs:7-64) makes of the calls of contig_dataset `d`: every call whose 2 x 16-base windows fit is
-    replaced by the allele whose reference window aligns best to the read's window (first best).  Updates d["reads"][...] cells in place."""
+def realign_windows(d, flank=16):
+    """The (read window, REF window, ALT window) triples alignment::realign (alignment.rs:21-37) scores for contig_dataset `d`, as uint8 arrays
+    [N, 2 * flank], and for each the (read index, cell index) it decides."""
     ref = np.frombuffer(d["ref"], np.uint8)
     snp_pos = np.array([q for q, _, _ in d["snps"]], np.int64)
     alleles = [(ord(r), ord(a)) for _, r, a in d["snps"]]
@@ -192,10 +202,16 @@ def realign_dataset(d, flank=16):
                     q += ln
                 if op in "MDN":
                     r += ln
-    if not wq:
+    return np.array(wq, np.uint8).reshape(-1, 2 * flank), np.array(wr0, np.uint8).reshape(-1, 2 * flank), np.array(wr1, np.uint8).reshape(-1, 2 * flank), where
+
+
+def realign_dataset(d, flank=16):
+    """What alignment::realign (alignment.rs:7-64) makes of the calls of contig_dataset `d`: every call whose 2 x 16-base windows fit is
+    replaced by the allele whose reference window aligns best to the read's window (first best).  Updates d["reads"][...] cells in place."""
+    Q, R0, R1, where = realign_windows(d, flank)
+    if not len(where):
         return 0
-    Q = np.array(wq, np.uint8)
-    s0 = nw_affine_batch(Q, np.array(wr0, np.uint8)); s1 = nw_affine_batch(Q, np.array(wr1, np.uint8))
+    s0 = nw_affine_batch(Q, R0); s1 = nw_affine_batch(Q, R1)
     changed = 0
     for (ri, k), a0, a1 in zip(where, s0, s1):
         new = 0 if a0 >= a1 else 1

@@ -117,6 +117,53 @@ def test_lp_hand_case_with_a_unique_optimum(floria_hip, tmp_path):
     assert ps == [["P", "1", "16", "0", "1", "2", "3"]]                          # one path through all four nodes
 
 
+def _stitch(floria_hip, path, tie):
+    r = subprocess.run([floria_hip, "--stitch-graph", path, "--lp-tie", tie], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split("\t") for ln in r.stdout.splitlines()]
+    u = [x for x in rows if x[0] == "U"][0]
+    return int(u[1]), int(u[2]), [float(x[4]) for x in rows if x[0] == "F"], [x for x in rows if x[0] == "P"], r.stdout
+
+
+def test_lp_hand_case_with_two_optimal_vertices(floria_hip, tmp_path):
+    # a chain 0 -(5)-> 1 -(3)-> 2: node 1 needs inflow == outflow, and every x in [3, 5] costs 2.  The reference's simplex stops at one of the
+    # two vertices (3, 3) and (5, 5); which one cannot be known without the crate.  The flow solver returns either, on request, says that the
+    # optimum is not unique, and both flows are >= 2 here so the single path through the three nodes is peeled either way.
+    g = "N\t0\t0\t0\t1\t1\t4\t0\nN\t1\t0\t1\t1\t5\t8\t1\nN\t2\t0\t2\t1\t9\t12\t2\nE\t0\t0\t0\t5\nE\t1\t0\t0\t3\n"
+    path = str(tmp_path / "t.txt")
+    open(path, "w").write(g)
+    c1, m1, f1, p1, _ = _stitch(floria_hip, path, "first")
+    c2, m2, f2, p2, _ = _stitch(floria_hip, path, "last")
+    assert c1 == c2 == 2 and m1 == m2 == 2                                       # both edges can move
+    assert sorted([f1, f2]) == [[3.0, 3.0], [5.0, 5.0]]
+    assert p1 == p2 == [["P", "1", "12", "0", "1", "2"]]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_lp_both_tie_orders_are_optimal_and_uniqueness_is_reported(floria_hip, tmp_path, seed):
+    """The two extremes of the solver's tie-breaking are both optimal for the reference's LP (HiGHS), have the same cost, and are identical
+    exactly when the solver says the optimum is unique."""
+    rng = np.random.default_rng(300 + seed)
+    path = str(tmp_path / "g.txt")
+    text = random_graph(rng, int(rng.integers(2, 12)), int(rng.integers(1, 5)))
+    res = []
+    for tie in ("first", "last"):
+        open(path, "w").write(text)
+        cost, movable, fl, ps, out = _stitch(floria_hip, path, tie)
+        open(path, "a").write(out)
+        cols, flows, paths = stitch.parse_debug_graph(path)
+        stitch.check_flows(cols, flows)
+        assert paths == stitch.disjoint_paths(cols, flows)
+        res.append((cost, movable, fl, ps))
+    assert res[0][0] == res[1][0]
+    if res[0][1] == 0:
+        assert res[1][1] == 0 and res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    if res[0][2] != res[1][2]:
+        assert res[0][1] > 0 and res[1][1] > 0
+        differing = sum(a != b for a, b in zip(res[0][2], res[1][2]))
+        assert differing <= res[0][1]                                            # only edges reported as movable differ
+
+
 def l_epsilon_restated(alignments):
     """l_epsilon_auto_detect (file_reader.rs:749-826) for gapless, unfiltered alignments [(pos, seq, cigar)] of ONE contig: every
     covered reference position is a pileup column; columns are counted and every 1000th is sampled (a sampled column with fewer
@@ -247,6 +294,27 @@ def test_realign_shortcut_is_exact_under_sequencing_errors(floria_hip, tmp_path,
         assert g["cells"] == list(zip(s.tolist(), a.tolist(), q.tolist())), f"read {i}"
         n_changed += sum(1 for x, y in zip(g["cells"], g0["cells"]) if x != y)
     assert n_changed > 0 if sub_rate > 0.1 else True                              # noise flips some calls, the same ones in both
+
+
+@pytest.mark.parametrize("sub_rate,edit_frac", [(0.03, 0.1), (0.12, 0.5)])
+def test_realign_calls_barely_depend_on_a_band(sub_rate, edit_frac):
+    """The reference scores the 32 x 32 realignment windows with block-aligner at a fixed block size of 8 (alignment.rs:14, :51), a heuristic that
+    walks an 8-wide block through the matrix; this library (and its numpy restatement) fills the whole matrix.  block-aligner's walk cannot be
+    restated without the crate (Cargo.lock: block-aligner 0.4, not vendored), so what is measured here is the sensitivity of the CALL to any
+    band at all: confine the DP to |i - j| <= b and count the calls that change.  A walk of 8-wide blocks that tracks the best cell covers at
+    least the +-4 diagonals around the path; the windows are cut around a SNP the aligner placed on the diagonal, so the optimal path leaves the
+    diagonal only by the indels inside the window.  Numbers recorded in DESIGN.md "Realignment"."""
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    d = synth_bam.contig_dataset(c, np.random.default_rng(4), edit_frac=edit_frac, sub_rate=sub_rate)
+    Q, R0, R1, where = synth_bam.realign_windows(d)
+    assert len(where) > 20000
+    full = synth_bam.nw_affine_batch(Q, R0) >= synth_bam.nw_affine_batch(Q, R1)
+    rates = {}
+    for b in (8, 4, 2):
+        banded = synth_bam.nw_affine_batch(Q, R0, band=b) >= synth_bam.nw_affine_batch(Q, R1, band=b)
+        rates[b] = float((banded != full).mean())
+    print("realign band sensitivity (sub_rate %.2f, edit_frac %.1f, %d windows): " % (sub_rate, edit_frac, len(where)) + ", ".join("+-%d: %.5f" % kv for kv in rates.items()))
+    assert rates[8] == 0.0 and rates[4] <= 1e-3 and rates[2] <= 1e-2
 
 
 def test_ignore_monomorphic(floria_hip, tmp_path):
