@@ -20,6 +20,12 @@
 // attains the position's maximal sum, 0 <=> nothing observed — which is all the distance needs (`same` <=> bit of the read's allele,
 // empty <=> 0): phase A reads 1 byte per (slab, cell) instead of 16, the sums are only touched by the read-modify-write that refreshes the
 // code, by copies and by the window-exit hash terms.  (Pileups with q = 0 cells keep classifying from the sums: their presence bit is part of it.)
+// NARROW sums (biallelic data without q = 0 cells, i.e. every BASELINE config): a sum is < n_reads * 2^24 < 2^40 (the host sends blocks of >= 65 536 reads
+// down the wide / generic kernels), so it is kept as a u32 low word in the [pos][allele] plane (8 B per SNP: eight positions per 64-B line instead of four)
+// and a u8 high byte in a second plane (2 B per SNP) that the read-modify-write reads but only writes on a carry.  The lines an add dirties halve:
+// measured on BASELINE config 4, write-back 129.6 -> 73.1 M KiB and fetch 58.0 -> 43.3 M KiB per two S1 calls (HBM traffic 35 x -> 23 x the algorithmic
+// bytes) at an unchanged step time (the inverse experiment, padding a position to 32 / 64 B, costs +13 % / +52 %: the step sits just left of the knee
+// of L2 capacity).
 #pragma once
 #include "wave_util.h"
 
@@ -149,12 +155,16 @@ void beam_slab_kernel(BeamArgs g) {
     uint64_t* r_np1 = (uint64_t*)(smem + LY.off_rnp1);
     uint64_t* r_np2 = (uint64_t*)(smem + LY.off_rnp2);
 
-    const uint32_t pos_bytes = A * 8;
-    const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
-    char* pool = (char*)g.state_pool + (uint64_t)blockIdx.x * g.state_stride;      // [NS slabs][span_max][A] u64, then [NS][span_pad] code bytes
     constexpr bool CODES = !Q0;
+    constexpr bool NARROW = CODES && A == 2;
+    const uint32_t pos_bytes = NARROW ? 8 : A * 8;
+    const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
+    // [NS slabs][span_max][A] u64 (NARROW: u32 low words), then (NARROW) [NS][span_pad][2] u8 high bytes, then [NS][span_pad] code bytes
+    char* pool = (char*)g.state_pool + (uint64_t)blockIdx.x * g.state_stride;
     const uint32_t span_pad = (g.span_max + 15u) & ~15u;
-    uint8_t* const codes = (uint8_t*)(pool + (uint64_t)NS * slab_bytes);
+    uint8_t* const hi_plane = (uint8_t*)(pool + (uint64_t)NS * slab_bytes);
+    const uint32_t hi_slab_bytes = NARROW ? span_pad * 2u : 0u;
+    uint8_t* const codes = hi_plane + (uint64_t)NS * hi_slab_bytes;
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
     uint64_t* r_t1 = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS));      // tail of the slot's traceback region (host reserves it)
     uint64_t* r_t2 = r_t1 + NS;
@@ -439,8 +449,14 @@ void beam_slab_kernel(BeamArgs g) {
                             if (act) {
                                 uint64_t v[A], r1[A], r2[A];
                                 const char* vp = pool + (slab_off + (uint32_t)pr * pos_bytes);
+                                if constexpr (NARROW) {
+                                    const uint2 lo = *(const uint2*)vp;
+                                    const uint32_t hb = *(const uint16_t*)(hi_plane + ((uint32_t)live_id[li] * hi_slab_bytes + (uint32_t)pr * 2u));
+                                    v[0] = ((uint64_t)(hb & 0xffu) << 32) | lo.x; v[1] = ((uint64_t)(hb >> 8) << 32) | lo.y;
+                                } else {
 #pragma unroll
                                 for (int h = 0; h < A / 2; ++h) { const ulonglong2 w2 = *(const ulonglong2*)(vp + 16 * h); v[2 * h] = w2.x; v[2 * h + 1] = w2.y; }
+                                }
 #pragma unroll
                                 for (int al = 0; al < A; ++al) { const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al); r1[al] = g.Rq1[hx]; r2[al] = g.Rq2[hx]; }
 #pragma unroll
@@ -717,6 +733,21 @@ void beam_slab_kernel(BeamArgs g) {
                     cm2 &= cm2 - 1;
                     const uint32_t su = rl32(u_old, jj);
                     const uint32_t du = newid[su];
+                    if constexpr (NARROW) {
+                        const uint32_t cb = (uint32_t)(hi_rel - (int32_t)first_rel + 1);
+                        const uint2* s = (const uint2*)(pool + (su * slab_bytes + first_rel * pos_bytes));
+                        uint2* d = (uint2*)(pool + (du * slab_bytes + first_rel * pos_bytes));
+                        const uint16_t* sh = (const uint16_t*)(hi_plane + (su * hi_slab_bytes + first_rel * 2u));
+                        uint16_t* dh = (uint16_t*)(hi_plane + (du * hi_slab_bytes + first_rel * 2u));
+                        uint32_t x = lane;
+                        for (; x + 192 < cb; x += 256) {
+                            const uint2 v0 = s[x], v1 = s[x + 64], v2 = s[x + 128], v3 = s[x + 192];
+                            const uint16_t h0 = sh[x], h1 = sh[x + 64], h2 = sh[x + 128], h3 = sh[x + 192];
+                            d[x] = v0; d[x + 64] = v1; d[x + 128] = v2; d[x + 192] = v3;
+                            dh[x] = h0; dh[x + 64] = h1; dh[x + 128] = h2; dh[x + 192] = h3;
+                        }
+                        for (; x < cb; x += 64) { d[x] = s[x]; dh[x] = sh[x]; }
+                    } else {
                     const ulonglong2* s = (const ulonglong2*)(pool + (su * slab_bytes + first_rel * pos_bytes));
                     ulonglong2* d = (ulonglong2*)(pool + (du * slab_bytes + first_rel * pos_bytes));
                     uint32_t x = lane;
@@ -725,6 +756,7 @@ void beam_slab_kernel(BeamArgs g) {
                         d[x] = v0; d[x + 64] = v1; d[x + 128] = v2; d[x + 192] = v3;
                     }
                     for (; x < cnt2; x += 64) d[x] = s[x];
+                    }
                     if (CODES) {
                         const uint8_t* sc = codes + (su * span_pad + first_rel);
                         uint8_t* dc = codes + (du * span_pad + first_rel);
@@ -745,7 +777,7 @@ void beam_slab_kernel(BeamArgs g) {
             }
             __syncthreads();
             if (new_hi > hi_rel) {
-                const uint32_t cntz = (uint32_t)(new_hi - hi_rel) * A;
+                const uint32_t cntz = (uint32_t)(new_hi - hi_rel) * (NARROW ? 1u : (uint32_t)A);      // 8-B words per slab
                 const uint32_t items = nl * cntz;
 #ifdef FLORIA_PROF
                 c_zero_items += items / A;
@@ -761,6 +793,7 @@ void beam_slab_kernel(BeamArgs g) {
                     for (uint32_t x = lane; x < items_c; x += 64) {
                         const uint32_t e = items_c < (1u << 20) ? div_small(x, rcp_cz) : x / cz, o = x - e * cz;
                         codes[(uint32_t)live_id[e] * span_pad + (uint32_t)(hi_rel + 1) + o] = 0;
+                        if constexpr (NARROW) *(uint16_t*)(hi_plane + ((uint32_t)live_id[e] * hi_slab_bytes + ((uint32_t)(hi_rel + 1) + o) * 2u)) = 0;
                     }
                 }
             }
@@ -795,7 +828,7 @@ void beam_slab_kernel(BeamArgs g) {
                         // up to 4 read-modify-writes in flight per lane and pass, exactly as many as the pass has (a step has ~105 of them over 64 lanes: 2)
                         auto add_pass = [&](auto NC, uint32_t x0) {
                             constexpr int AU = decltype(NC)::value;
-                            uint32_t w[AU], al[AU]; uint64_t* base[AU]; uint8_t* cptr[AU];
+                            uint32_t w[AU], al[AU]; uint64_t* base[AU]; uint8_t* cptr[AU]; uint8_t* hptr[AU];
 #pragma unroll
                             for (int u = 0; u < AU; ++u) {
                                 const uint32_t xx = x0 + lane + 64 * u;
@@ -806,20 +839,31 @@ void beam_slab_kernel(BeamArgs g) {
                                 w[u] = aw & 0x0fffffffu; al[u] = aw >> 28;
                                 base[u] = ok ? (uint64_t*)(pool + (sl * slab_bytes + pr * pos_bytes)) : dummy + lane * A;
                                 cptr[u] = ok ? codes + (sl * span_pad + pr) : dummy_code + lane;
+                                if constexpr (NARROW) hptr[u] = ok ? hi_plane + (sl * hi_slab_bytes + pr * 2u) : dummy_code + 64 + 2 * lane;
                             }
                             ulonglong2 vv[AU][A / 2];
+                            uint32_t hv[AU];
 #pragma unroll
-                            for (int u = 0; u < AU; ++u)
+                            for (int u = 0; u < AU; ++u) {
+                                if constexpr (NARROW) { const uint2 lo = *(const uint2*)base[u]; vv[u][0].x = lo.x; vv[u][0].y = lo.y; hv[u] = *(const uint16_t*)hptr[u]; }
+                                else {
 #pragma unroll
                                 for (int x = 0; x < A / 2; ++x) vv[u][x] = ((const ulonglong2*)base[u])[x];
+                                }
+                            }
 #pragma unroll
                             for (int u = 0; u < AU; ++u) {
                                 uint64_t v[A];
 #pragma unroll
                                 for (int x = 0; x < A; x += 2) { v[x] = vv[u][x / 2].x; v[x + 1] = vv[u][x / 2].y; }
+                                if constexpr (NARROW) { v[0] |= (uint64_t)(hv[u] & 0xffu) << 32; v[1] |= (uint64_t)(hv[u] >> 8) << 32; }
                                 uint64_t nv = 0;
 #pragma unroll
                                 for (int x = 0; x < A; ++x) { if (x == (int)al[u]) { v[x] += w[u]; nv = v[x]; } }
+                                if constexpr (NARROW) {
+                                    ((uint32_t*)base[u])[al[u]] = (uint32_t)nv;
+                                    if ((uint32_t)nv < w[u]) hptr[u][al[u]] = (uint8_t)(nv >> 32);          // the low word wrapped: one time in ~256 adds
+                                } else
                                 base[u][al[u]] = nv;
                                 uint32_t code;
                                 if (A == 2) code = (v[0] | v[1]) ? ((v[0] >= v[1] ? 1u : 0u) | (v[1] >= v[0] ? 2u : 0u)) : 0u;

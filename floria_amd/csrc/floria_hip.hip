@@ -392,7 +392,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         // shared-slab kernels: register heap for ploidy*beam <= 63 (the CLI defaults give <= 50), LDS heap beyond; the generic kernel
         // (per-state slabs, any size) remains for beams whose slab tables fit neither
         const bool wide_ok = fits32 && LM * p <= (uint32_t)fl::WIDE_NS_MAX && LM < 65000 && q.WL.total <= 150 * 1024;
-        q.slab = LM <= 63 && fits32 && LM * p <= (uint32_t)fl::SLAB_NS_MAX && q.SL.total <= 60 * 1024;
+        // (narrow sums: the register-heap slab kernel keeps biallelic sums in 40 bits, beam_slab_kernel.h; a block of >= 65 536 reads goes down the wide / generic kernels)
+        const bool narrow = A == 2 && !any_q0;
+        q.slab = LM <= 63 && fits32 && LM * p <= (uint32_t)fl::SLAB_NS_MAX && q.SL.total <= 60 * 1024 && !(narrow && n_max >= 65536u);
         q.wide = !q.slab && wide_ok;
         switch (K.beam_path) {                               // dev/test knob
             case 1: q.wide = false; q.slab = false; break;                     // generic
@@ -400,7 +402,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             case 3: q.wide = wide_ok; q.slab = q.slab && !wide_ok; break;      // wide (where it applies)
             default: break;
         }
-        if (q.slab) q.state_bytes += slab_code_bytes;
+        if (q.slab) q.state_bytes = narrow ? (uint64_t)LM * p * ((uint64_t)span_max * 8 + 3ull * ((span_max + 15u) & ~15u)) : q.state_bytes + slab_code_bytes;
         if (!q.shortcut) {
             if (q.LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
             if (q.wide) q.beam_slots = std::min<uint32_t>(q.beam_slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.WL.total + 512))));

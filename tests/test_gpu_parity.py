@@ -663,3 +663,39 @@ def test_p16_n40_takes_the_generic_kernel(gpu_ctx, hip_lib, oracle_mod):
         rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(EPS, P, B))
         assert_block_results_equal(ro, rg, f"-p {P} -n {B}")
         assert rg.min_prune_margin == ro.min_prune_margin
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_sums_beyond_32_bits_carry_into_the_high_plane(gpu_ctx, hip_lib, oracle_mod, seed):
+    # The slab kernel keeps a biallelic sum as a u32 low word + a u8 high byte (beam_slab_kernel.h, NARROW).  Quality 93 weighs 2^24 * (1 - 5e-10), so a
+    # haplotype that has absorbed more than 256 such reads at a position wraps its low word: 1500 deep reads over 12 SNPs from two strains put ~750
+    # on every (haplotype, position, allele) — sums near 2^33.6, several carries per position, in-place adds, copies and window exits included.
+    rng = np.random.default_rng(4100 + seed)
+    n, S = 1500, 12
+    strains = rng.integers(0, 2, size=(2, S))
+    reads = []
+    for i in range(n):
+        lo = int(rng.integers(1, 4)); hi = int(rng.integers(S - 3, S + 1))
+        src = strains[i % 2]
+        al = [int(src[q - 1]) ^ (1 if rng.random() < 0.03 else 0) for q in range(lo, hi + 1)]
+        reads.append((list(range(lo, hi + 1)), al, [93 if rng.random() < 0.9 else 40] * (hi - lo + 1)))
+    reads.sort(key=lambda r: (r[0][0], r[0][-1]))
+    pile = Pileup.from_reads(reads)
+    ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1], [S], P=3)
+    assert_block_results_equal(ro, rg, f"seed {seed}")
+    assert int(ro.best_ploidy[0]) == 2
+
+
+def test_a_block_of_65536_reads_leaves_the_narrow_sum_kernel(gpu_ctx, hip_lib, oracle_mod):
+    # 40-bit sums hold 65 535 reads of full weight; the host sends a batch whose largest block has more down the wide kernel (u64 sums).
+    # Same results as the oracle either way — this pins the routing rule and the wide kernel on a long block.
+    rng = np.random.default_rng(77)
+    n = 65536 + 200
+    reads = []
+    for i in range(n):
+        q = 1 + (i * 6) // n                                     # first positions ascend: reads sorted as Frag::cmp wants
+        a = int(rng.integers(0, 2))
+        reads.append(([q, q + 1], [a, a ^ int(rng.random() < 0.1)], [30, 30]))
+    pile = Pileup.from_reads(reads)
+    ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1], [7], P=2)
+    assert_block_results_equal(ro, rg, "65536 reads")
