@@ -725,7 +725,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
     }
     c->hw_queues = probe_hw_queues(c);
     if (c->knobs.trace) fprintf(stderr, "[floria_hip] device %d: %u streams run side by side\n", device, c->hw_queues);
-    if (c->hw_queues < 6) {
+    if (c->hw_queues < 5) {      // (the probe reads 6 with GPU_MAX_HW_QUEUES=12 - two rounds of its 12 spins - and 3-4 with HIP's default of 4 queues - three or four rounds)
         static std::atomic<bool> said{false};
         if (!said.exchange(true))
             fprintf(stderr, "floria_hip: only %u streams of this process run concurrently on device %d (GPU_MAX_HW_QUEUES was not set to 12 before HIP initialised?): "
@@ -1421,14 +1421,14 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms)
     uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 48 ? 2 : 1);
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
-    if (ctx->hw_queues < 6 && !ctx->knobs.groups) G = std::min<uint32_t>(G, 2);
+    if (ctx->hw_queues < 5 && !ctx->knobs.groups) G = std::min<uint32_t>(G, 2);
     // chunked: consecutive chunks may share a job group (SC.chunk_groups), which then starts when its LAST chunk has landed
     std::vector<uint32_t> chunk_group;
     hipEvent_t group_ev[floria_hip_ctx::MAX_GROUPS] = {};
     if (chunked) {
         const uint32_t nc = std::min<uint32_t>(SC.n_chunks, floria_hip_ctx::MAX_GROUPS);
         G = SC.chunk_groups ? std::min<uint32_t>(SC.chunk_groups, nc) : nc;
-        if (ctx->hw_queues < 6) G = std::min<uint32_t>(G, 2);          // (groups on shared hardware queues serialise: two at most)
+        if (ctx->hw_queues < 5) G = std::min<uint32_t>(G, 2);          // (groups on shared hardware queues serialise: two at most)
         chunk_group.resize(SC.n_chunks);
         for (uint32_t c = 0; c < SC.n_chunks; ++c) { chunk_group[c] = std::min<uint32_t>((uint32_t)((uint64_t)std::min(c, nc - 1) * G / nc), G - 1); group_ev[chunk_group[c]] = SC.chunk_ev[std::min(c, nc - 1)]; }
     }
@@ -1458,7 +1458,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // (floria_hip_create measured how many streams really run side by side: hw_queues; main, copy and flatten streams take up to three of them)
         // With GPU_MAX_HW_QUEUES=12 the probe sees 6 spinning kernels side by side on an MI355X, and stages of up to 10 lanes measured fine (round 2: 250
         // contigs 24-26 ms against 38 without); with the runtime's default of 4 queues it sees 4 or fewer, and there the gated lanes serialise (3-8x).
-        const uint32_t lanes_ok = ctx->hw_queues >= 6 ? 10u : (ctx->hw_queues > 1 ? ctx->hw_queues - 1 : 1u);
+        const uint32_t lanes_ok = ctx->hw_queues >= 5 ? 10u : (ctx->hw_queues > 1 ? ctx->hw_queues - 1 : 1u);
         if (ctx->knobs.speculate < 0 && spec) { const uint32_t w = spec == 1 ? P : std::max<uint32_t>(std::min(3u, P), P > 3 ? P - 3 : 0); if (w * G > lanes_ok) spec = 0; }
         if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);

@@ -325,7 +325,7 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
  * "upload_chunks" (chunks of floria_hip_phase_pileups_batch, 0 = auto), "reassign_path", "no_bulk" (tests: every beam step through the general
  * insert path with its duplicate test), "hw_queues" (tests: override the number of
  * concurrently running streams floria_hip_create measured — 6 on an MI355X whose host set GPU_MAX_HW_QUEUES=12 before HIP initialised, 4 or fewer
- * with the runtime's default; below 6 the launch plans stay within two job groups and do not speculate). */
+ * with the runtime's default; below 5 the launch plans stay within two job groups and do not speculate). */
 int  floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus
