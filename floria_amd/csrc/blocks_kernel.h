@@ -16,6 +16,8 @@ struct ScanArgs {
     uint32_t n_blocks, max_ploidy;
     uint32_t *cnt, *pos0, *span;       // out (pass 1)
     uint64_t* bytes;                   // out (pass 1)
+    uint32_t *h_cnt, *h_span;          // out (pass 1): the same counts written straight into pinned host memory (null = not wanted); the host
+    uint64_t* h_bytes;                 //   waits for the kernel instead of for three small copies that would queue behind the pileup's upload
     const uint64_t* roff;              // in  (pass 2)
     uint32_t* rids;                    // out (pass 2)
 };
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(64) void block_reads_kernel(ScanArgs g) {
             g.pos0[b] = cnt ? mn : 0;
             g.span[b] = cnt ? mx - mn + 1 : 0;
             g.bytes[b] = cnt ? 16 + bytes + cnt + 8ull * g.max_ploidy + 4 : 0;
+            if (g.h_cnt) { g.h_cnt[b] = cnt; g.h_span[b] = cnt ? mx - mn + 1 : 0; g.h_bytes[b] = cnt ? 16 + bytes + cnt + 8ull * g.max_ploidy + 4 : 0; }
         }
     }
 }
