@@ -1359,6 +1359,7 @@ struct S1Contigs {
     uint32_t n_chunks = 0;
     hipEvent_t* chunk_ev = nullptr;
     uint32_t chunk_groups = 0;     // job groups the chunks are merged into (0 = one per chunk)
+    bool ends_apart = false;       // with three groups: first chunk | middle chunks | last chunk
 };
 
 // host mailbox -> device array, by a kernel on the call's own stream (no copy engine involved)
@@ -1474,7 +1475,12 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         G = SC.chunk_groups ? std::min<uint32_t>(SC.chunk_groups, nc) : nc;
         if (ctx->hw_queues < 5) G = std::min<uint32_t>(G, 2);          // (groups on shared hardware queues serialise: two at most)
         chunk_group.resize(SC.n_chunks);
-        for (uint32_t c = 0; c < SC.n_chunks; ++c) { chunk_group[c] = std::min<uint32_t>((uint32_t)((uint64_t)std::min(c, nc - 1) * G / nc), G - 1); group_ev[chunk_group[c]] = SC.chunk_ev[std::min(c, nc - 1)]; }
+        for (uint32_t c = 0; c < SC.n_chunks; ++c) {
+            const uint32_t cc = std::min(c, nc - 1);
+            // ends_apart: the first chunk is a group of its own (it starts while the rest is still arriving and is too small to own every wave slot), so is the last
+            chunk_group[c] = SC.ends_apart && G == 3 && nc >= 3 ? (cc == 0 ? 0u : cc == nc - 1 ? 2u : 1u) : std::min<uint32_t>((uint32_t)((uint64_t)cc * G / nc), G - 1);
+            group_ev[chunk_group[c]] = SC.chunk_ev[cc];
+        }
     }
     std::vector<uint32_t> group_off(G + 1, 0);
     if (chunked) {
@@ -1734,9 +1740,9 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
         SC.len_max = BINOM_NMAX_CAP; SC.nall = 2; SC.any_q0 = false;                      // optimistic plan, verified below
         SC.contig_chunk = UP.contig_chunk.data(); SC.n_chunks = UP.n_chunks; SC.chunk_ev = ctx->ev_chunk;
         // the compact wire form is on the device in a tenth of the step: what counts then is that the expand / flatten launches of the later chunks are
-        // not starved by persistent grids that already own every wave slot — two job groups (the first starts when the first half has landed) measured
-        // best (config 4, ms per step: 106.7 against 109.6 with a group per chunk and 109.4 with a single group)
-        if (pk) SC.chunk_groups = 2;
+        // not starved by persistent grids that already own every wave slot.  Measured on config 4 (5 chunks, three runs each, ms per step; chunk -> group):
+        // 0|111|2 106.7, 0|11|22 107.7, 00|11|2 108.0, 000|11 108.9, 00|111 108.9, 0|1111 109.3, a group per chunk 109.6, one group 109.4
+        if (pk) { SC.chunk_groups = 3; SC.ends_apart = true; }
         rc = s1_core(ctx, SC, blk_contig, blk_start, blk_end, n_blocks, prm, &R);
         if (rc) return drop(rc);
         const floria_timing tm = ctx->timing;
