@@ -364,7 +364,18 @@ def test_packed_upload_equals_csr_upload(gpu_ctx, hip_lib):
     r_pk3 = gpu_ctx.phase_pileups_batch(parr, bc, bs, be, par)
     assert gpu_ctx.timing()["upload_chunks"] == 3
     r_csr = gpu_ctx.phase_pileups_batch(hip_lib.c_pileups(pinned), bc, bs, be, par)
+    # five chunks, one ploidy per stage (the plan of a full-size batch): a packed call runs them as three job groups, first | middle | last chunk
+    # (the biallelic contigs alone: a batch with four alleles or q = 0 cells abandons the optimistic pipelined plan and phases again from the resident arrays)
+    arena2, parr2, _ = hip_lib.pack_pileups([c.pileup for c in contigs])
+    gpu_ctx.set_option("speculate", 0)
+    gpu_ctx.set_option("upload_chunks", 5)
+    r_pk5 = gpu_ctx.phase_pileups_batch(parr2, [x - 4 for x in bc], bs, be, par)
+    t5 = gpu_ctx.timing()
+    assert t5["upload_chunks"] == 5 and t5["streams"] == 3 and t5["stage_width"] == 1
+    gpu_ctx.set_option("speculate", -1)
     gpu_ctx.set_option("upload_chunks", 0)
+    assert_block_results_equal(r_res, r_pk5, "resident vs packed host pileups in 5 chunks / 3 job groups")
+    arena2.free()
     assert_block_results_equal(r_res, r_pk, "resident vs packed host pileups")
     assert_block_results_equal(r_res, r_pk3, "resident vs packed host pileups in 3 chunks")
     assert_block_results_equal(r_res, r_csr, "resident vs CSR host pileups")
