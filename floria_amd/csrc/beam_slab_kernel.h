@@ -898,9 +898,6 @@ void beam_slab_kernel(BeamArgs g) {
                     }
                 }
             }
-#ifdef FLORIA_X_SLEEP
-            __builtin_amdgcn_s_sleep(FLORIA_X_SLEEP);
-#endif
             cm_cur = cm_next; sm_cur = sm_next;
             if (i + 2 < n) { cm_next = rec_cm(rec_hold); sm_next = rec_sm(rec_hold); }
             __syncthreads();
