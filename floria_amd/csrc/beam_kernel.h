@@ -44,6 +44,7 @@ struct BeamArgs {
     const double* binom_tab;       // host libm table of stable_binom_cdf_p_rev(n,k), tri-indexed, n <= binom_nmax
     uint32_t  binom_nmax;
     double    eps, div_factor, cutoff;
+    float     ln_eps, ln_1meps;    // ln(eps), ln(1 - eps) rounded to f32: the level-1 screen of beam_slab_kernel's pruning test
     const uint64_t *Rq1, *Rp1, *Rq2, *Rp2;   // [span_max*A] random multipliers of the linear state hash
     uint8_t*  part_out;            // [blk_read_off[n_blocks]] partition of every read of every block
     double*   job_margin;          // [n_blocks*max_ploidy] min |p_k - lse - ln(PROB_CUTOFF)| over the pruning decisions of the (block, ploidy) job

@@ -85,6 +85,60 @@ constexpr int SLAB_DUMMY_WORDS = 64 * FLORIA_MAX_ALLELES * 2 + 16;      // u32 w
 constexpr double PRUNE_SCREEN = 1e-3;     // >> the f32 screen's error bound (2e-5)
 constexpr int SLAB_U = 6;      // 16-B slab loads in flight per lane (q = 0 pileups: classification from the sums)
 
+// stable_binom_cdf_p_rev (utils_frags.rs:211-248) in f32 with the hardware reciprocal and log2: the SCREEN of the pruning test (the decisions it cannot make take
+// the exact host-libm table).  a = k/n and 1 - a = (n - k)/n are formed from the integers, so neither loses bits next to 0 or 1; the two clamps are the reference's.
+// |result - exact| <= BINOM_SCREEN_C * n for n <= 1024 and 1e-3 <= eps <= 0.2: measured 4.7e-6 * n at eps = 2^-5, 9.2e-6 * n at eps = 1e-3 with every rcp / log2
+// result moved one ulp against the sign of the error (numpy emulation), and on the device over the whole table by floria_hip_selftest (tests/test_gpu_parity.py).
+constexpr float BINOM_SCREEN_C = 2e-5f;
+__device__ __forceinline__ float binom_screen_f32(uint32_t nn, uint32_t kk, float ln_eps, float ln_1meps, float eps_f, float rdiv_f) {
+    const float n = (float)nn, k = (float)kk;
+    const float rn = __builtin_amdgcn_rcpf(n);
+    float a = k * rn, b = (n - k) * rn;
+    if (kk == nn) { a = 0.9999999f; b = 1.0000000000287557e-07f; }      // (1.0 - 0.9999999 in f64)
+    if (kk == 0) { a = 1e-7f; b = 0.9999999f; }
+    const float la = __builtin_amdgcn_logf(a) * 0.693147180559945309f - ln_eps;
+    const float lb = __builtin_amdgcn_logf(b) * 0.693147180559945309f - ln_1meps;
+    float rel = a * la + b * lb;
+    rel = a < eps_f ? -rel : rel;
+    return nn ? -(n * rdiv_f) * rel : 0.f;
+}
+
+// Level 2 of the pruning test (see phase B): exact p-values from the host-libm table, the f32 exp2 / log2 screen on their exact differences and, where that
+// is not decisive, the f64 exp / log of the reference formula.  Out of line: reached in a few percent of the steps, and its f64 temporaries would otherwise count
+// against the steady-state register budget.  The whole wave calls it (wave-uniform branch); TPS = compile-time ploidy of the DPP-segmented instances, else 0.
+struct Prune2 { double min_margin; uint32_t pass, fallback; };
+template <int TPS>
+__device__ __attribute__((noinline)) Prune2 prune_level2(uint32_t nn, uint32_t kk, bool act, int seg0, uint32_t p, const double* tab, uint32_t nmax, double eps, double div_factor,
+                                                         double cutoff, double min_margin) {
+    constexpr uint32_t PSC = TPS == 2 ? 2 : 4;
+    Prune2 r; r.fallback = 0;
+    double pv = 0.0;
+    if (act) {
+        if (nn <= nmax) pv = tab[nn * (nn + 1) / 2 + kk];
+        else { pv = binom_device(nn, kk, eps, div_factor); r.fallback = 1; }
+    }
+    double mx = 0.0;
+    if constexpr (TPS != 0) static_for<0, TPS>([&](auto J) { constexpr int j = decltype(J)::value; const double o = seg_get_f64<PSC, j>(pv); mx = (j == 0) ? o : (o > mx ? o : mx); });
+    else for (uint32_t j = 0; j < p; ++j) { const double o = shfl_f64(pv, seg0 + (int)j); mx = (j == 0) ? o : (o > mx ? o : mx); }
+    const double dx = pv - mx;
+    const float ef2 = __builtin_amdgcn_exp2f((float)dx * 1.44269504088896341f);
+    float sumf2 = 0.f;
+    if constexpr (TPS != 0) static_for<0, TPS>([&](auto J) { sumf2 += seg_get_f32<PSC, decltype(J)::value>(ef2); });
+    else for (uint32_t j = 0; j < p; ++j) sumf2 += __shfl(ef2, seg0 + (int)j);
+    const double dscr = (dx - (double)(__builtin_amdgcn_logf(sumf2) * 0.693147180559945309f)) - cutoff;
+    const double ascr = fabs(dscr);
+    const bool far_enough = ascr >= PRUNE_SCREEN && ascr - PRUNE_SCREEN >= min_margin;     // false for NaN
+    bool pass = dscr > 0.0;
+    if (__any(act && !far_enough)) {
+        const double lse = mx + log_sum_exp_terms(dx, seg0, p);
+        const double am = fabs((pv - lse) - cutoff);
+        if (act) min_margin = am < min_margin ? am : min_margin;
+        pass = (pv - lse) > cutoff;
+    }
+    r.pass = pass ? 1u : 0u; r.min_margin = min_margin;
+    return r;
+}
+
 struct SlabLds {
     uint32_t off_coff, off_caw, off_crp1, off_crp2;
     uint32_t off_q[2], off_h1[2], off_h2[2], off_m[2], off_sl[2];     // state arrays (SoA) x2
@@ -178,6 +232,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t psl = DPPSEG ? PSC : p;
     const uint32_t S = 64 / psl;
     const float rcp_p = __builtin_amdgcn_rcpf((float)p);
+    const float eps_f = (float)g.eps, rdiv_f = (float)(1.0 / g.div_factor), cutoff_f = (float)g.cutoff;
     const uint32_t my_sl = lane / psl, my_k = lane % psl;
     const bool lane_pair = my_sl < S && my_k < p;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -190,6 +245,7 @@ void beam_slab_kernel(BeamArgs g) {
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
     unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0, c_copy_pos = 0, c_ncopy = 0, c_add_items = 0, c_zero_items = 0, c_nlead = 0, c_trunc = 0;
+    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0;
 #endif
 
     for (;;) {
@@ -267,6 +323,7 @@ void beam_slab_kernel(BeamArgs g) {
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
             const uint64_t tw1 = sm_cur.tw1, tw2 = sm_cur.tw2;
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
+            const float tol1 = 4.f * BINOM_SCREEN_C * (float)L + 1e-3f;      // level-1 screen of the pruning test (phase B): n <= L in every lane
             const uint32_t ntiles = (L + SLAB_TILE - 1) / SLAB_TILE;
             const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
             uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);
@@ -539,7 +596,8 @@ void beam_slab_kernel(BeamArgs g) {
                 const bool act = lane_pair && a < nstates;
                 uint64_t qd = 0, t1 = 0, t2 = 0, np1 = 0, np2 = 0;
                 uint32_t m = 0;
-                double pv = 0.0;
+                uint32_t nn = 0, kk = 0;
+                float pvf = 0.f;
                 if (act) {
                     const uint32_t li = s2l[st_sl[a * p + my_k]];
                     const uint64_t qs = r_qs[li];
@@ -548,40 +606,43 @@ void beam_slab_kernel(BeamArgs g) {
                     if (Q0) { np1 = r_np1[li]; np2 = r_np2[li]; }
                     const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
                     // `as usize` of the two sums: both are < 2^32 (a read has < 2^32 cells of weight <= 1), so the 1-instruction u32 conversion is exact
-                    const uint32_t nn = (uint32_t)(same_f + diff_f), kk = (uint32_t)diff_f;
-                    if (nn <= g.binom_nmax) pv = g.binom_tab[nn * (nn + 1) / 2 + kk];
-                    else { pv = binom_device(nn, kk, g.eps, g.div_factor); n_fallback++; }
+                    nn = (uint32_t)(same_f + diff_f); kk = (uint32_t)diff_f;
+                    pvf = binom_screen_f32(nn, kk, g.ln_eps, g.ln_1meps, eps_f, rdiv_f);
                 }
-                double mx = 0.0;
                 uint64_t ts1 = 0, ts2 = 0;
-                if constexpr (DPPSEG) {
-                    static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; const double o = seg_get_f64<PSC, j>(pv); mx = (j == 0) ? o : (o > mx ? o : mx); });
-                    if (trunc) static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; ts1 += seg_get64<PSC, j>(t1); ts2 += seg_get64<PSC, j>(t2); });
-                } else {
-                for (uint32_t j = 0; j < p; ++j) {
-                    const double o = shfl_f64(pv, seg0 + (int)j);
-                    mx = (j == 0) ? o : (o > mx ? o : mx);
-                }
-                if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
-                }
-                // Pruning test (pv - lse) > ln 0.01 and its margin.  Screen with hardware f32 exp2/log2 (error of the screened
-                // value < 2e-5): a decision further than PRUNE_SCREEN from the threshold AND from the wave's running
-                // minimum margin has the same outcome and cannot lower the minimum, so the f64 exp/log (identical to the generic
-                // kernels and the oracle's formula) only run in the steps where some lane is close.
-                const double dx = pv - mx;
-                const float ef = __builtin_amdgcn_exp2f((float)dx * 1.44269504088896341f);
-                float sumf = 0.f;
-                if constexpr (DPPSEG) static_for<0, TP>([&](auto J) { sumf += seg_get_f32<PSC, decltype(J)::value>(ef); });
-                else for (uint32_t j = 0; j < p; ++j) sumf += __shfl(ef, seg0 + (int)j);
-                const double dscr = (dx - (double)(__builtin_amdgcn_logf(sumf) * 0.693147180559945309f)) - g.cutoff;
-                const double ascr = fabs(dscr);
-                const bool far_enough = ascr >= PRUNE_SCREEN && ascr - PRUNE_SCREEN >= min_margin;     // false for NaN
-                bool pass = dscr > 0.0;
-                if (__any(act && !far_enough)) {
-                    const double lse = mx + log_sum_exp_terms(dx, seg0, p);
-                    const double am = fabs((pv - lse) - g.cutoff);
-                    if (act) min_margin = am < min_margin ? am : min_margin;
-                    pass = (pv - lse) > g.cutoff;
+                if constexpr (DPPSEG) { if (trunc) static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; ts1 += seg_get64<PSC, j>(t1); ts2 += seg_get64<PSC, j>(t2); }); }
+                else if (trunc) for (uint32_t j = 0; j < p; ++j) { ts1 += shfl_u64(t1, seg0 + (int)j); ts2 += shfl_u64(t2, seg0 + (int)j); }
+                // Pruning test (pv - lse) > ln 0.01 and its margin, decided in two screens.
+                // Level 1, every step, no memory: pv from an f32 evaluation of stable_binom_cdf_p_rev (hardware rcp / log2; |error| <= BINOM_SCREEN_C * n, n <= L,
+                // checked against the host table by floria_hip_selftest), log-sum-exp in f32.  |d_f32 - d_exact| <= tol1 (log-sum-exp is 1-Lipschitz in the
+                // max norm of its arguments): a decision further than tol1 from the threshold AND from the job's running minimum margin has the same outcome and
+                // cannot lower the minimum.  Level 2, only when some lane is closer: the exact p-values from the host-libm table (one gather), then the round-3
+                // screen on them (f32 exp2 / log2 of exact differences) and, where that is not decisive either, the f64 exp / log of the reference formula.
+                bool pass;
+                {
+                    float mxf = 0.f;
+                    if constexpr (DPPSEG) static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; const float o = seg_get_f32<PSC, j>(pvf); mxf = (j == 0) ? o : (o > mxf ? o : mxf); });
+                    else for (uint32_t j = 0; j < p; ++j) { const float o = __shfl(pvf, seg0 + (int)j); mxf = (j == 0) ? o : (o > mxf ? o : mxf); }
+                    const float dxf = pvf - mxf;
+                    const float ef = __builtin_amdgcn_exp2f(dxf * 1.44269504088896341f);
+                    float sumf = 0.f;
+                    if constexpr (DPPSEG) static_for<0, TP>([&](auto J) { sumf += seg_get_f32<PSC, decltype(J)::value>(ef); });
+                    else for (uint32_t j = 0; j < p; ++j) sumf += __shfl(ef, seg0 + (int)j);
+                    const float dsf = (dxf - __builtin_amdgcn_logf(sumf) * 0.693147180559945309f) - cutoff_f;
+                    const float asf = fabsf(dsf) - tol1;
+                    const bool far1 = asf > 0.f && (double)asf >= min_margin;     // false for NaN
+                    pass = dsf > 0.f;
+#ifdef FLORIA_NO_BINOM_SCREEN
+                    if (true) {
+#else
+                    if (__any(act && !far1)) {
+#endif
+#ifdef FLORIA_PROF
+                        c_lvl2++;
+#endif
+                        const Prune2 r2 = prune_level2<DPPSEG ? TP : 0>(nn, kk, act, seg0, p, g.binom_tab, g.binom_nmax, g.eps, g.div_factor, g.cutoff, min_margin);
+                        pass = r2.pass != 0; min_margin = r2.min_margin; n_fallback += r2.fallback;
+                    }
                 }
                 pass = pass && act;
                 uint64_t ch1 = 0, ch2 = 0, cq = 0, cs = 0;
@@ -774,7 +835,13 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint64_t fm = __ballot(rf);
                 if (rf) { const uint32_t idx = nl + mbcnt64(fm); live_id[idx] = (uint16_t)x; s2l[x] = (uint16_t)idx; }
                 nl += (uint32_t)__popcll(fm);
+#ifdef FLORIA_PROF
+                c_id8 += (unsigned)__popcll(__ballot(rf && x >= 8)); c_id16 += (unsigned)__popcll(__ballot(rf && x >= 16)); c_id32 += (unsigned)__popcll(__ballot(rf && x >= 32));
+#endif
             }
+#ifdef FLORIA_PROF
+            { c_nl += nl; const uint32_t Wd = (uint32_t)(new_hi - (int32_t)first_rel + 1); c_wsum += Wd; c_w128 += Wd > 128; c_w256 += Wd > 256; c_w512 += Wd > 512; if (!bulk) c_general++; }
+#endif
             __syncthreads();
             if (new_hi > hi_rel) {
                 const uint32_t cntz = (uint32_t)(new_hi - hi_rel) * (NARROW ? 1u : (uint32_t)A);      // 8-B words per slab
@@ -805,6 +872,7 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint32_t nlead = (uint32_t)__popcll(lmask);
 #ifdef FLORIA_PROF
                 c_nlead += nlead; c_add_items += (unsigned long long)nlead * L;
+                { const uint32_t it = nlead * L; c_it64 += it > 64; c_it128 += it > 128; c_it256 += it > 256; }
 #endif
                 // leaders' target slabs, compacted into freelist[] (reused as scratch)
                 if (lead) freelist[mbcnt64(lmask)] = newid[u_old];
@@ -939,6 +1007,8 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[26 + g.ploidy], wall_clock64() - t_wall0);
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
                      atomicAdd(&g.prof[32], c_copy_pos); atomicAdd(&g.prof[33], c_ncopy); atomicAdd(&g.prof[34], c_add_items); atomicAdd(&g.prof[35], c_zero_items); atomicAdd(&g.prof[36], c_nlead); atomicAdd(&g.prof[37], c_trunc);
+                     atomicAdd(&g.prof[38], c_nl); atomicAdd(&g.prof[39], c_id8); atomicAdd(&g.prof[40], c_id16); atomicAdd(&g.prof[41], c_id32); atomicAdd(&g.prof[42], c_w128); atomicAdd(&g.prof[43], c_w256);
+                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general);
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     n_fallback = wave_sum_u32(n_fallback);

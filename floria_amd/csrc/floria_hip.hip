@@ -538,6 +538,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
                     a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
                     a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
+                    a.ln_eps = (float)std::log(prm->epsilon); a.ln_1meps = (float)std::log(1.0 - prm->epsilon);
                     a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
                     a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
                     a.prof = (unsigned long long*)(d_diag + 4);
@@ -1153,7 +1154,13 @@ bool pack_layout(const floria_pileup* in, uint32_t n, PackLayout& Y) {
         const uint64_t R = p->n_reads;
         if (R && (!p->read_off || !p->first || !p->last || !p->snp || !p->allele || !p->qual)) return false;
         uint64_t bits = 0;
-        for (uint64_t r = 0; r < R; ++r) { if (p->last[r] < p->first[r]) return false; bits += (uint64_t)p->last[r] - p->first[r] + 1; }
+        // read_off sizes every buffer (through read_off[R]) AND bounds the packing loop below, which runs before any device-side validation: it must be a
+        // CSR offset array — 0 first, strictly ascending (a read without cells is refused by the CSR upload as well)
+        if (R && p->read_off[0] != 0) return false;
+        for (uint64_t r = 0; r < R; ++r) {
+            if (p->last[r] < p->first[r] || p->read_off[r + 1] <= p->read_off[r]) return false;
+            bits += (uint64_t)p->last[r] - p->first[r] + 1;
+        }
         if (bits >= (1ull << 32)) return false;
         Y.rp[i + 1] = Y.rp[i] + R; Y.cp[i + 1] = Y.cp[i] + (R ? p->read_off[R] : 0); Y.pb[i + 1] = Y.pb[i] + (bits + 7) / 8 + 1;
     }
@@ -1175,7 +1182,7 @@ int floria_hip_pack_pileups_batch(const floria_pileup* in, uint32_t n, void* buf
     if ((n && (!in || !out)) || (!buf && buf_bytes)) return fail(FLORIA_E_INVALID, "null argument");
     if (!n) return 0;
     PackLayout Y;
-    if (!pack_layout(in, n, Y)) return fail(FLORIA_E_INVALID, "pileup cannot be packed (null field, last < first, or spans of 2^32 bits and more)");
+    if (!pack_layout(in, n, Y)) return fail(FLORIA_E_INVALID, "pileup cannot be packed (null field, read_off not a strictly ascending offset array from 0, last < first, or spans of 2^32 bits and more)");
     if (buf_bytes < Y.total) return fail(FLORIA_E_INVALID, "pack buffer too small (floria_hip_pack_bytes_batch)");
     char* B = (char*)buf;
     memset(B + Y.o_pr, 0, Y.pb[n] + 16); memset(B + Y.o_a2, 0, Y.cp[n] / 4 + n + 16);
@@ -1191,9 +1198,11 @@ int floria_hip_pack_pileups_batch(const floria_pileup* in, uint32_t n, void* buf
             const uint32_t F = p->first[r], span = p->last[r] - F + 1;
             for (uint32_t c = p->read_off[r]; c < p->read_off[r + 1]; ++c) {
                 const uint32_t sp = p->snp[c];
-                const std::string where = " (read " + std::to_string((unsigned long long)r) + (n > 1 ? ", contig " + std::to_string(i) + " of the batch)" : ")");
-                if (sp < F || sp - F >= span) return fail(FLORIA_E_INVALID, "cell outside [first, last]" + where);
-                if (p->allele[c] > 3) return fail(FLORIA_E_UNSUPPORTED, "allele index > 3" + where);
+                if (sp < F || sp - F >= span || p->allele[c] > 3) {
+                    const std::string where = " (read " + std::to_string((unsigned long long)r) + (n > 1 ? ", contig " + std::to_string(i) + " of the batch)" : ")");
+                    if (p->allele[c] > 3 && !(sp < F || sp - F >= span)) return fail(FLORIA_E_UNSUPPORTED, "allele index > 3" + where);
+                    return fail(FLORIA_E_INVALID, "cell outside [first, last]" + where);
+                }
                 const uint64_t bi = bit + (sp - F);
                 pr[bi >> 3] |= (uint8_t)(1u << (bi & 7));
                 a2[c >> 2] |= (uint8_t)(p->allele[c] << (2 * (c & 3)));
@@ -1529,7 +1538,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
               // zero-initialised, contiguous (ONE memset): partition output, mec / num_alleles / iters, stop-rule state, queue counters, diagnostics
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),
               s_done = seg(n_blocks + 4), s_best = seg(4ull * n_blocks + 4), s_tried = seg(4ull * n_blocks + 4), s_ready = seg(4ull * n_blocks + 4),
-              s_q = seg(8ull * floria_hip_ctx::MAX_LANES * FLORIA_MAX_PLOIDY + 16), s_diag = seg(16 + 8 * 48), s_steps = seg(16);
+              s_q = seg(8ull * floria_hip_ctx::MAX_LANES * FLORIA_MAX_PLOIDY + 16), s_diag = seg(16 + 8 * 64), s_steps = seg(16);
     const size_t zero_bytes = cursor - s_out.off;
     const Seg s_stop = seg(4ull * n_blocks + 4);             // speculative stages: smallest ploidy at which the stop rule is known to break, 0xffffffff = unknown
     rc = ctx->misc.ensure(cursor + 256); if (rc) return rc;
@@ -1617,7 +1626,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     TR.mark("results on the host");
     if (diag[1]) { return fail(FLORIA_E_DEVICE, "internal: beam slab free-list underflow"); }
 #ifdef FLORIA_PROF
-    { unsigned long long prof[48]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 48; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
+    { unsigned long long prof[64]; (void)hipMemcpy(prof, M + s_diag.off + 16, sizeof(prof), hipMemcpyDeviceToHost); fprintf(stderr, "[prof]"); for (int i = 0; i < 64; ++i) fprintf(stderr, " %d:%.1fM", i, prof[i] / 1e6); fprintf(stderr, "\n"); }
 #endif
     memcpy(R->read_off, roff.data(), 8ull * (n_blocks + 1));
     // the pruning decisions of the (block, ploidy) jobs the reference runs, i.e. ploidy <= ploidies_tried (a speculative stage may have run more)

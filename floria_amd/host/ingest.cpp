@@ -574,15 +574,19 @@ bool BamStream::next(BamFile& seg, size_t min_bytes) {
             whole_end = o;
         }
         if (at_end && whole_end != buf.size()) throw Error(FLORIA_E_INVALID, I.path + " is truncated");
+        // Unplaced reads (tid = -1) sort behind every target: once one is seen, every target is complete and nothing that follows is of use (the reference fetches
+        // per contig through the index and never reads them, file_reader.rs:389-436).  The stream ends there — carrying an unmapped tail larger than the window
+        // from call to call would never make progress.
+        const bool closing = at_end || saw_unmapped;
         size_t cut; int32_t complete_upto;
-        if (at_end) { cut = saw_unmapped ? last_start_of_tid : whole_end; complete_upto = n_targets; }
+        if (closing) { cut = saw_unmapped ? last_start_of_tid : whole_end; complete_upto = n_targets; }
         else { cut = last_start_of_tid; complete_upto = cur_tid == INT32_MIN ? I.done_upto : std::min(cur_tid, n_targets); }      // the target of the last record may continue
-        if (!at_end && (cut == 0 || complete_upto <= I.done_upto) && !(cur_tid == n_targets)) { want = std::max(want * 2, buf.size() * 2); continue; }   // one target fills the buffer: read on
+        if (!closing && (cut == 0 || complete_upto <= I.done_upto)) { want = std::max(want * 2, buf.size() * 2); continue; }   // one target fills the buffer: read on
         // ---- hand out
         seg = BamFile();
         seg.target_names = I.names; seg.target_len = I.lens;
         seg.by_tid.resize(I.names.size());
-        I.carry.assign(buf.begin() + (ptrdiff_t)cut, buf.begin() + (ptrdiff_t)(at_end ? cut : buf.size()));
+        I.carry.assign(buf.begin() + (ptrdiff_t)cut, buf.begin() + (ptrdiff_t)(closing ? cut : buf.size()));
         buf.resize(cut);
         seg.raw = std::move(buf);
         I.peak = std::max(I.peak, seg.raw.size() + I.carry.size());
@@ -590,7 +594,7 @@ bool BamStream::next(BamFile& seg, size_t min_bytes) {
         seg.tid_begin = I.done_upto; seg.tid_end = complete_upto;
         I.done_upto = complete_upto;
         I.last_tid_seen = std::max(I.last_tid_seen, std::min(prev, n_targets));
-        if (at_end) { I.eof = true; I.carry.clear(); }
+        if (closing) { I.eof = true; I.carry.clear(); I.bi = I.blocks.size(); }
         return true;
     }
 }

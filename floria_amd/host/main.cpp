@@ -97,10 +97,11 @@ int main(int argc, char** argv) {
     std::string stitch_graph;
     LpTie lp_tie = LpTie::First;         // --lp-tie first|last: which optimal vertex of the stitching LP is used where the optimum is not unique (stitch.cpp)
     std::atomic<size_t> lp_contigs{0}, lp_not_unique{0}, lp_edges{0}, lp_movable{0};
+    bool lp_report = false;              // --lp-report (implied by --debug): count the edges whose flow differs in another optimal solution of the stitching LP
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
     std::vector<int> devices;            // --devices: the GPUs the contigs of a batch are dealt to (empty: --device alone)
     size_t bam_window = (size_t)512 << 20;   // --bam-window-mb: inflated BAM bytes held at a time (more only when one contig alone is larger)
-    bool eps_as_estimated = false;       // --epsilon-as-estimated: use the auto-estimated -e as it comes (default: rounded to a multiple of 2^-10, see below)
+    bool eps_round = false;              // --epsilon-round: round an auto-estimated -e to a multiple of 2^-10 (default: used as estimated, like the reference)
     std::string run_note;                // second line of cmd.log
     std::thread freer;                   // frees the Frags of the previous batch while the next one is ingested; joined before the process leaves main
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } freer_guard{freer};
@@ -125,12 +126,14 @@ int main(int argc, char** argv) {
             else if (a == "-X" || a == "--no-supp") o.dont_use_supp_aln = true;
             else if (a == "--no-stop-heuristic") o.stopping_heuristic = false;
             else if (a == "--overwrite") o.overwrite = true;
-            else if (a == "--debug" || a == "--trace") debug = true;
+            else if (a == "--debug" || a == "--trace") { debug = true; lp_report = true; }
+            else if (a == "--lp-report") lp_report = true;
             else if (a == "--lp-tie") { const std::string v = val(); if (v != "first" && v != "last") throw Error(FLORIA_E_INVALID, "--lp-tie takes first or last"); lp_tie = v == "last" ? LpTie::Last : LpTie::First; }
             else if (a == "-q") {}
             else if (a == "-G" || a == "--contigs") { while (i + 1 < argc && argv[i + 1][0] != '-') o.list_to_phase.push_back(argv[++i]); }
             else if (a == "--device") o.device = std::stoi(val());
-            else if (a == "--epsilon-as-estimated") eps_as_estimated = true;
+            else if (a == "--epsilon-as-estimated") {}                          // (the default since round 4; accepted for older command lines)
+            else if (a == "--epsilon-round") eps_round = true;
             else if (a == "--bam-window-mb") bam_window = std::max<size_t>(1, std::stoul(val())) << 20;
             else if (a == "--bam-window-kb") bam_window = std::max<size_t>(1, std::stoul(val())) << 10;       // (tests: many segments on a small file)
             else if (a == "--devices") {                                 // "0-7", "0,2,5", "0-3,6"; a device may be named twice (two contexts on it)
@@ -233,9 +236,10 @@ int main(int argc, char** argv) {
         // ---- the epsilon policy (DESIGN.md "Arithmetic").  Every weighted sum of the phasing path is an exact multiple of 2^-24; the only inexact
         // terms of the reference are its running `+= epsilon` additions, whose rounding depends on hash-map iteration order unless epsilon is dyadic.
         // For an epsilon that is a multiple of 2^-10 every one of those sums is exact in f64 in ANY order, so the function this library computes IS the
-        // reference's function.  Hence: an auto-estimated epsilon (parse_cmd_line.rs:72-90) is rounded to the nearest multiple of 2^-10 (a change of at
-        // most 0.0005 to an estimate that is itself a coverage-sampled average) and cmd.log says so; an explicit -e is used as given, with one warning
-        // when it is not such a multiple (results are then an equally good solution, but may differ from the Rust binary's in tie-breaking).
+        // reference's function.  An auto-estimated epsilon (parse_cmd_line.rs:72-90) is used AS ESTIMATED, like the reference does, and cmd.log has the
+        // reference's single line; --epsilon-round rounds it to the nearest multiple of 2^-10 (a change of at most 0.0005 to a coverage-sampled average)
+        // and records both values on a second line of cmd.log.  Whatever its origin, an epsilon that is not such a multiple gets one warning on stderr:
+        // results are then an equally good solution, but may differ from the Rust binary's where scores tie in exact arithmetic.
         auto dyadic10 = [](double e) { const double k = e * 1024.0; return k == std::floor(k); };
         if (!have_e || !have_l) {                                                     // parse_cmd_line.rs:72-90
             tp = now_s();
@@ -247,11 +251,11 @@ int main(int argc, char** argv) {
             if (!have_l) o.block_length = est.first;
             if (!have_e) {
                 o.epsilon = est.second;
-                if (!eps_as_estimated) {
+                if (eps_round) {
                     o.epsilon = std::max(1.0, std::floor(est.second * 1024.0 + 0.5)) / 1024.0;
                     char buf[256];
                     snprintf(buf, sizeof buf, "# floria-hip: -e estimated %.17g, used %.10g (rounded to a multiple of 2^-10: every sum of the phasing path is then exact in f64; "
-                                              "--epsilon-as-estimated or an explicit -e override this)", est.second, o.epsilon);
+                                              "requested by --epsilon-round)", est.second, o.epsilon);
                     run_note = buf;
                 }
             }
@@ -259,7 +263,7 @@ int main(int argc, char** argv) {
         }
         if (!dyadic10(o.epsilon))
             fprintf(stderr, "floria-hip: warning: -e %.17g is not a multiple of 2^-10; sums of epsilon terms are then rounded once here and term by term (in hash-map order) in floria, "
-                            "so haplosets can differ from floria's in exact ties (e.g. -e %.10g avoids that)\n", o.epsilon, std::max(1.0, std::floor(o.epsilon * 1024.0 + 0.5)) / 1024.0);
+                            "so haplosets can differ from floria's in exact ties (-e %.10g, or --epsilon-round for an estimated one, avoids that)\n", o.epsilon, std::max(1.0, std::floor(o.epsilon * 1024.0 + 0.5)) / 1024.0);
         if (!ingest_only) write_run_files(o, argc, argv, run_note);
         const std::vector<std::string> contigs = stream.target_names();                 // get_contigs_to_phase (file_reader.rs:738-746)
         tp = now_s();
@@ -341,13 +345,15 @@ int main(int argc, char** argv) {
                     const std::string& contig = todo[done + i];
                     ContigWork& w = got[i];
                     w.name = contig; w.out_dir = o.out_dir + "/" + contig;
-                    if (!ingest_only) prepare_contig_dir(w.out_dir, o);
                     const auto fa = fasta.find(contig);
                     auto fr = ing[i]->finish();
                     ing[i].reset();
                     w.all_frags = std::move(fr.first); w.frags_without_snps = std::move(fr.second);
                     const auto sgp = vp.snp_to_genome_pos.find(contig);
                     w.snp_to_genome_pos = sgp == vp.snp_to_genome_pos.end() ? nullptr : &sgp->second;
+                    // the contig directory is (re)made only for a contig that has fragments and SNPs, as floria.rs:263-281 does: with --overwrite a contig
+                    // that yields nothing in this run keeps what an earlier run wrote
+                    if (!ingest_only && !w.all_frags.empty() && w.snp_to_genome_pos) prepare_contig_dir(w.out_dir, o);
                     w.contig_len = fa == fasta.end() ? 0 : fa->second.size();
                     std::sort(w.all_frags.begin(), w.all_frags.end());                     // floria.rs:289-293
                     for (size_t k = 0; k < w.all_frags.size(); ++k) w.all_frags[k].counter_id = k;
@@ -384,9 +390,11 @@ int main(int argc, char** argv) {
                 tm[0] += now_s() - t1; t1 = now_s();
                 parallel_for(part.size(), threads, [&](size_t i) {
                     ContigWork& w = part[i];
+                    // (the uniqueness diagnostics cost O(E (V + E)) on top of the solve — 60-70 % more on layered graphs of thousands of columns — and feed
+                    // one summary line: only under --debug / --lp-report)
                     LpInfo li;
-                    w.flows = solve_lp_graph(w.hap_graph, lp_tie, &li);
-                    ++lp_contigs; lp_not_unique += li.movable_edges != 0; lp_edges += w.flows.size(); lp_movable += li.movable_edges;
+                    w.flows = solve_lp_graph(w.hap_graph, lp_tie, lp_report ? &li : nullptr);
+                    if (lp_report) { ++lp_contigs; lp_not_unique += li.movable_edges != 0; lp_edges += w.flows.size(); lp_movable += li.movable_edges; }
                     auto paths = get_disjoint_paths_rewrite(w.hap_graph, w.flows, o);
                     w.path_parts = std::move(paths.first); w.path_ranges = std::move(paths.second);
                     if (debug) write_debug_graph(w);
@@ -436,6 +444,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
+        if (lp_report)
         fprintf(stderr, "LP: the optimum is not unique for %zu of %zu contigs (%zu of %zu edge flows differ in some other optimal solution); this run used the '%s' vertex, "
                         "rerun with --lp-tie %s to see what depends on it\n", lp_not_unique.load(), lp_contigs.load(), lp_movable.load(), lp_edges.load(),
                 lp_tie == LpTie::First ? "first" : "last", lp_tie == LpTie::First ? "last" : "first");

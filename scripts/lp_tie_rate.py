@@ -51,7 +51,7 @@ def main():
     for tie in ("first", "last"):
         out = os.path.join(tmp, "o_" + tie)
         r = subprocess.run([tool, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", "0.03125", "-l", "5000", "--debug",
-                            "--snp-count-filter", "50", "--lp-tie", tie], capture_output=True, text=True)
+                            "--snp-count-filter", "50", "--lp-report", "--lp-tie", tie], capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr); sys.exit(1)
         m = re.search(r"LP: the optimum is not unique for (\d+) of (\d+) contigs \((\d+) of (\d+) edge flows", r.stderr)

@@ -201,14 +201,23 @@ def test_auto_estimated_parameters(floria_hip, tmp_path):
     assert r.returncode == 0, r.stderr
     m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+) \(used where not given: -l (\d+), -e ([0-9.eE+-]+)\)", r.stderr)
     assert m and 0.01 <= float(m.group(2)) < 0.2 and int(m.group(1)) >= 500
-    # the epsilon policy: the estimate is rounded to a multiple of 2^-10 (there every sum of the path is exact and the product's function is the
-    # reference's), cmd.log records it on a second line, and no "not a multiple" warning is printed
+    # the epsilon policy: the estimate is used AS ESTIMATED, like the reference (parse_cmd_line.rs:72-90), cmd.log has the reference's single
+    # line, and a value that is not a multiple of 2^-10 gets the one warning
+    used = float(m.group(4))
+    assert abs(used - float(m.group(2))) <= 1e-5 * used          # (the message prints the estimate with %g)
+    assert len(open(os.path.join(out, "cmd.log")).read().strip().split("\n")) == 1
+    assert r.stderr.count("not a multiple of 2^-10") == (0 if used * 1024 == int(used * 1024) else 1)
+    assert os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))
+    # --epsilon-round: the estimate rounded to a multiple of 2^-10 (there every sum of the path is exact and the product's function is the reference's),
+    # cmd.log records both values on a second line, and no warning is printed
+    r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "--epsilon-round", "--overwrite"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Estimated -l (\d+), -e ([0-9.eE+-]+) \(used where not given: -l (\d+), -e ([0-9.eE+-]+)\)", r.stderr)
     used = float(m.group(4))
     assert used * 1024 == int(used * 1024) and abs(used - float(m.group(2))) <= 0.5 / 1024 + 1e-12
     lines = open(os.path.join(out, "cmd.log")).read().split("\n")
     assert lines[1].startswith("# floria-hip: -e estimated") and f"used {used:.10g}" in lines[1]
     assert "not a multiple of 2^-10" not in r.stderr
-    assert os.path.exists(os.path.join(out, c.name, f"{c.name}.vartigs"))
     # an explicit non-dyadic -e is used as given, with one warning; --overwrite removes what an earlier run left in the contig directory
     stale = os.path.join(out, c.name, "long_reads")
     os.makedirs(stale); open(os.path.join(stale, "0_part.fastq"), "w").write("stale")
@@ -278,3 +287,43 @@ def test_contigs_dealt_to_several_device_contexts_write_the_same_files(floria_hi
         for n in names:
             if n != "cmd.log":                                   # (the command line itself differs)
                 assert t[n] == trees[0][n], n
+
+
+def test_overwrite_keeps_the_directory_of_a_contig_without_fragments(floria_hip, tmp_path):
+    # floria.rs:263-281: the contig directory is removed (--overwrite) and re-made only AFTER `all_frags.len() == 0 -> continue` and only for a contig of the SNP
+    # map; a contig that yields no fragments in this run keeps what an earlier run wrote.
+    import struct
+    from tests.test_host_cpu import _bgzf_member, _BGZF_EOF
+    cs = [synth.make_config_contig(4, 90 + i, 0.12, keep_layout=True) for i in range(2)]
+    prefix = str(tmp_path / "ow")
+    synth_bam.write_dataset(prefix, cs, seed=4)
+    out = str(tmp_path / "o")
+    base = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", str(EPS), "-l", "10000", "--snp-count-filter", "20"]
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    first = {c.name: open(os.path.join(out, c.name, f"{c.name}.haplosets")).read() for c in cs}
+    # the same BAM without the records of the second contig
+    raw = gzip.open(prefix + ".bam", "rb").read()
+    l_text = struct.unpack_from("<I", raw, 4)[0]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<I", raw, o)[0]; o += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<I", raw, o)[0]; o += 4 + ln + 4
+    kept = raw[:o]
+    while o < len(raw):
+        bs = struct.unpack_from("<I", raw, o)[0]
+        if struct.unpack_from("<i", raw, o + 4)[0] == 0:
+            kept += raw[o:o + 4 + bs]
+        o += 4 + bs
+    with open(prefix + ".bam", "wb") as f:
+        for k in range(0, len(kept), 60000):
+            f.write(_bgzf_member(kept[k:k + 60000]))
+        f.write(_BGZF_EOF)
+    for c in cs:
+        open(os.path.join(out, c.name, "stale.txt"), "w").write("stale")
+    r = subprocess.run(base + ["--overwrite"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(os.path.join(out, cs[0].name, "stale.txt"))                       # phased again: directory re-made
+    assert open(os.path.join(out, cs[0].name, f"{cs[0].name}.haplosets")).read() == first[cs[0].name]
+    assert os.path.exists(os.path.join(out, cs[1].name, "stale.txt"))                           # no fragments in this run: untouched
+    assert open(os.path.join(out, cs[1].name, f"{cs[1].name}.haplosets")).read() == first[cs[1].name]

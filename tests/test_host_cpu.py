@@ -662,3 +662,50 @@ def test_unsorted_bam_is_refused(floria_hip, tmp_path):
     r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", str(tmp_path / "o"), "-e", "0.03", "-l", "10000", "--ingest-only"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "not sorted by reference sequence" in r.stderr
+
+
+def test_unmapped_tail_larger_than_the_window_ends_the_stream(floria_hip, tmp_path):
+    # a sorted BAM ends in its unplaced reads (tid = -1); when they outgrow the window BamStream::next used to hand the same empty segment
+    # out for ever.  50 mapped + 3000 unplaced records with a 1-KiB window (main loop, and the -e / -l estimator loop when neither flag is given) must finish,
+    # give the Frags of the same file without the tail, and the same with the default window.
+    import struct
+    rng = np.random.default_rng(5)
+    L1 = 20000
+    ref1 = "".join("ACGT"[i] for i in rng.integers(0, 4, size=L1))
+    nxt = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    snps = [500 + 150 * i for i in range(120)]
+    def files(prefix, n_unmapped):
+        open(prefix + ".fa", "w").write(f">c1\n{ref1}\n")
+        with open(prefix + ".vcf", "w") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+            for q in snps:
+                f.write(f"c1\t{q + 1}\t.\t{ref1[q]}\t{nxt[ref1[q]]}\t50\tPASS\tDP=10\n")
+        recs = []
+        for r in range(50):
+            beg = 200 * r
+            s = list(ref1[beg:beg + 3000])
+            for q in snps:
+                if beg <= q < beg + 3000 and (r + q) % 3 == 0:
+                    s[q - beg] = nxt[ref1[q]]
+            recs.append(_bam_record(0, beg, f"m{r}", 0, 60, [("M", 3000)], "".join(s), [30] * 3000))
+        for r in range(n_unmapped):
+            recs.append(_bam_record(-1, -1, f"u{r}", 4, 0, [], "ACGTACGTAC" * 10, [20] * 100))
+        text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:%d\n" % L1
+        stream = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 3) + b"c1\0" + struct.pack("<I", L1) + b"".join(recs)
+        with open(prefix + ".bam", "wb") as f:
+            for k in range(0, len(stream), 50000):
+                f.write(_bgzf_member(stream[k:k + 50000]))
+            f.write(_BGZF_EOF)
+    pa, pb = str(tmp_path / "tail"), str(tmp_path / "notail")
+    files(pa, 3000); files(pb, 0)
+    def run(prefix, extra):
+        dump = prefix + ".dump"
+        r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", prefix + "_out", "--ingest-only", "--dump-frags", dump,
+                            "--snp-count-filter", "10", "--no-realign", "-t", "2", *extra], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        return open(dump).read()
+    base = run(pb, ("-e", "0.03", "-l", "10000"))
+    assert base.count("m") >= 50
+    assert run(pa, ("-e", "0.03", "-l", "10000", "--bam-window-kb", "1")) == base
+    assert run(pa, ("-e", "0.03", "-l", "10000")) == base
+    assert run(pa, ("--bam-window-kb", "1")) == run(pb, ())          # the estimator loop walks the same stream

@@ -69,3 +69,20 @@ def test_packer_refuses_what_it_cannot_represent(hip_lib):
     bad.last[2] = bad.first[2] - 1 if bad.first[2] > 1 else 0    # last < first
     c = bad.as_c()
     assert L.floria_hip_pack_bytes(C.byref(c)) == 0
+    # read_off sizes the buffers through read_off[R] but the packing loop walks [read_off[r], read_off[r+1]) — an offset array that is not
+    # strictly ascending from 0 must be refused before anything is written (it used to read and write out of bounds)
+    for mangle in ("nonmonotone", "overshoot", "nonzero_start", "empty_read"):
+        bad = Pileup(p.read_off.copy(), p.snp.copy(), p.allele.copy(), p.qual.copy(), p.first.copy(), p.last.copy())
+        if mangle == "nonmonotone":
+            bad.read_off[1], bad.read_off[2] = bad.read_off[2] + 5, bad.read_off[1]
+        elif mangle == "overshoot":
+            bad.read_off[3] = bad.read_off[-1] + 1000
+        elif mangle == "nonzero_start":
+            bad.read_off[0] = 1
+        else:
+            bad.read_off[4] = bad.read_off[5]
+        c = bad.as_c()
+        assert L.floria_hip_pack_bytes(C.byref(c)) == 0, mangle
+        buf = (C.c_char * (1 << 20))()
+        out = capi.CPileupPacked()
+        assert L.floria_hip_pack_pileup(C.byref(c), buf, len(buf), C.byref(out)) == capi.FLORIA_E_INVALID, mangle
