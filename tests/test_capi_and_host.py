@@ -98,3 +98,17 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
         cls = pairs[name]
         assert int(size) == C.sizeof(cls), f"{name}: header {size} B, ctypes {C.sizeof(cls)} B"
         assert [int(o) for o in offs] == [getattr(cls, f).offset for f, _ in cls._fields_], name
+
+
+def test_rust_binding_sketch_covers_every_declared_symbol():
+    # INTEGRATION.md §2 is what a Rust maintainer would paste into ffi.rs; no rustc exists here, so the least it must do is name every entry point the header
+    # declares (a host following a sketch without floria_hip_hap_graph_free leaks every graph) and nothing the header does not have.
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "floria_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(floria_hip_[a-z0-9_]+)\s*\(", code))
+    sketch = open(os.path.join(root, "INTEGRATION.md")).read()
+    bound = set(re.findall(r"\bpub fn (floria_hip_[a-z0-9_]+)\s*\(", sketch))
+    assert declared - bound == set(), f"not bound in INTEGRATION.md: {sorted(declared - bound)}"
+    assert bound - declared == set(), f"bound but not declared: {sorted(bound - declared)}"
