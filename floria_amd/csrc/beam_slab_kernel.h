@@ -106,12 +106,12 @@ __device__ __forceinline__ float binom_screen_f32(uint32_t nn, uint32_t kk, floa
 // Level 2 of the pruning test (see phase B): exact p-values from the host-libm table, the f32 exp2 / log2 screen on their exact differences and, where that
 // is not decisive, the f64 exp / log of the reference formula.  Out of line: reached in a few percent of the steps, and its f64 temporaries would otherwise count
 // against the steady-state register budget.  The whole wave calls it (wave-uniform branch); TPS = compile-time ploidy of the DPP-segmented instances, else 0.
-struct Prune2 { double min_margin; uint32_t pass, fallback; };
+struct Prune2 { double min_margin; uint32_t pass, fallback, exact; };
 template <int TPS>
 __device__ __attribute__((noinline)) Prune2 prune_level2(uint32_t nn, uint32_t kk, bool act, int seg0, uint32_t p, const double* tab, uint32_t nmax, double eps, double div_factor,
                                                          double cutoff, double min_margin) {
     constexpr uint32_t PSC = TPS == 2 ? 2 : 4;
-    Prune2 r; r.fallback = 0;
+    Prune2 r; r.fallback = 0; r.exact = 0;
     double pv = 0.0;
     if (act) {
         if (nn <= nmax) pv = tab[nn * (nn + 1) / 2 + kk];
@@ -130,6 +130,7 @@ __device__ __attribute__((noinline)) Prune2 prune_level2(uint32_t nn, uint32_t k
     const bool far_enough = ascr >= PRUNE_SCREEN && ascr - PRUNE_SCREEN >= min_margin;     // false for NaN
     bool pass = dscr > 0.0;
     if (__any(act && !far_enough)) {
+        r.exact = 1;
         const double lse = mx + log_sum_exp_terms(dx, seg0, p);
         const double am = fabs((pv - lse) - cutoff);
         if (act) min_margin = am < min_margin ? am : min_margin;
@@ -233,6 +234,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t S = 64 / psl;
     const float rcp_p = __builtin_amdgcn_rcpf((float)p);
     const float eps_f = (float)g.eps, rdiv_f = (float)(1.0 / g.div_factor), cutoff_f = (float)g.cutoff;
+    const double margin_alone = fabs(0.0 - g.cutoff);      // |(p_k - lse) - ln 0.01| with p_k == lse
     const uint32_t my_sl = lane / psl, my_k = lane % psl;
     const bool lane_pair = my_sl < S && my_k < p;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -245,7 +247,7 @@ void beam_slab_kernel(BeamArgs g) {
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
     unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0, c_copy_pos = 0, c_ncopy = 0, c_add_items = 0, c_zero_items = 0, c_nlead = 0, c_trunc = 0;
-    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0;
+    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0;
 #endif
 
     for (;;) {
@@ -630,7 +632,15 @@ void beam_slab_kernel(BeamArgs g) {
                     else for (uint32_t j = 0; j < p; ++j) sumf += __shfl(ef, seg0 + (int)j);
                     const float dsf = (dxf - __builtin_amdgcn_logf(sumf) * 0.693147180559945309f) - cutoff_f;
                     const float asf = fabsf(dsf) - tol1;
-                    const bool far1 = asf > 0.f && (double)asf >= min_margin;     // false for NaN
+                    // The commonest decision of all — ONE partition explains the read and every other is more than 40 log units behind — is known exactly
+                    // without any of this: the other terms of the log-sum-exp are below e^-40, their sum is below 2^-53 for p <= 16, so the f64 sum of the
+                    // reference formula is exactly 1.0, lse == max, the winner's margin is |0 - ln 0.01| to the bit and the losers' margins exceed 35.  (Left
+                    // to the screen, that winner would tie with the job's running minimum margin - the same constant - and force the exact path every step.)
+                    const uint64_t closeb = __ballot(act && dxf > -(40.f + tol1));
+                    const uint32_t segbits = (uint32_t)(closeb >> seg0) & ((1u << psl) - 1u);
+                    const bool alone = act && (segbits & (segbits - 1u)) == 0u;           // (an active lane's segment has at least its maximum in the set)
+                    if (alone) min_margin = margin_alone < min_margin ? margin_alone : min_margin;
+                    const bool far1 = alone || (asf > 0.f && (double)asf >= min_margin);     // false for NaN
                     pass = dsf > 0.f;
 #ifdef FLORIA_NO_BINOM_SCREEN
                     if (true) {
@@ -642,6 +652,9 @@ void beam_slab_kernel(BeamArgs g) {
 #endif
                         const Prune2 r2 = prune_level2<DPPSEG ? TP : 0>(nn, kk, act, seg0, p, g.binom_tab, g.binom_nmax, g.eps, g.div_factor, g.cutoff, min_margin);
                         pass = r2.pass != 0; min_margin = r2.min_margin; n_fallback += r2.fallback;
+#ifdef FLORIA_PROF
+                        c_exact += r2.exact;
+#endif
                     }
                 }
                 pass = pass && act;
@@ -1008,7 +1021,7 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
                      atomicAdd(&g.prof[32], c_copy_pos); atomicAdd(&g.prof[33], c_ncopy); atomicAdd(&g.prof[34], c_add_items); atomicAdd(&g.prof[35], c_zero_items); atomicAdd(&g.prof[36], c_nlead); atomicAdd(&g.prof[37], c_trunc);
                      atomicAdd(&g.prof[38], c_nl); atomicAdd(&g.prof[39], c_id8); atomicAdd(&g.prof[40], c_id16); atomicAdd(&g.prof[41], c_id32); atomicAdd(&g.prof[42], c_w128); atomicAdd(&g.prof[43], c_w256);
-                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general);
+                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact);
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     n_fallback = wave_sum_u32(n_fallback);

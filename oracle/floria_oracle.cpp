@@ -352,8 +352,8 @@ inline SD distance_read_haplo_epsilon_empty(const Pile& P, uint32_t r, const Hap
     return d;
 }
 // the two f64 values the reference goes on with
-inline double sd_same(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) == 1 ? d.same_f : qm_to_f64(d.same, 0, eps); }
-inline double sd_diff(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) == 1 ? d.diff_f : qm_to_f64(d.diff, d.m, eps); }
+inline double sd_same(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) >= 1 ? d.same_f : qm_to_f64(d.same, 0, eps); }
+inline double sd_diff(const SD& d, double eps) { return g_arith_mode.load(std::memory_order_relaxed) >= 1 ? d.diff_f : qm_to_f64(d.diff, d.m, eps); }
 
 // Frag.positions (file_reader.rs:729-733) = seq_dict.keys().collect::<FxHashSet<_>>(): seq_dict is an FxHashMap filled in ascending
 // order by the CIGAR walk (:661-727, growing as it goes); `collect` reserves room for all keys at once and inserts them in the map's
@@ -362,6 +362,10 @@ inline double sd_diff(const SD& d, double eps) { return g_arith_mode.load(std::m
 // does not say which cell came from which alignment, so such reads are emulated as one alignment.)
 inline std::vector<uint32_t> build_cell_order(const floria_pileup* p) {
     std::vector<uint32_t> ord(p->read_off[p->n_reads]);
+    if (g_arith_mode.load() == 2) {                            // mode 2: running sums with every container iterated in ASCENDING key order (tests/test_py_restatement.py)
+        for (uint32_t c = 0; c < (uint32_t)ord.size(); ++c) ord[c] = c;
+        return ord;
+    }
     for (uint32_t r = 0; r < p->n_reads; ++r) {
         const uint32_t b = p->read_off[r], e = p->read_off[r + 1];
         FxSet seq_dict, positions;
@@ -523,7 +527,7 @@ void beam_search_phasing(const Pile& P, const std::vector<uint32_t>& all_reads, 
                     nn.diff_q = pn.diff_q + sd[j].diff;
                     nn.diff_m = pn.diff_m + sd[j].m;
                     nn.score  = qm_to_f64(nn.diff_q, nn.diff_m, epsilon);               // new_node_score = -(-mec) :105
-                    if (g_arith_mode.load(std::memory_order_relaxed) == 1) {
+                    if (g_arith_mode.load(std::memory_order_relaxed) >= 1) {
                         nn.errv[j] = pn.errv[j] + sd[j].diff_f;                         // node.error_vec[i].1 + diff :198
                         double mec = 0.0;                                               // new_error_vec.iter().map(|x| x.1).sum() :202
                         for (int k = 0; k < ploidy; ++k) mec += nn.errv[k];
@@ -588,6 +592,12 @@ std::vector<QM> mec_stats_of_block(const HapBlock& hb, uint64_t one, const Pile*
             FxSet pos_map;
             for (uint32_t r : (*part_order)[pi])
                 for (uint32_t cc = P->beg(r); cc < P->end(r); ++cc) pos_map.insert(P->p->snp[P->order[cc]]);
+            if (g_arith_mode.load(std::memory_order_relaxed) == 2) {       // ascending positions
+                std::vector<uint32_t> ps;
+                pos_map.for_each([&](uint64_t pos) { ps.push_back((uint32_t)pos); });
+                std::sort(ps.begin(), ps.end());
+                for (uint32_t pos : ps) { const Site* site = hap.find(pos); if (site) site_terms(*site, true); }
+            } else
             pos_map.for_each([&](uint64_t pos) { const Site* site = hap.find((uint32_t)pos); if (site) site_terms(*site, true); });
         }
         v.push_back(s);
@@ -658,7 +668,7 @@ std::vector<std::vector<uint32_t>> opt_iterate(const Pile& P, const std::vector<
 // ---- optimize_clustering (local_clustering.rs:71-130) -------------------------------------------------------
 double mec_score_of(const std::vector<QM>& v, double epsilon) {
     double s = 0.0;                                   // binom_vec.iter().map(|x| x.1).sum()
-    const bool running = g_arith_mode.load(std::memory_order_relaxed) == 1;
+    const bool running = g_arith_mode.load(std::memory_order_relaxed) >= 1;
     for (const QM& x : v) s += running ? x.errors_f : qm_to_f64(x.errors, x.m, epsilon);
     return s * -1.0;
 }
@@ -669,7 +679,7 @@ std::vector<std::vector<uint32_t>> optimize_clustering(const Pile& P, std::vecto
     if (iters_done) *iters_done = 0;
     if (!not_empty) return partition;                                                    // :82-85
     HapBlock prev_hap_block = hap_block_from_partition(P, partition, true);
-    const bool running = g_arith_mode.load(std::memory_order_relaxed) == 1 && P.order;
+    const bool running = g_arith_mode.load(std::memory_order_relaxed) >= 1 && P.order;
     auto stats_of = [&](const HapBlock& hb, const std::vector<std::vector<uint32_t>>& part, const std::vector<FxSet>* sh) {
         if (!running) return mec_stats_of_block(hb, 1u << 24);
         const auto ord = set_orders(part, sh);
@@ -729,7 +739,7 @@ void get_local_hap_blocks(const Pile& P, uint32_t start, uint32_t end, const flo
         auto optimized_part = optimize_clustering(P, std::move(part), epsilon, NUM_ITER_OPTIMIZE, nullptr, emu ? &shadow : nullptr);  // :153-154
         if (emu) shadow_vector.push_back(shadow);
         HapBlock np = hap_block_from_partition(P, optimized_part, false);                   // :156 (_no_phred)
-        const bool running = g_arith_mode.load(std::memory_order_relaxed) == 1 && P.order;
+        const bool running = g_arith_mode.load(std::memory_order_relaxed) >= 1 && P.order;
         const auto final_orders = running ? set_orders(optimized_part, emu ? &shadow : nullptr) : std::vector<std::vector<uint32_t>>();
         for (const QM& s : (running ? mec_stats_of_block(np, 1, &P, &final_orders, epsilon) : mec_stats_of_block(np, 1))) {   // :158-162
             double good = (double)s.bases;
@@ -998,7 +1008,7 @@ int floria_oracle_phase_blocks(const floria_pileup* pileup, const uint32_t* blk_
     if (!params || params->max_ploidy < 1 || params->max_ploidy > FLORIA_MAX_PLOIDY || params->beam < 1) { g_err = "bad params"; return FLORIA_E_INVALID; }
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<BlockOut> outs(n_blocks);
     std::atomic<uint32_t> next{0};
     auto worker = [&]() {
@@ -1052,7 +1062,7 @@ int floria_oracle_one_ploidy(const floria_pileup* pileup, uint32_t start, uint32
     if (rc) return rc;
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<uint32_t> reads = find_reads_in_interval(P, start, end);
     *n_out = (uint32_t)reads.size();
     if (reads.empty()) return 0;
@@ -1080,7 +1090,7 @@ int floria_oracle_optimize_given(const floria_pileup* pileup, const uint32_t* re
     if (rc) return rc;
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<uint32_t>> part(ploidy);
     for (uint32_t i = 0; i < n; ++i) { if (part_in[i] >= ploidy) return -1; part[part_in[i]].push_back(read_id[i]); }
     auto opt = optimize_clustering(P, part, epsilon, NUM_ITER_OPTIMIZE, iters);
@@ -1104,7 +1114,7 @@ int floria_oracle_reassign_ordered(const floria_pileup* pileup, const uint64_t* 
     if (rc) return rc;
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<uint32_t>> parts(n_groups);
     std::vector<std::pair<uint32_t, uint32_t>> ranges(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) {
@@ -1160,7 +1170,7 @@ int floria_oracle_hap_graph(const floria_pileup* pileup, const uint32_t* blk_sta
     if (rc) return rc;
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<NodeO>> cols;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         if (best_ploidy[b] == 0) continue;                               // None -> no column (graph_processing.rs:355-361)
@@ -1221,7 +1231,7 @@ int floria_oracle_haploset_stats(const floria_pileup* pileup, const uint32_t* re
     if (rc) return rc;
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<uint32_t> fs(reads, reads + n);
     Hap hap_map = set_to_seq_dict(P, fs, false);                                   // :606
     double errors = 0., total_support = 0., sum_support = 0.;
@@ -1262,7 +1272,7 @@ int floria_oracle_hapq(const floria_pileup* pileup, const uint64_t* grp_off, con
     if (rc) return rc;
     Pile P{pileup};
     std::vector<uint32_t> cell_order_;
-    if (g_arith_mode.load() == 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
+    if (g_arith_mode.load() >= 1) { cell_order_ = build_cell_order(pileup); P.order = cell_order_.data(); }
     std::vector<std::vector<uint32_t>> parts(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) parts[g].assign(grp_read + grp_off[g], grp_read + grp_off[g + 1]);
     double weight = 0., error = 0.;

@@ -170,7 +170,9 @@ def set_order_mode(mode):
 def set_arith_mode(mode):
     """0 = canonical arithmetic (every weighted sum an exact (Q24, #epsilon) pair turned into f64 once: what the HIP path computes),
     1 = the reference's running f64 sums, terms added in the iteration order of its (emulated) hash containers.  Identical for
-    dyadic epsilon; mode 1 is for counting how often they part elsewhere (scripts/arith_sensitivity.py)."""
+    dyadic epsilon; mode 1 is for counting how often they part elsewhere (scripts/arith_sensitivity.py).
+    2 = the same running f64 sums with every container iterated in ASCENDING key order (positions, alleles, counter_ids) instead of the emulated
+    hash orders: the mode the independent Python restatement (oracle/py_restatement.py) is compared with at a non-dyadic epsilon."""
     lib().floria_oracle_set_arith_mode(C.c_int(mode))
 
 
