@@ -247,7 +247,7 @@ void beam_slab_kernel(BeamArgs g) {
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
     unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0, c_copy_pos = 0, c_ncopy = 0, c_add_items = 0, c_zero_items = 0, c_nlead = 0, c_trunc = 0;
-    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0;
+    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0, c_boring = 0;
 #endif
 
     for (;;) {
@@ -589,6 +589,8 @@ void beam_slab_kernel(BeamArgs g) {
             uint64_t evalid = 0;
             H.len = 0;
             bool bulk = false;                       // this step took the no-duplicate / no-eviction path
+            bool fastm = false;                      // ... and the slab structure carries over unchanged (see phase M)
+            uint32_t nlead_f = 0;
             uint64_t b_h1 = 0, b_h2 = 0;             // its children's state hashes (lane = (state, partition) pair)
             uint32_t src_map = 0;                    // lane r = child lane of entry r
             uint64_t* const E_s = ST_q(cur ^ 1); uint64_t* const E_h1 = ST_h1(cur ^ 1); uint64_t* const E_h2 = ST_h2(cur ^ 1);
@@ -693,6 +695,35 @@ void beam_slab_kernel(BeamArgs g) {
                         if (!__any(coll)) {
                             bulk = true;
                             b_h1 = ch1; b_h2 = ch2;
+#ifndef FLORIA_NO_FASTM
+                            // STRUCTURE-PRESERVING step (6 steps in 10): every state has exactly one passing child and no child inherits a slab that another
+                            // child extends.  Then every new version goes in place, every slab keeps its id, the live list and the states' slab tables carry
+                            // over (a child's table is its parent's), and phase M needs no reference counts, no leader election by atomics, no free list and
+                            // no live-list rebuild.  Tested here, on the child lanes: a byte per slab id (the `ref` array, dead until phase M) — every
+                            // (state, partition) lane clears its slab's byte, the passing lanes write 1 + lane into theirs, everybody reads back: a passing
+                            // lane that finds its own number leads its slab; a non-passing lane's slab is inherited by its state's child, so a number there
+                            // means "extended by someone AND inherited".  Explicit DS instructions, as for the hash-slot table above.
+                            {
+                                const uint32_t segp = (uint32_t)(passmask >> seg0) & ((1u << psl) - 1u);
+                                const bool one = segp != 0u && (segp & (segp - 1u)) == 0u;
+                                if (npass == nstates && !__any(act && !one)) {
+                                    const uint32_t sid_f = act ? (uint32_t)st_sl[a * p + my_k] : 0u;
+                                    const uint32_t t_addr = lds_base + LY.off_ref + sid_f;
+                                    const uint32_t zero = 0u, mine = 1u + lane;
+                                    if (act) asm volatile("ds_write_b8 %0, %1" :: "v"(t_addr), "v"(zero) : "memory");
+                                    if (pass) asm volatile("ds_write_b8 %0, %1" :: "v"(t_addr), "v"(mine) : "memory");
+                                    uint32_t t_val;
+                                    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t_val) : "v"(t_addr) : "memory");
+                                    if (!__any(act && !pass && t_val != 0u)) {
+                                        fastm = true;
+                                        const bool lead_f = pass && t_val == mine;
+                                        const uint64_t lm_f = __ballot(lead_f);
+                                        nlead_f = (uint32_t)__popcll(lm_f);
+                                        if (lead_f) freelist[mbcnt64(lm_f)] = (uint16_t)sid_f;
+                                    }
+                                }
+                            }
+#endif
                             uint32_t r = 0;
                             while (passmask) {
                                 const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
@@ -748,8 +779,19 @@ void beam_slab_kernel(BeamArgs g) {
             }
             uint64_t* nx_q = ST_q(cur ^ 1); uint64_t* nx_h1 = ST_h1(cur ^ 1); uint64_t* nx_h2 = ST_h2(cur ^ 1);
             uint32_t* nx_m = ST_m(cur ^ 1); uint16_t* nx_sl = ST_sl(cur ^ 1);
-            for (uint32_t x = lane; x < NS; x += 64) { ref[x] = 0; leader[x] = 0xffffffffu; }
+            uint32_t u_old = 0, ncopy = 0;
+            uint64_t cmask = 0;
+            bool lead = false;
             s_pk[lane] = n_pk;
+            if (fastm) {
+                // structure-preserving step (phase B): the next states' slab tables are their parents', everything else about the slabs stands
+                __syncthreads();
+                for (uint32_t x = lane; x < nnext * p; x += 64) {
+                    const uint32_t j = div_small(x, rcp_p), k = x - j * p;
+                    nx_sl[x] = st_sl[(s_pk[j] & 0xffff) * p + k];
+                }
+            } else {
+            for (uint32_t x = lane; x < NS; x += 64) { ref[x] = 0; leader[x] = 0xffffffffu; }
             __syncthreads();
             // inherited pointers (every partition but the modified one) and the modified slab's leader
             for (uint32_t x = lane; x < nnext * p; x += 64) {
@@ -759,18 +801,18 @@ void beam_slab_kernel(BeamArgs g) {
                 nx_sl[x] = (uint16_t)sid;
                 if (k != (pk >> 16)) ref[sid] = 1;
             }
-            const uint32_t u_old = surv ? st_sl[pj * p + kj] : 0;
+            u_old = surv ? st_sl[pj * p + kj] : 0;
             if (surv) atomicMin(&leader[u_old], lane);
             __syncthreads();
-            const bool lead = surv && leader[u_old] == lane;
+            lead = surv && leader[u_old] == lane;
             const bool inplace = lead && ref[u_old] == 0;
             const bool needcopy = lead && !inplace;
             __syncthreads();                                           // all reads of ref[] done before in-place marks
             if (inplace) { ref[u_old] = 2; newid[u_old] = (uint16_t)u_old; }
             __syncthreads();
             // free slabs = not referenced; the first ncopy of them (ascending id) go to the copy leaders
-            const uint64_t cmask = __ballot(needcopy);
-            const uint32_t ncopy = (uint32_t)__popcll(cmask);
+            cmask = __ballot(needcopy);
+            ncopy = (uint32_t)__popcll(cmask);
             if (ncopy) {
                 uint32_t found = 0;
                 for (uint32_t x0 = 0; x0 < NS && found < ncopy; x0 += 64) {
@@ -786,10 +828,11 @@ void beam_slab_kernel(BeamArgs g) {
                 if (needcopy) { const uint32_t f = freelist[mbcnt64(cmask)]; newid[u_old] = (uint16_t)f; ref[f] = 2; }
                 __syncthreads();
             }
+            }
             // survivor records
             if (surv) {
                 nx_q[lane] = n_q; nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; nx_m[lane] = n_m;
-                nx_sl[lane * p + kj] = newid[u_old];
+                if (!fastm) nx_sl[lane * p + kj] = newid[u_old];
                 if (FLORIA_NT_AUX) __builtin_nontemporal_store(pj | (kj << 16), slot_hist + beam_hist_off(i, LM, B) + lane);
                 else slot_hist[beam_hist_off(i, LM, B) + lane] = pj | (kj << 16);
             }
@@ -841,7 +884,8 @@ void beam_slab_kernel(BeamArgs g) {
             }
             __syncthreads();
             // next live list = every referenced slab (ascending id); zero their newly reached positions (hi_rel, new_hi]
-            uint32_t nl = 0;
+            uint32_t nl = fastm ? nlive : 0u;
+            if (!fastm)
             for (uint32_t x0 = 0; x0 < NS; x0 += 64) {
                 const uint32_t x = x0 + lane;
                 const bool rf = x < NS && ref[x] != 0;
@@ -853,7 +897,7 @@ void beam_slab_kernel(BeamArgs g) {
 #endif
             }
 #ifdef FLORIA_PROF
-            { c_nl += nl; const uint32_t Wd = (uint32_t)(new_hi - (int32_t)first_rel + 1); c_wsum += Wd; c_w128 += Wd > 128; c_w256 += Wd > 256; c_w512 += Wd > 512; if (!bulk) c_general++; }
+            { c_nl += nl; const uint32_t Wd = (uint32_t)(new_hi - (int32_t)first_rel + 1); c_wsum += Wd; c_w128 += Wd > 128; c_w256 += Wd > 256; c_w512 += Wd > 512; if (!bulk) c_general++; if (fastm) c_boring++; }
 #endif
             __syncthreads();
             if (new_hi > hi_rel) {
@@ -882,13 +926,13 @@ void beam_slab_kernel(BeamArgs g) {
             // add the read ONCE per distinct new version (types_structs.rs:368-373)
             {
                 const uint64_t lmask = __ballot(lead);
-                const uint32_t nlead = (uint32_t)__popcll(lmask);
+                const uint32_t nlead = fastm ? nlead_f : (uint32_t)__popcll(lmask);
 #ifdef FLORIA_PROF
                 c_nlead += nlead; c_add_items += (unsigned long long)nlead * L;
                 { const uint32_t it = nlead * L; c_it64 += it > 64; c_it128 += it > 128; c_it256 += it > 256; }
 #endif
                 // leaders' target slabs, compacted into freelist[] (reused as scratch)
-                if (lead) freelist[mbcnt64(lmask)] = newid[u_old];
+                if (lead) freelist[mbcnt64(lmask)] = newid[u_old];            // (a structure-preserving step filled the list in phase B)
                 for (uint32_t t = 0; t < ntiles; ++t) {
                     if (ntiles > 1) stage_tile(t); else __syncthreads();
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
@@ -1021,7 +1065,7 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
                      atomicAdd(&g.prof[32], c_copy_pos); atomicAdd(&g.prof[33], c_ncopy); atomicAdd(&g.prof[34], c_add_items); atomicAdd(&g.prof[35], c_zero_items); atomicAdd(&g.prof[36], c_nlead); atomicAdd(&g.prof[37], c_trunc);
                      atomicAdd(&g.prof[38], c_nl); atomicAdd(&g.prof[39], c_id8); atomicAdd(&g.prof[40], c_id16); atomicAdd(&g.prof[41], c_id32); atomicAdd(&g.prof[42], c_w128); atomicAdd(&g.prof[43], c_w256);
-                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact);
+                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact); atomicAdd(&g.prof[60], c_boring);
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     n_fallback = wave_sum_u32(n_fallback);

@@ -23,17 +23,16 @@ template <class T> __device__ __forceinline__ T sload(const T* p) {
 }
 
 // v_writelane_b32: lane l of v := x (x and l wave-uniform, in SGPRs): one instruction per dword instead of move + compare + select.
-// gfx9 allows one SGPR operand per VALU instruction, so the lane select travels in M0; M0 is a register the compiler reserves for itself (the LDS-DMA's
-// LDS base lives there) and does not track across inline asm, so the asm saves and restores it.  The LANE operand must come from scalar arithmetic, not straight from a v_readlane / v_cmp: the s_mov
-// in between is the only separation the hardware gets ("VALU writes SGPR -> lane select" wants wait states that the assembler cannot see here).
+// gfx9 allows one SGPR operand per VALU instruction, so the lane select travels in M0.  M0 is on the clobber list: hipcc re-materialises its own M0 values (the
+// LDS base of an LDS-DMA) behind the asm (checked in the ISA; round 3 saved and restored M0 by hand, two more scalar instructions per call, ten calls per beam
+// step).  The LANE operand must come from scalar arithmetic, not straight from a v_readlane / v_cmp: the s_mov in between is the only separation the hardware
+// gets ("VALU writes SGPR -> lane select" wants wait states that the assembler cannot see here).
 __device__ __forceinline__ void wlane(uint32_t& v, uint32_t x, uint32_t l) {
-    uint32_t keep;
-    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(v), "=&s"(keep) : "s"(x), "s"(l));
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0");
 }
 __device__ __forceinline__ void wlane3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t xa, uint32_t xb, uint32_t xc, uint32_t l) {
-    uint32_t keep;
-    asm("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
-        : "+v"(a), "+v"(b), "+v"(c), "=&s"(keep) : "s"(xa), "s"(xb), "s"(xc), "s"(l));
+    asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+        : "+v"(a), "+v"(b), "+v"(c) : "s"(xa), "s"(xb), "s"(xc), "s"(l) : "m0");
 }
 
 // Scores are non-negative f64 (sums of non-negative terms), so their IEEE bit patterns order like the values:
