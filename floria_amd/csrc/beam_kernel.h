@@ -52,7 +52,6 @@ struct BeamArgs {
     uint32_t* diag;                // [0] = count of binom evaluations beyond the table, [1] = free-list underflow
     unsigned long long* steps_done;
     unsigned long long* prof;      // [32] phase cycle counters (-DFLORIA_PROF)
-    uint32_t  row_lg;              // beam_lean_kernel: log2 of the positions an LDS code row holds (8 / 9 / 10)
     uint32_t  no_bulk;             // (tests) beam_slab_kernel: no bulk-insert shortcut, every child through the entry table and the duplicate test
 };
 

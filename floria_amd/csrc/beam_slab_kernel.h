@@ -592,6 +592,9 @@ void beam_slab_kernel(BeamArgs g) {
             bool fastm = false;                      // ... and the slab structure carries over unchanged (see phase M)
             uint32_t nlead_f = 0;
             uint64_t b_h1 = 0, b_h2 = 0;             // its children's state hashes (lane = (state, partition) pair)
+#ifdef FLORIA_BULK_SHFL
+            uint64_t b_q = 0; uint32_t b_m = 0;      // ... and (sum of diffs, #eps)
+#endif
             uint32_t src_map = 0;                    // lane r = child lane of entry r
             uint64_t* const E_s = ST_q(cur ^ 1); uint64_t* const E_h1 = ST_h1(cur ^ 1); uint64_t* const E_h2 = ST_h2(cur ^ 1);
             uint32_t* const E_pk = ST_m(cur ^ 1);
@@ -695,6 +698,9 @@ void beam_slab_kernel(BeamArgs g) {
                         if (!__any(coll)) {
                             bulk = true;
                             b_h1 = ch1; b_h2 = ch2;
+#ifdef FLORIA_BULK_SHFL
+                            b_q = cq; b_m = cm;
+#endif
 #ifndef FLORIA_NO_FASTM
                             // STRUCTURE-PRESERVING step (6 steps in 10): every state has exactly one passing child and no child inherits a slab that another
                             // child extends.  Then every new version goes in place, every slab keeps its id, the live list and the states' slab tables carry
@@ -769,11 +775,18 @@ void beam_slab_kernel(BeamArgs g) {
                 const int esrc = (int)__shfl(src_map, (int)eid);
                 n_h1 = shfl_u64(b_h1, esrc); n_h2 = shfl_u64(b_h2, esrc);
                 n_pk = __shfl(my_sl | (my_k << 16), esrc);
+#ifdef FLORIA_BULK_SHFL
+                n_q = shfl_u64(b_q, esrc); n_m = __shfl(b_m, esrc);
+#endif
             } else if (surv) {
                 n_h1 = E_h1[eid]; n_h2 = E_h2[eid]; n_pk = E_pk[eid];
             }
             const uint32_t pj = n_pk & 0xffff, kj = n_pk >> 16;
+#ifdef FLORIA_BULK_SHFL
+            if (surv && !bulk) {
+#else
             if (surv) {                            // the child's (sum of diffs, #eps) = its parent's + the read's distance to the extended slab
+#endif
                 const uint32_t li = s2l[st_sl[pj * p + kj]];
                 n_q = st_q[pj] + r_qd[li]; n_m = st_m[pj] + r_m[li];
             }

@@ -31,7 +31,6 @@
 #include "beam_kernel.h"
 #include "wave_util.h"
 #include "beam_slab_kernel.h"
-#include "beam_lean_kernel.h"
 #include "beam_wide_kernel.h"
 #include "optimize_kernel.h"
 #include "reassign_kernel.h"
@@ -157,7 +156,7 @@ BigCache g_big;
 // FLORIA_HIP_OPT_THREADS, FLORIA_HIP_OPT_GLOBAL, FLORIA_HIP_SPECULATE); none of them changes results.
 struct Knobs {
     uint32_t groups = 0;          // job groups (0 = auto: 2 when the batch has >= 48 x CUs non-empty blocks)
-    uint32_t beam_path = 0;       // 0 auto | 1 generic | 2 slab | 3 wide | 4 lean (where it applies, else slab)
+    uint32_t beam_path = 0;       // 0 auto | 1 generic | 2 slab | 3 wide
     uint32_t no_specialized = 0;  // runtime ploidy / beam width instead of the template instances
     uint32_t no_p1_shortcut = 0;  // run the beam kernel for ploidy 1 too
     uint32_t opt_threads = 0;     // 0 auto | 128 | 512 | 1024
@@ -167,7 +166,6 @@ struct Knobs {
     uint32_t trace = 0;           // print host-side timestamps of the S1 call to stderr
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
-    uint32_t lean_row_lg = 0;     // (tests) beam_lean_kernel: log2 of the positions an LDS code row holds (0 = auto from the batch's largest block span, else 4..10)
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
 };
 
@@ -356,9 +354,7 @@ double mec_threshold(const floria_params* prm, uint32_t p) {
 
 struct PloidyPlan {
     uint32_t p = 0, LM = 0;
-    bool shortcut = false, wide = false, slab = false, beam_spec = false, lean = false;
-    uint32_t row_lg = 9;
-    fl::LeanLds LL{};
+    bool shortcut = false, wide = false, slab = false, beam_spec = false;
     uint64_t state_bytes = 0, hist_stride = 0;
     fl::SlabLds SL{}; fl::WideLds WL{}; fl::BeamLds LY{};
     uint32_t beam_slots = 0;
@@ -428,16 +424,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             default: break;
         }
         if (q.slab) q.state_bytes = narrow ? (uint64_t)LM * p * ((uint64_t)span_max * 8 + 3ull * ((span_max + 15u) & ~15u)) : q.state_bytes + slab_code_bytes;
-        // the production kernel (beam_lean_kernel.h): position codes in LDS rows, 12-byte records in HBM; where the ploidy-specialised slab instances applied
-        q.lean = q.slab && q.beam_spec && (K.beam_path == 0 || K.beam_path == 4) && (uint64_t)LM * p * span_max * fl::LEAN_POSB < 0xf0000000ull;
-        if (q.lean) {
-            q.row_lg = K.lean_row_lg ? K.lean_row_lg : span_max <= 256 ? 8 : span_max <= 512 ? 9 : 10;        // a row holds the widest window the batch can have (blocks of more positions classify from the sums while their window exceeds it)
-            q.LL = fl::lean_lds_layout(LM, p, 1u << q.row_lg, (uint32_t)fl::lean_pf_cap((int)p));
-            q.state_bytes = (((uint64_t)LM * p * span_max * fl::LEAN_POSB) + 255) & ~255ull;
-            const uint32_t by_lds_lean = std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.LL.total + 256)));
-            q.beam_slots = ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * fl::LEAN_WAVES, by_lds_lean);
-            q.beam_slots = std::min(q.beam_slots, nj_max);
-        }
         if (!q.shortcut) {
             if (q.LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
             if (q.wide) q.beam_slots = std::min<uint32_t>(q.beam_slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.WL.total + 512))));
@@ -494,7 +480,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
     hipStream_t ls[floria_hip_ctx::MAX_LANES];
     for (uint32_t l = 0; l < n_lanes; ++l) {
         if (l == 0) { ls[0] = ctx->stream; continue; }
-        if (W > 1 && (l % W) >= 3) {        // a speculative stage's lanes of ploidy >= 4: lowest dispatch priority, so that the ploidies every
+        if (W > 1 && (l % W) >= (stages.front().size() > 1 ? 3u : 1u)) {      // ({1}{2}{3}{4..P}: the lanes of ploidy >= 5)        // a speculative stage's lanes of ploidy >= 4: lowest dispatch priority, so that the ploidies every
                                                             // block needs get the wave slots first and the stop rule is known before most of these jobs start
             if (!ctx->gstream_low[l]) {
                 int least = 0, greatest = 0;
@@ -560,7 +546,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
-                    const bool gated = stage.size() > 1 && stage[0] <= 2 && p >= 4;      // (ungated ploidy 4 / 5 measured worse: 24.3 against 22.5 ms for the 250-contig shard)
+                    const bool gated = stage.size() > 1 && ((stage[0] <= 2 && p >= 4) || (stage[0] == 4 && p >= 5));      // (ungated ploidy 4 / 5 measured worse: 24.3 against 22.5 ms for the 250-contig shard)
                     // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
                     // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
                     const uint32_t slots = gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
@@ -573,14 +559,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     if (q.wide) {
                         if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
                         else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(slots), dim3(64), q.WL.total, st, a); }
-                    } else if (q.lean) {
-                        const bool sp = a.stop_at != nullptr;      // speculative stage: the instances that can drop a job
-                        a.row_lg = q.row_lg;
-                        const uint32_t lds = q.LL.total;
-                        if (p == 2) { if (sp) hipLaunchKernelGGL((fl::beam_lean_kernel<2, 10, true>), dim3(slots), dim3(64), lds, st, a); else hipLaunchKernelGGL((fl::beam_lean_kernel<2, 10, false>), dim3(slots), dim3(64), lds, st, a); }
-                        else if (p == 3) { if (sp) hipLaunchKernelGGL((fl::beam_lean_kernel<3, 10, true>), dim3(slots), dim3(64), lds, st, a); else hipLaunchKernelGGL((fl::beam_lean_kernel<3, 10, false>), dim3(slots), dim3(64), lds, st, a); }
-                        else if (p == 4) { if (sp) hipLaunchKernelGGL((fl::beam_lean_kernel<4, 10, true>), dim3(slots), dim3(64), lds, st, a); else hipLaunchKernelGGL((fl::beam_lean_kernel<4, 10, false>), dim3(slots), dim3(64), lds, st, a); }
-                        else { if (sp) hipLaunchKernelGGL((fl::beam_lean_kernel<5, 10, true>), dim3(slots), dim3(64), lds, st, a); else hipLaunchKernelGGL((fl::beam_lean_kernel<5, 10, false>), dim3(slots), dim3(64), lds, st, a); }
                     } else if (q.slab) {
                         const bool sp = a.stop_at != nullptr;      // speculative stage: the instances that can drop a job
                         if (any_q0) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
@@ -602,7 +580,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     T.end(t);
                     HIPCHK(hipGetLastError());
                     ctx->timing.beam_launches++;
-                    if (stage.size() > 1 && stage[0] <= 2 && p == 2) {          // (the beam search of ploidy 2 opens the gate; ploidy 3 measured worse)
+                    if (stage.size() > 1 && ((stage[0] <= 2 && p == 2) || (stage[0] == 4 && p == 4))) {          // (the beam search of ploidy 2 opens the gate; ploidy 3 measured worse)
                         if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
                         HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
                     }
@@ -624,7 +602,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.fuse_select = stage.size() == 1 ? 1 : 0;
                     a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
                     a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
-                    if (stage.size() > 1) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
+                    // (a plan with ANY speculative stage publishes ready bits and stop_at from every stage: a later stage's stop rule compares with these MEC values)
+                    if (W > 1) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
                     int t = T.begin(K_OPT, st);
                     auto launch = [&](auto kern) -> hipError_t {
                         if (lds > 48 * 1024) { hipError_t e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e2 != hipSuccess) return e2; }
@@ -756,12 +735,12 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
     {   // development knobs: environment defaults, read once (floria_hip_set_option overrides them)
         Knobs& K = c->knobs;
         if (const char* v = getenv("FLORIA_HIP_GROUPS")) K.groups = (uint32_t)std::max(0, std::min<int>(atoi(v), floria_hip_ctx::MAX_GROUPS));
-        if (const char* v = getenv("FLORIA_HIP_BEAM")) K.beam_path = !strcmp(v, "generic") ? 1 : !strcmp(v, "slab") ? 2 : !strcmp(v, "wide") ? 3 : !strcmp(v, "lean") ? 4 : 0;
+        if (const char* v = getenv("FLORIA_HIP_BEAM")) K.beam_path = !strcmp(v, "generic") ? 1 : !strcmp(v, "slab") ? 2 : !strcmp(v, "wide") ? 3 : 0;
         K.no_specialized = getenv("FLORIA_HIP_NO_SPECIALIZED") != nullptr;
         K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
-        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(2, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(3, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_DIV")) K.spec_gate_div = (uint32_t)std::max(1, std::min(16, atoi(v)));
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
@@ -814,15 +793,14 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     const std::string k(key);
     Knobs& K = ctx->knobs;
     if (k == "groups") K.groups = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
-    else if (k == "beam_path") { if (value < 0 || value > 4) return fail(FLORIA_E_INVALID, "beam_path: 0 auto | 1 generic | 2 slab | 3 wide | 4 lean"); K.beam_path = (uint32_t)value; }
+    else if (k == "beam_path") { if (value < 0 || value > 3) return fail(FLORIA_E_INVALID, "beam_path: 0 auto | 1 generic | 2 slab | 3 wide"); K.beam_path = (uint32_t)value; }
     else if (k == "no_specialized") K.no_specialized = value != 0;
     else if (k == "no_p1_shortcut") K.no_p1_shortcut = value != 0;
     else if (k == "opt_threads") { if (value != 0 && value != 128 && value != 512 && value != 1024) return fail(FLORIA_E_INVALID, "opt_threads: 0 | 128 | 512 | 1024"); K.opt_threads = (uint32_t)value; }
     else if (k == "opt_global") K.opt_global = value != 0;
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
-    else if (k == "speculate") { if (value < -1 || value > 2) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2"); K.speculate = (int32_t)value; }
+    else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "no_bulk") K.no_bulk = value != 0;
-    else if (k == "lean_row_lg") { if (value != 0 && (value < 4 || value > 10)) return fail(FLORIA_E_INVALID, "lean_row_lg: 0 auto | 4..10"); K.lean_row_lg = (uint32_t)value; }
     else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "trace") K.trace = value != 0;
@@ -1542,10 +1520,15 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // contigs 24-26 ms against 38 without); with the runtime's default of 4 queues it sees 4 or fewer, and there the gated lanes serialise (3-8x).
         const uint32_t lanes_ok = ctx->hw_queues >= 5 ? 10u : (ctx->hw_queues > 1 ? ctx->hw_queues - 1 : 1u);
         if (ctx->knobs.speculate < 0 && spec) { const uint32_t w = spec == 1 ? P : std::max<uint32_t>(std::min(3u, P), P > 3 ? P - 3 : 0); if (w * G > lanes_ok) spec = 0; }
-        if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
+        if (spec == 3 && P >= 5) {          // {1}{2}{3}{4..P}: only the ploidies few blocks reach run side by side
+            for (uint32_t p = 1; p <= 3; ++p) stages.push_back({p});
+            stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p);
+        }
+        else if (spec == 1) { stages.emplace_back(); for (uint32_t p = 1; p <= P; ++p) stages.back().push_back(p); }
         else if (spec == 2) { stages.emplace_back(); for (uint32_t p = 1; p <= std::min(3u, P); ++p) stages.back().push_back(p);
                               if (P > 3) { stages.emplace_back(); for (uint32_t p = 4; p <= P; ++p) stages.back().push_back(p); } }
         else for (uint32_t p = 1; p <= P; ++p) stages.push_back({p});
+        if (spec == 3 && P < 5) { stages.clear(); for (uint32_t p = 1; p <= P; ++p) stages.push_back({p}); }
     }
     uint32_t stage_w = 1;
     for (auto& st : stages) stage_w = std::max<uint32_t>(stage_w, (uint32_t)st.size());

@@ -700,29 +700,3 @@ def test_a_block_of_65536_reads_leaves_the_narrow_sum_kernel(gpu_ctx, hip_lib, o
     ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1], [7], P=2)
     assert_block_results_equal(ro, rg, "65536 reads")
 
-
-@pytest.mark.parametrize("seed", range(16))
-def test_lean_kernel_rows_prefetch_and_fallbacks(gpu_ctx, hip_lib, oracle_mod, seed):
-    # beam_lean_kernel (biallelic, no q = 0 cells, -n 10, ploidy 2..5: the production path): position codes in LDS rows, the read-modify-write's records
-    # prefetched by LDS-DMA, slab bookkeeping ahead of the heap pushes in bulk steps.  Against the oracle in every regime it has: rows of the automatic
-    # width; rows of 16 / 64 positions (windows outgrow them: classification from the sums in HBM, for good or from some step on); every step through the
-    # general insert path (bookkeeping behind the heap, no run-ahead); few wave slots; sequential and speculative ploidy stages; and the slab kernel beside it.
-    rng = np.random.default_rng(9000 + seed)
-    ploidy = int(rng.integers(2, 6))
-    pile = random_pileup(rng, int(rng.integers(150, 700)), int(rng.integers(20, 160)), ploidy, max_len=int(rng.integers(3, 90)),
-                         alleles=2, err=float(rng.choice([0.0, 0.03, 0.1])), qlo=20 if seed % 4 == 0 else 5, qhi=20 if seed % 4 == 0 else 40,
-                         drop=float(rng.choice([0.0, 0.1, 0.4])))
-    S = int(pile.last.max())
-    s = np.array([1, max(1, S // 3)]); e = np.array([max(1, S // 2), S])
-    P = int(rng.integers(2, 6))
-    eps = [EPS, 0.04][seed % 2]
-    ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, 10), threads=4)
-    try:
-        for path, row_lg, no_bulk, spec in ((4, 0, 0, 0), (4, 0, 0, 1), (4, 4, 0, 0), (4, 6, 0, 1), (4, 0, 1, 0), (4, 6, 1, 1), (2, 0, 0, 0)):
-            gpu_ctx.set_option("beam_path", path); gpu_ctx.set_option("lean_row_lg", row_lg); gpu_ctx.set_option("no_bulk", no_bulk); gpu_ctx.set_option("speculate", spec)
-            rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, 10))
-            assert_block_results_equal(ro, rg, f"seed {seed} path {path} row_lg {row_lg} no_bulk {no_bulk} speculate {spec}")
-            assert rg.min_prune_margin == ro.min_prune_margin
-    finally:
-        for k, v in (("beam_path", 0), ("lean_row_lg", 0), ("no_bulk", 0), ("speculate", -1)):
-            gpu_ctx.set_option(k, v)

@@ -217,13 +217,13 @@ def test_ploidy_stages_do_not_change_results(gpu_ctx, hip_lib, oracle_mod, cfg, 
         bc += [i] * len(s); bs += list(s); be += list(e)
     out = {}
     try:
-        for spec, width in ((0, 1), (1, C["max_ploidy"]), (2, 3)):
+        for spec, width in ((0, 1), (1, C["max_ploidy"]), (2, 3), (3, max(1, C["max_ploidy"] - 3) if C["max_ploidy"] >= 5 else 1)):
             gpu_ctx.set_option("speculate", spec)
             out[spec] = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
             assert gpu_ctx.timing()["stage_width"] == width
     finally:
         gpu_ctx.set_option("speculate", -1)
-    for spec in (1, 2):
+    for spec in (1, 2, 3):
         assert_block_results_equal(out[0], out[spec], f"speculate {spec}")
         assert out[0].min_prune_margin == out[spec].min_prune_margin
     # the same with the chip over-subscribed (few wave slots: most jobs of the higher ploidies are dequeued after the stop rule of their
