@@ -143,7 +143,7 @@ __device__ __attribute__((noinline)) Prune2 prune_level2(uint32_t nn, uint32_t k
 struct SlabLds {
     uint32_t off_coff, off_caw, off_crp1, off_crp2;
     uint32_t off_q[2], off_h1[2], off_h2[2], off_m[2], off_sl[2];     // state arrays (SoA) x2
-    uint32_t off_live, off_s2l, off_ref, off_leader, off_newid, off_free, off_pk;
+    uint32_t off_live, off_ref, off_leader, off_newid, off_free, off_pk;
     uint32_t off_rqs, off_rqd, off_rm, off_rt1, off_rt2, off_rnp1, off_rnp2;
     uint32_t total;
 };
@@ -159,7 +159,7 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
         L.off_q[i] = take((LM + 1) * 8); L.off_h1[i] = take((LM + 1) * 8); L.off_h2[i] = take((LM + 1) * 8); L.off_m[i] = take((LM + 1) * 4);   // +1: see the entry table of phase B
         L.off_sl[i] = take(NS * 2);
     }
-    L.off_live = take(NS * 2); L.off_s2l = take(NS * 2);
+    L.off_live = take(NS * 2);
     L.off_free = take(64 * 2); L.off_pk = take(64 * 4);
     L.off_rqs = take(NS * 8); L.off_rqd = take(NS * 8); L.off_rm = take(NS * 4);
     L.off_rt1 = 0; L.off_rt2 = 0;                    // the window-exit hash terms live in HBM scratch (needed in ~1/4 of the steps)
@@ -198,7 +198,6 @@ void beam_slab_kernel(BeamArgs g) {
     uint64_t* const c_rp1 = (uint64_t*)(smem + LY.off_crp1);       // q=0 pileups only: presence-hash words of the current tile
     uint64_t* const c_rp2 = (uint64_t*)(smem + LY.off_crp2);
     uint16_t* live_id = (uint16_t*)(smem + LY.off_live);
-    uint16_t* s2l = (uint16_t*)(smem + LY.off_s2l);
     uint8_t*  ref = (uint8_t*)(smem + LY.off_ref);
     uint32_t* leader = (uint32_t*)(smem + LY.off_leader);
     uint16_t* newid = (uint16_t*)(smem + LY.off_newid);
@@ -275,7 +274,7 @@ void beam_slab_kernel(BeamArgs g) {
         auto ST_sl = [&](int w) { return (uint16_t*)(smem + (w ? LY.off_sl[1] : LY.off_sl[0])); };
         uint32_t nstates = 1, nlive = 1;
         // root: every partition points at slab 0, which is logically empty (nothing written: hi_rel = -1)
-        if (lane == 0) { ST_q(0)[0] = 0; ST_h1(0)[0] = 0; ST_h2(0)[0] = 0; ST_m(0)[0] = 0; live_id[0] = 0; s2l[0] = 0; }
+        if (lane == 0) { ST_q(0)[0] = 0; ST_h1(0)[0] = 0; ST_h2(0)[0] = 0; ST_m(0)[0] = 0; live_id[0] = 0; }
         if (lane < p) ST_sl(0)[lane] = 0;
         int32_t hi_rel = -1;
         uint32_t start_rel = 0;
@@ -488,9 +487,10 @@ void beam_slab_kernel(BeamArgs g) {
                     if (trunc) { t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs); }
                     if (Q0) { np1 = seg_sum_u64(np1, Gs); np2 = seg_sum_u64(np2, Gs); }
                     if (act && sub == 0) {
-                        r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m;
-                        if (trunc) { r_t1[li] = t1; r_t2[li] = t2; }
-                        if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
+                        const uint32_t sidr = live_id[li];
+                        r_qs[sidr] = qs; r_qd[sidr] = qd; r_m[sidr] = m;
+                        if (trunc) { r_t1[sidr] = t1; r_t2[sidr] = t2; }
+                        if (Q0) { r_np1[sidr] = np1; r_np2[sidr] = np2; }
                     }
                 }
             } else {
@@ -523,19 +523,20 @@ void beam_slab_kernel(BeamArgs g) {
                             }
                         }
                         t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs);
-                        if (act && sub == 0) { r_t1[li] = t1; r_t2[li] = t2; }
+                        if (act && sub == 0) { const uint32_t sidr = live_id[li]; r_t1[sidr] = t1; r_t2[sidr] = t2; }
                     }
                 }
                 // (2) distances from the code bytes.  Gl = 64 / nlive lanes per slab (any integer, not a power of two: 6 live slabs get 10 lanes each, not 8),
                 // every lane walks ceil(nin / Gl) cells in batches of 2 / 4 / 6 / 8 independent byte loads chosen by the exact count, sums in 32 bits inside a
                 // batch, and the lanes of a slab combine through LDS atomics (3 instructions instead of a 4-stage DPP butterfly on three values)
-                for (uint32_t x = lane; x < nlive; x += 64) { r_qs[x] = 0; r_qd[x] = 0; r_m[x] = 0; }
+                for (uint32_t x = lane; x < nlive; x += 64) { const uint32_t sidr = live_id[x]; r_qs[sidr] = 0; r_qd[sidr] = 0; r_m[sidr] = 0; }
                 const uint32_t Gl = nlive <= 64u ? div_small(64u, __builtin_amdgcn_rcpf((float)nlive)) : 1u;
                 const float rcp_gl = __builtin_amdgcn_rcpf((float)Gl);
                 for (uint32_t l0 = 0; l0 < nlive; l0 += 64u) {             // (one pass unless more than 64 slabs are live: then Gl == 1)
                     const uint32_t lsl = div_small(lane, rcp_gl), sub = lane - lsl * Gl, li = l0 + lsl;
                     const bool act = li < nlive;
-                    const uint8_t* const cbase = codes + (act ? (uint32_t)live_id[li] : 0u) * span_pad;
+                    const uint32_t sidr = act ? (uint32_t)live_id[li] : 0u;
+                    const uint8_t* const cbase = codes + sidr * span_pad;
                     uint64_t qs = 0, qd = 0;
                     uint32_t m = 0;
                     auto batch = [&](auto NC, uint32_t u0) {
@@ -571,9 +572,9 @@ void beam_slab_kernel(BeamArgs g) {
                         }
                     }
                     if (act) {
-                        atomicAdd((unsigned long long*)&r_qs[li], (unsigned long long)qs);
-                        atomicAdd((unsigned long long*)&r_qd[li], (unsigned long long)qd);
-                        atomicAdd(&r_m[li], m);
+                        atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs);
+                        atomicAdd((unsigned long long*)&r_qd[sidr], (unsigned long long)qd);
+                        atomicAdd(&r_m[sidr], m);
                     }
                 }
             }
@@ -592,9 +593,6 @@ void beam_slab_kernel(BeamArgs g) {
             bool fastm = false;                      // ... and the slab structure carries over unchanged (see phase M)
             uint32_t nlead_f = 0;
             uint64_t b_h1 = 0, b_h2 = 0;             // its children's state hashes (lane = (state, partition) pair)
-#ifdef FLORIA_BULK_SHFL
-            uint64_t b_q = 0; uint32_t b_m = 0;      // ... and (sum of diffs, #eps)
-#endif
             uint32_t src_map = 0;                    // lane r = child lane of entry r
             uint64_t* const E_s = ST_q(cur ^ 1); uint64_t* const E_h1 = ST_h1(cur ^ 1); uint64_t* const E_h2 = ST_h2(cur ^ 1);
             uint32_t* const E_pk = ST_m(cur ^ 1);
@@ -606,7 +604,7 @@ void beam_slab_kernel(BeamArgs g) {
                 uint32_t nn = 0, kk = 0;
                 float pvf = 0.f;
                 if (act) {
-                    const uint32_t li = s2l[st_sl[a * p + my_k]];
+                    const uint32_t li = st_sl[a * p + my_k];          // (the per-slab tables of phase A are indexed by slab id)
                     const uint64_t qs = r_qs[li];
                     qd = r_qd[li]; m = r_m[li];
                     if (trunc) { t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2; }
@@ -698,9 +696,6 @@ void beam_slab_kernel(BeamArgs g) {
                         if (!__any(coll)) {
                             bulk = true;
                             b_h1 = ch1; b_h2 = ch2;
-#ifdef FLORIA_BULK_SHFL
-                            b_q = cq; b_m = cm;
-#endif
 #ifndef FLORIA_NO_FASTM
                             // STRUCTURE-PRESERVING step (6 steps in 10): every state has exactly one passing child and no child inherits a slab that another
                             // child extends.  Then every new version goes in place, every slab keeps its id, the live list and the states' slab tables carry
@@ -775,19 +770,12 @@ void beam_slab_kernel(BeamArgs g) {
                 const int esrc = (int)__shfl(src_map, (int)eid);
                 n_h1 = shfl_u64(b_h1, esrc); n_h2 = shfl_u64(b_h2, esrc);
                 n_pk = __shfl(my_sl | (my_k << 16), esrc);
-#ifdef FLORIA_BULK_SHFL
-                n_q = shfl_u64(b_q, esrc); n_m = __shfl(b_m, esrc);
-#endif
             } else if (surv) {
                 n_h1 = E_h1[eid]; n_h2 = E_h2[eid]; n_pk = E_pk[eid];
             }
             const uint32_t pj = n_pk & 0xffff, kj = n_pk >> 16;
-#ifdef FLORIA_BULK_SHFL
-            if (surv && !bulk) {
-#else
             if (surv) {                            // the child's (sum of diffs, #eps) = its parent's + the read's distance to the extended slab
-#endif
-                const uint32_t li = s2l[st_sl[pj * p + kj]];
+                const uint32_t li = st_sl[pj * p + kj];
                 n_q = st_q[pj] + r_qd[li]; n_m = st_m[pj] + r_m[li];
             }
             uint64_t* nx_q = ST_q(cur ^ 1); uint64_t* nx_h1 = ST_h1(cur ^ 1); uint64_t* nx_h2 = ST_h2(cur ^ 1);
@@ -903,7 +891,7 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint32_t x = x0 + lane;
                 const bool rf = x < NS && ref[x] != 0;
                 const uint64_t fm = __ballot(rf);
-                if (rf) { const uint32_t idx = nl + mbcnt64(fm); live_id[idx] = (uint16_t)x; s2l[x] = (uint16_t)idx; }
+                if (rf) live_id[nl + mbcnt64(fm)] = (uint16_t)x;
                 nl += (uint32_t)__popcll(fm);
 #ifdef FLORIA_PROF
                 c_id8 += (unsigned)__popcll(__ballot(rf && x >= 8)); c_id16 += (unsigned)__popcll(__ballot(rf && x >= 16)); c_id32 += (unsigned)__popcll(__ballot(rf && x >= 32));
