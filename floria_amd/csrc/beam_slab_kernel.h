@@ -572,8 +572,9 @@ void beam_slab_kernel(BeamArgs g) {
                         }
                     }
                     if (act) {
-                        atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs);
-                        atomicAdd((unsigned long long*)&r_qd[sidr], (unsigned long long)qd);
+                        // (a one-tile read's sums stay below 2^32 — at most 256 cells of weight < 2^24 — so the 32-bit atomic on the low word is the whole add)
+                        if (ntiles == 1) { atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs); atomicAdd((uint32_t*)&r_qd[sidr], (uint32_t)qd); }
+                        else { atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs); atomicAdd((unsigned long long*)&r_qd[sidr], (unsigned long long)qd); }
                         atomicAdd(&r_m[sidr], m);
                     }
                 }
