@@ -69,6 +69,7 @@ __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return 
 // lines out of L2 (measured: 91.8 against 92.8 ms per resident step, twice)
 constexpr int FLORIA_NT_AUX = 2;
 constexpr int SLAB_NS_MAX = 512;
+constexpr int SLAB_PAD_IDX = 64;     // dummy position indices behind a slot's slabs (narrow-sum layout)
 constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
 constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
 template <int N> struct IC { static constexpr int value = N; };
@@ -212,13 +213,18 @@ void beam_slab_kernel(BeamArgs g) {
     constexpr bool CODES = !Q0;
     constexpr bool NARROW = CODES && A == 2;
     const uint32_t pos_bytes = NARROW ? 8 : A * 8;
-    const uint32_t slab_bytes = g.span_max * pos_bytes;                // host guarantees NS*slab_bytes < 2^32
-    // [NS slabs][span_max][A] u64 (NARROW: u32 low words), then (NARROW) [NS][span_pad][2] u8 high bytes, then [NS][span_pad] code bytes
-    char* pool = (char*)g.state_pool + (uint64_t)blockIdx.x * g.state_stride;
     const uint32_t span_pad = (g.span_max + 15u) & ~15u;
-    uint8_t* const hi_plane = (uint8_t*)(pool + (uint64_t)NS * slab_bytes);
+    // NARROW: the three planes of a slot — low words [idx][2] u32, high bytes [idx][2] u8, code bytes [idx] — share ONE position index idx = slab * span_pad +
+    // position, followed by SLAB_PAD_IDX dummy indices (one per lane) for the branch-free tails of the add phase: an add computes idx once and addresses
+    // all three with it, every access as pool (scalar) + 32-bit offset.  Otherwise: [NS slabs][span_max][A] u64, then [NS][span_pad] code bytes.
+    const uint32_t slab_bytes = (NARROW ? span_pad : g.span_max) * pos_bytes;                // host guarantees the slot's bytes < 2^32
+    char* pool = (char*)g.state_pool + (uint64_t)blockIdx.x * g.state_stride;
+    const uint32_t n_idx = NS * span_pad + (uint32_t)SLAB_PAD_IDX;
+    const uint32_t hi_base = NARROW ? n_idx * 8u : NS * slab_bytes;
+    const uint32_t code_base = NARROW ? hi_base + n_idx * 2u : hi_base;
+    uint8_t* const hi_plane = (uint8_t*)(pool + hi_base);
     const uint32_t hi_slab_bytes = NARROW ? span_pad * 2u : 0u;
-    uint8_t* const codes = hi_plane + (uint64_t)NS * hi_slab_bytes;
+    uint8_t* const codes = (uint8_t*)(pool + code_base);
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
     uint64_t* r_t1 = (uint64_t*)(slot_hist + (g.hist_stride - 4ull * NS));      // tail of the slot's traceback region (host reserves it)
     uint64_t* r_t2 = r_t1 + NS;
@@ -949,7 +955,53 @@ void beam_slab_kernel(BeamArgs g) {
                     // read-modify-writes in flight per lane, branch-free: the tail slots go to the lane's dummy words in the slot's
                     // scratch.  (A load left unconsumed on some path makes hipcc wait vmcnt(0) at the top of the next step, i.e.
                     // for the acknowledgement of these stores, before phase A can issue its loads.)
-                    if (CODES) {
+                    if constexpr (NARROW) {
+                        // lane <-> cell (chunks of 64 cells), leaders in an outer scalar loop: no index division, the cell words are read once per chunk and
+                        // leader, a leader's slab offset is a scalar, and every address is pool + a 32-bit offset built from ONE position index (layout above).
+                        // NCH chunks x NE leaders are in flight together (<= 4 read-modify-writes per lane); tail lanes go to their dummy index.
+                        const uint32_t flv = lane < nlead ? (uint32_t)freelist[lane] : 0u;          // leaders' slabs, lane e = leader e (nlead <= 63)
+                        const uint32_t nch = (tl + 63u) >> 6;
+                        auto add_round = [&](auto NCHC, auto NEC, uint32_t e0) {
+                            constexpr int NCH = decltype(NCHC)::value, NE = decltype(NEC)::value, AU = NCH * NE;
+                            uint32_t w[NCH], al[NCH], pr[NCH]; bool okc[NCH];
+#pragma unroll
+                            for (int c = 0; c < NCH; ++c) {
+                                const uint32_t cc = lane + 64u * c;
+                                okc[c] = cc < tl;
+                                const uint32_t cx = okc[c] ? cc : 0u;
+                                const uint32_t aw = c_aw[cx];
+                                pr[c] = c_snp[cx] - pos0; w[c] = aw & 0x0fffffffu; al[c] = aw >> 28;
+                            }
+                            uint32_t idx[AU]; uint2 lo[AU]; uint32_t hv[AU];
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) {
+                                const uint32_t sb = rl32(flv, e0 + (uint32_t)e) * span_pad;                 // scalar
+#pragma unroll
+                                for (int c = 0; c < NCH; ++c) idx[e * NCH + c] = okc[c] ? sb + pr[c] : NS * span_pad + lane;
+                            }
+#pragma unroll
+                            for (int u = 0; u < AU; ++u) { lo[u] = *(const uint2*)(pool + idx[u] * 8u); hv[u] = *(const uint16_t*)(pool + (hi_base + idx[u] * 2u)); }
+#pragma unroll
+                            for (int u = 0; u < AU; ++u) {
+                                const int c = u % NCH;
+                                uint64_t v0 = ((uint64_t)(hv[u] & 0xffu) << 32) | lo[u].x, v1 = ((uint64_t)(hv[u] >> 8) << 32) | lo[u].y;
+                                uint64_t nv;
+                                if (al[c]) { v1 += w[c]; nv = v1; } else { v0 += w[c]; nv = v0; }
+                                *(uint32_t*)(pool + (idx[u] * 8u + al[c] * 4u)) = (uint32_t)nv;
+                                if ((uint32_t)nv < w[c]) *(uint8_t*)(pool + (hi_base + idx[u] * 2u + al[c])) = (uint8_t)(nv >> 32);      // the low word wrapped: one time in ~256 adds
+                                const uint32_t code = (v0 | v1) ? ((v0 >= v1 ? 1u : 0u) | (v1 >= v0 ? 2u : 0u)) : 0u;
+                                *(uint8_t*)(pool + (code_base + idx[u])) = (uint8_t)code;
+                            }
+                        };
+                        uint32_t e0 = 0;
+                        if (nch <= 2) {                      // two leaders at a time
+                            for (; e0 + 2 <= nlead; e0 += 2) { if (nch == 1) add_round(IC<1>{}, IC<2>{}, e0); else add_round(IC<2>{}, IC<2>{}, e0); }
+                        }
+                        for (; e0 < nlead; ++e0) {
+                            if (nch == 1) add_round(IC<1>{}, IC<1>{}, e0); else if (nch == 2) add_round(IC<2>{}, IC<1>{}, e0);
+                            else if (nch == 3) add_round(IC<3>{}, IC<1>{}, e0); else add_round(IC<4>{}, IC<1>{}, e0);
+                        }
+                    } else if (CODES) {
                         // the position's A sums come in together (one 16-B piece for biallelic data): add the read's weight, store the changed
                         // sum, and refresh the position's code byte from the new sums
                         // up to 4 read-modify-writes in flight per lane and pass, exactly as many as the pass has (a step has ~105 of them over 64 lanes: 2)

@@ -423,7 +423,10 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             case 3: q.wide = wide_ok; q.slab = q.slab && !wide_ok; break;      // wide (where it applies)
             default: break;
         }
-        if (q.slab) q.state_bytes = narrow ? (uint64_t)LM * p * ((uint64_t)span_max * 8 + 3ull * ((span_max + 15u) & ~15u)) : q.state_bytes + slab_code_bytes;
+        // (narrow sums: low words, high bytes and code bytes over one position-index space of NS * span_pad + SLAB_PAD_IDX entries, beam_slab_kernel.h)
+        const uint64_t narrow_bytes = (((uint64_t)LM * p * ((span_max + 15u) & ~15u) + fl::SLAB_PAD_IDX) * 11ull + 255ull) & ~255ull;
+        if (q.slab && narrow && narrow_bytes >= 0xf0000000ull) q.slab = false;
+        if (q.slab) q.state_bytes = narrow ? narrow_bytes : q.state_bytes + slab_code_bytes;
         if (!q.shortcut) {
             if (q.LY.total > 160 * 1024 - 64) return fail(FLORIA_E_UNSUPPORTED, "ploidy*beam needs more LDS than a CU has");
             if (q.wide) q.beam_slots = std::min<uint32_t>(q.beam_slots, (uint32_t)ctx->n_cu * std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.WL.total + 512))));
