@@ -30,6 +30,9 @@ for k in f:
 bk=[k for k in out["kernels"] if "beam_slab" in k]
 if bk:      # calls-weighted mean over the kernel's ploidy-specialised instances (bench.py's roofline.traffic)
     out["hbm_bytes_per_launch"]=sum(out["kernels"][k]["hbm_bytes_per_launch_corrected"]*out["kernels"][k]["launches"] for k in bk)/sum(out["kernels"][k]["launches"] for k in bk)
+# per S1 call (= step): every launch of the two kernel families; the counter passes ran two S1 calls (one warm-up, one timed)
+calls=2.0
+out["hbm_bytes_per_step"]={fam: sum((2*v["fetch_kib"]+v["write_kib"])*1024 for k,v in out["kernels"].items() if key in k)/calls for fam,key in (("beam","beam_"),("optimize","optimize"))}
 json.dump(out, open(O+"/pmc_summary.json","w"), indent=1)
 print(json.dumps(out)[:600])
 PY
