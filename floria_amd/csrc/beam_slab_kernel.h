@@ -141,6 +141,15 @@ __device__ __attribute__((noinline)) Prune2 prune_level2(uint32_t nn, uint32_t k
     return r;
 }
 
+// A kernel-argument field read from the KERNARG SEGMENT at its point of use (one scalar load) instead of from the by-value copy that hipcc loads into SGPRs at
+// kernel entry and then keeps alive - or spills into VGPR lanes - across the whole step loop.  For the fields a job touches once (queue, block tables, outputs)
+// or a step touches rarely (binomial table, diagnostics): the step loop of beam_slab_kernel had 70-100 SGPR spill moves per step before (round 4).
+template <class T> __device__ __forceinline__ T kernarg_at(size_t off) {
+    return *(const __attribute__((address_space(4))) T*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+}
+#define GCOLD(f) kernarg_at<decltype(BeamArgs::f)>(offsetof(BeamArgs, f))
+#define GCOLD_BS(f) kernarg_at<decltype(BlockSet::f)>(offsetof(BeamArgs, bs) + offsetof(BlockSet, f))
+
 struct SlabLds {
     uint32_t off_coff, off_caw, off_crp1, off_crp2;
     uint32_t off_q[2], off_h1[2], off_h2[2], off_m[2], off_sl[2];     // state arrays (SoA) x2
@@ -238,7 +247,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t psl = DPPSEG ? PSC : p;
     const uint32_t S = 64 / psl;
     const float rcp_p = __builtin_amdgcn_rcpf((float)p);
-    const float eps_f = (float)g.eps, rdiv_f = (float)(1.0 / g.div_factor), cutoff_f = (float)g.cutoff;
+    const float eps_f = (float)g.eps, rdiv_f = (float)(1.0 / GCOLD(div_factor)), cutoff_f = (float)g.cutoff;
     const double margin_alone = fabs(0.0 - g.cutoff);      // |(p_k - lse) - ln 0.01| with p_k == lse
     const uint32_t my_sl = lane / psl, my_k = lane % psl;
     const bool lane_pair = my_sl < S && my_k < p;
@@ -257,19 +266,19 @@ void beam_slab_kernel(BeamArgs g) {
 
     for (;;) {
         uint32_t job = 0;
-        if (lane == 0) job = atomicAdd(g.queue_head, 1u);
+        if (lane == 0) job = atomicAdd(GCOLD(queue_head), 1u);
         job = uni(__shfl(job, 0));
-        if (job >= g.n_jobs) break;
-        const uint32_t b = uni(g.job_block[job]);
-        if (g.blk_done[b]) continue;
-        if (SPEC && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
+        if (job >= GCOLD(n_jobs)) break;
+        const uint32_t b = uni(GCOLD(job_block)[job]);
+        if (GCOLD(blk_done)[b]) continue;
+        if (SPEC && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
         bool dropped = false;
         min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
-        const ContigDev cd = g.bs.contigs[g.bs.blk_contig[b]];
-        const uint64_t roff = g.bs.blk_read_off[b];
-        const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
-        const uint32_t* reads = g.bs.blk_read + roff;
-        const uint32_t pos0 = g.bs.blk_pos0[b];
+        const ContigDev cd = GCOLD_BS(contigs)[GCOLD_BS(blk_contig)[b]];
+        const uint64_t roff = GCOLD_BS(blk_read_off)[b];
+        const uint32_t n = (uint32_t)(GCOLD_BS(blk_read_off)[b + 1] - roff);
+        const uint32_t* reads = GCOLD_BS(blk_read) + roff;
+        const uint32_t pos0 = GCOLD_BS(blk_pos0)[b];
 
         int cur = 0;
         // (select between the two static carve-outs; indexing LY.off_*[cur] dynamically would put LY in scratch)
@@ -324,7 +333,7 @@ void beam_slab_kernel(BeamArgs g) {
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            if (SPEC && (i & 63u) == 63u && uni(__hip_atomic_load(&g.stop_at[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
+            if (SPEC && (i & 63u) == 63u && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
             const uint32_t cbeg = cm_cur.cbeg, L = cm_cur.L;
             const uint32_t first_rel = sm_cur.first - pos0;
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
@@ -660,7 +669,7 @@ void beam_slab_kernel(BeamArgs g) {
 #ifdef FLORIA_PROF
                         c_lvl2++;
 #endif
-                        const Prune2 r2 = prune_level2<DPPSEG ? TP : 0>(nn, kk, act, seg0, p, g.binom_tab, g.binom_nmax, g.eps, g.div_factor, g.cutoff, min_margin);
+                        const Prune2 r2 = prune_level2<DPPSEG ? TP : 0>(nn, kk, act, seg0, p, GCOLD(binom_tab), GCOLD(binom_nmax), g.eps, GCOLD(div_factor), g.cutoff, min_margin);
                         pass = r2.pass != 0; min_margin = r2.min_margin; n_fallback += r2.fallback;
 #ifdef FLORIA_PROF
                         c_exact += r2.exact;
@@ -831,7 +840,7 @@ void beam_slab_kernel(BeamArgs g) {
                     if (fr && pos < 64) freelist[pos] = (uint16_t)x;
                     found += (uint32_t)__popcll(fm);
                 }
-                if (found < ncopy && lane == 0) atomicAdd(&g.diag[1], 1u);
+                if (found < ncopy && lane == 0) atomicAdd(&GCOLD(diag)[1], 1u);
                 __syncthreads();
                 if (needcopy) { const uint32_t f = freelist[mbcnt64(cmask)]; newid[u_old] = (uint16_t)f; ref[f] = 2; }
                 __syncthreads();
@@ -1092,7 +1101,7 @@ void beam_slab_kernel(BeamArgs g) {
         if (n > 0 && !(SPEC && dropped)) {
             H.hp_id = lane;
             uint32_t ecur = H.sorted_first();
-            uint8_t* out = g.part_out + roff;
+            uint8_t* out = GCOLD(part_out) + roff;
             for (int32_t i = (int32_t)n - 1; i >= 0; i -= 8) {                 // 8 traceback rows per memory round trip
                 uint32_t row[8];
 #pragma unroll
@@ -1106,8 +1115,8 @@ void beam_slab_kernel(BeamArgs g) {
                     }
                 }
             }
-            if (lane == 0) atomicAdd(g.steps_done, (unsigned long long)n);
-            { const double jm = wave_min_f64(min_margin); if (lane == 0) g.job_margin[(uint64_t)b * g.max_ploidy + p - 1] = jm; }
+            if (lane == 0) atomicAdd(GCOLD(steps_done), (unsigned long long)n);
+            { const double jm = wave_min_f64(min_margin); if (lane == 0) GCOLD(job_margin)[(uint64_t)b * GCOLD(max_ploidy) + p - 1] = jm; }
         }
         __syncthreads();
         BEAM_TICK(6);
@@ -1124,7 +1133,7 @@ void beam_slab_kernel(BeamArgs g) {
 #endif
     n_fallback = wave_sum_u32(n_fallback);
     if (lane == 0) {
-        if (n_fallback) atomicAdd(&g.diag[0], n_fallback);
+        if (n_fallback) atomicAdd(&GCOLD(diag)[0], n_fallback);
     }
 }
 
