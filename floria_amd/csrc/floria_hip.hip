@@ -1513,8 +1513,11 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // (measured on config-4 shards, resident, with the gated high ploidies and the early stop-rule flags of run_phase; ms for speculate = 0 / 1 / 2:
         //   915 blocks 37.6 / 21.3 / 24.3   1822: 40.4 / 24.8 / 27.1   2724: 44.1 / 32.2 / 32.7   3636: 48.0 / 46.5 / 36.8   4543: 50.9 / 57.7 / 44.9
         //   5455: 55.5 / 69.1 / 50.9   6348: 58.7 / 80.8 / 56.9   7249: 61.6 / - / 62.5   14503: 98.6 / 141-155 / 115.5)
-        // -> every ploidy at once up to 11 x CUs blocks, {1,2,3} then {4..P} up to 25 x CUs, one ploidy per stage above
-        if (spec < 0) spec = !(slab_path && P >= 3) ? 0 : jobs.size() <= (size_t)ctx->n_cu * 11 ? 1 : (jobs.size() <= (size_t)ctx->n_cu * 25 && P >= 4) ? 2 : 0;
+        // round 4, faster beam steps (scripts/shard_sweep.py, profiles/r04_shard_sweep.txt; ms for speculate = 0 / 1 / 2):
+        //   915: 32.7 / 19.8 / 26.6   1822: 36.1 / 23.0 / 29.5   2724: 40.6 / 31.3 / 34.9   3636: 43.2 / 36.1 / 39.5   4543: 46.6 / 42.2 / 44.2
+        //   5455: 50.4 / 50.3 / 48.9   6348: 52.7 / 56.0 / 53.3   7249: 56.8 / 63.7 / 58.1
+        // -> every ploidy at once up to 18 x CUs blocks, {1,2,3} then {4..P} up to 23 x CUs, one ploidy per stage above
+        if (spec < 0) spec = !(slab_path && P >= 3) ? 0 : jobs.size() <= (size_t)ctx->n_cu * 18 ? 1 : (jobs.size() <= (size_t)ctx->n_cu * 23 && P >= 4) ? 2 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
         // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
         // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
@@ -1714,8 +1717,8 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
     UploadPlan UP;
     uint32_t chunk_cap = floria_hip_ctx::MAX_GROUPS;
     if (!ctx->knobs.upload_chunks && ctx->knobs.speculate < 0 && prm->max_ploidy >= 3) {
-        if (n_blocks <= (uint32_t)ctx->n_cu * 11) chunk_cap = std::max<uint32_t>(1, 10 / prm->max_ploidy);
-        else if (n_blocks <= (uint32_t)ctx->n_cu * 25 && prm->max_ploidy >= 4) chunk_cap = std::max<uint32_t>(1, 10 / std::max<uint32_t>(3, prm->max_ploidy - 3));
+        if (n_blocks <= (uint32_t)ctx->n_cu * 18) chunk_cap = std::max<uint32_t>(1, 10 / prm->max_ploidy);          // (the thresholds of s1_core's stage plan)
+        else if (n_blocks <= (uint32_t)ctx->n_cu * 23 && prm->max_ploidy >= 4) chunk_cap = std::max<uint32_t>(1, 10 / std::max<uint32_t>(3, prm->max_ploidy - 3));
     }
     int rc = plan_upload(ctx, pileups, pk, n_contigs, std::min<uint32_t>(std::min(want_chunks, chunk_cap), floria_hip_ctx::MAX_GROUPS), UP);
     if (rc) return rc;
