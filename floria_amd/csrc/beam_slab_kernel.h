@@ -104,6 +104,19 @@ __device__ __forceinline__ float binom_screen_f32(uint32_t nn, uint32_t kk, floa
     return nn ? -(n * rdiv_f) * rel : 0.f;
 }
 
+// floria_hip_selftest: max over the table of |f32 screen - host-libm table entry| / n (one thread per n, all k): the error bound the level-1 screen assumes
+__global__ void binom_screen_selftest_kernel(const double* tab, uint32_t nmax, float ln_eps, float ln_1meps, float eps_f, float rdiv_f, double* out_max) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    double worst = 0.0;
+    if (n <= nmax)
+        for (uint32_t k = 0; k <= n; ++k) {
+            const double e = fabs((double)binom_screen_f32(n, k, ln_eps, ln_1meps, eps_f, rdiv_f) - tab[n * (n + 1) / 2 + k]) / (double)n;
+            worst = e > worst ? e : worst;
+        }
+    worst = wave_min_f64(-worst);                  // (max through the wave-min helper)
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out_max, (unsigned long long)__double_as_longlong(-worst));     // non-negative doubles order like their bit patterns
+}
+
 // Level 2 of the pruning test (see phase B): exact p-values from the host-libm table, the f32 exp2 / log2 screen on their exact differences and, where that
 // is not decisive, the f64 exp / log of the reference formula.  Out of line: reached in a few percent of the steps, and its f64 temporaries would otherwise count
 // against the steady-state register budget.  The whole wave calls it (wave-uniform branch); TPS = compile-time ploidy of the DPP-segmented instances, else 0.

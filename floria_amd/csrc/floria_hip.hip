@@ -1953,6 +1953,24 @@ int floria_hip_haploset_stats(floria_hip_ctx* ctx, const floria_hip_contig* cons
     return 0;
 }
 
+// ---- self-test of an assumption the kernels make about the hardware: the f32 screen of stable_binom_cdf_p_rev (beam_slab_kernel.h: binom_screen_f32, hardware rcp / log2)
+// against the host-libm table, over every (n, k) with n <= n_max.  *max_err_per_n receives max |screen - table| / n; the screen's tolerance assumes <= BINOM_SCREEN_C = 2e-5.
+int floria_hip_selftest(floria_hip_ctx* ctx, double epsilon, uint32_t n_max, double* max_err_per_n) {
+    if (!ctx || !max_err_per_n || !(epsilon > 0.0 && epsilon < 1.0) || n_max == 0 || n_max > 4096) return fail(FLORIA_E_INVALID, "selftest: context, 0 < epsilon < 1, 1 <= n_max <= 4096");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->batch_token = 0;
+    int rc = ensure_binom(ctx, epsilon, n_max); if (rc) return rc;
+    rc = ctx->misc.ensure(256); if (rc) return rc;
+    double* d_out = ctx->misc.as<double>();
+    HIPCHK(hipMemsetAsync(d_out, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(fl::binom_screen_selftest_kernel, dim3((n_max + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_binom.as<double>(), n_max,
+                       (float)std::log(epsilon), (float)std::log(1.0 - epsilon), (float)epsilon, (float)(1.0 / DIV_FACTOR), d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(max_err_per_n, d_out, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // ---- alignment::realign (alignment.rs:7-64) for the windows the host could not decide --------------------------------------------------------
 int floria_hip_realign(floria_hip_ctx* ctx, const uint8_t* read_windows, const uint8_t* ref_windows, const uint8_t* alleles, const uint8_t* n_alleles,
                        uint64_t n, uint8_t* best, int32_t* score) {

@@ -19,7 +19,7 @@ _LIB = None
 
 # every symbol include/floria_hip.h declares
 SYMBOLS = [
-    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version", "floria_hip_realign",
+    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version", "floria_hip_realign", "floria_hip_selftest",
     "floria_hip_block_ranges", "floria_hip_ranges_free", "floria_hip_contig_upload", "floria_hip_contig_free",
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",
@@ -276,6 +276,14 @@ class FloriaHip:
     def set_option(self, key, value):
         """Tuning / test knobs (floria_hip_set_option); none changes results."""
         _check(load().floria_hip_set_option(self._h, key.encode(), C.c_int64(int(value))))
+
+    def selftest(self, epsilon, n_max=1024):
+        """floria_hip_selftest: max |f32 screen - host table| / n of the binomial p-value on this device."""
+        out = C.c_double(0.0)
+        fn = load().floria_hip_selftest
+        fn.argtypes = [C.c_void_p, C.c_double, C.c_uint32, C.POINTER(C.c_double)]
+        _check(fn(self._h, C.c_double(epsilon), C.c_uint32(n_max), C.byref(out)))
+        return out.value
 
     def upload(self, pileup: Pileup):
         return ResidentContig(self, pileup)

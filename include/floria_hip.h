@@ -315,6 +315,11 @@ int  floria_hip_realign(floria_hip_ctx* ctx, const uint8_t* read_windows, const 
 
 int  floria_hip_last_timing(const floria_hip_ctx* ctx, floria_timing* out);
 
+/* Self-test of a hardware assumption: the beam kernel screens the pruning test (global_clustering.rs:98) with an f32 evaluation of stable_binom_cdf_p_rev
+ * (utils_frags.rs:211-248) built on the hardware reciprocal and log2, and falls back to the exact host-libm table wherever the screen's error bound leaves a
+ * decision open.  *max_err_per_n = max over n <= n_max, k <= n of |screen(n, k) - table(n, k)| / n on THIS device; the kernel assumes <= 2e-5. */
+int  floria_hip_selftest(floria_hip_ctx* ctx, double epsilon, uint32_t n_max, double* max_err_per_n);
+
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */
 int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
 

@@ -700,3 +700,13 @@ def test_a_block_of_65536_reads_leaves_the_narrow_sum_kernel(gpu_ctx, hip_lib, o
     ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1], [7], P=2)
     assert_block_results_equal(ro, rg, "65536 reads")
 
+
+
+def test_binomial_screen_error_bound_on_this_device(gpu_ctx):
+    # the level-1 screen of the pruning test (beam_slab_kernel.h: binom_screen_f32) evaluates stable_binom_cdf_p_rev with the hardware reciprocal and log2 and
+    # assumes |screen - table| <= 2e-5 * n (BINOM_SCREEN_C); the numpy emulation with every rcp / log2 result moved one ulp the wrong way gave <= 9.2e-6 * n.
+    # Measured on the device against the host-libm table, every (n, k) with n <= 1024, at the epsilons the tests and the bench use and at the ends of the
+    # range the tool accepts: well inside the bound.
+    for eps in (0.03125, 0.04, 0.05, 0.0437, 0.01, 0.2):
+        err = gpu_ctx.selftest(eps, 1024)
+        assert 0.0 < err <= 1.0e-5, (eps, err)
