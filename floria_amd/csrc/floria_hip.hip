@@ -661,6 +661,12 @@ const char* floria_hip_last_error(void) { return g_err.c_str(); }
 
 }  // extern "C"
 
+// HIP reads GPU_MAX_HW_QUEUES once, when the runtime initialises (lazily, at the first API call); the launch plans of s1_core want 12 hardware queues (below).
+// A host that LINKS this library gets the variable set here, when the loader runs the library's constructors — before its main() and therefore before any HIP
+// call of its own; a host that dlopen()s it after having used HIP cannot be helped (probe_hw_queues notices, and the plans degrade with a message).  Never
+// overrides a value the user has set.
+__attribute__((constructor)) static void floria_hip_set_hw_queue_default() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+
 namespace {
 // How many streams of this process really execute side by side?  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
 // said otherwise BEFORE the runtime initialised — a host that touched HIP earlier cannot fix it afterwards), and streams that share a queue run one
