@@ -274,7 +274,7 @@ void beam_slab_kernel(BeamArgs g) {
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
     unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0, c_copy_pos = 0, c_ncopy = 0, c_add_items = 0, c_zero_items = 0, c_nlead = 0, c_trunc = 0;
-    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0, c_boring = 0;
+    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0, c_boring = 0, c_heapkeep = 0;
 #endif
 
     for (;;) {
@@ -754,6 +754,26 @@ void beam_slab_kernel(BeamArgs g) {
                                 }
                             }
 #endif
+#ifndef FLORIA_NO_HEAPKEEP
+                            // ... and when, on top of that, the children's scores still satisfy the heap property slot by slot (child of state a = entry a = pushed a-th,
+                            // and s_a <= s_parent(a) for every a makes std's sift_up stop at once: global_clustering.rs:130, Appendix A), the new heap IS the children in
+                            // their parents' slots: no scalar pushes, one lane-parallel comparison.  (Mirrored states tie before and after: `<=` holds.)
+                            if (fastm) {
+                                const bool ina = lane < npass;
+                                const uint32_t segp_a = (uint32_t)(passmask >> ((lane * psl) & 63u)) & ((1u << psl) - 1u);       // the passing partition of state `lane`
+                                const uint32_t esrc_a = ina ? lane * psl + (uint32_t)__ffs((int)segp_a) - 1u : 0u;
+                                const uint64_t cs_a = shfl_u64(cs, (int)esrc_a);
+                                const uint64_t cs_par = shfl_u64(cs_a, (int)(lane ? (lane - 1u) >> 1 : 0u));
+                                if (!__any(ina && lane != 0u && cs_a > cs_par)) {
+                                    H.hp_hi = (uint32_t)(cs_a >> 32); H.hp_lo = (uint32_t)cs_a; H.hp_id = lane; H.len = npass;
+                                    src_map = esrc_a;
+                                    passmask = 0;
+#ifdef FLORIA_PROF
+                                    c_heapkeep++;
+#endif
+                                }
+                            }
+#endif
                             uint32_t r = 0;
                             while (passmask) {
                                 const uint32_t src = (uint32_t)__ffsll((unsigned long long)passmask) - 1;
@@ -1141,7 +1161,7 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
                      atomicAdd(&g.prof[32], c_copy_pos); atomicAdd(&g.prof[33], c_ncopy); atomicAdd(&g.prof[34], c_add_items); atomicAdd(&g.prof[35], c_zero_items); atomicAdd(&g.prof[36], c_nlead); atomicAdd(&g.prof[37], c_trunc);
                      atomicAdd(&g.prof[38], c_nl); atomicAdd(&g.prof[39], c_id8); atomicAdd(&g.prof[40], c_id16); atomicAdd(&g.prof[41], c_id32); atomicAdd(&g.prof[42], c_w128); atomicAdd(&g.prof[43], c_w256);
-                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact); atomicAdd(&g.prof[60], c_boring);
+                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact); atomicAdd(&g.prof[60], c_boring); atomicAdd(&g.prof[61], c_heapkeep);
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     n_fallback = wave_sum_u32(n_fallback);
