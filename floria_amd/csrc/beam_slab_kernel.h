@@ -620,6 +620,7 @@ void beam_slab_kernel(BeamArgs g) {
             H.len = 0;
             bool bulk = false;                       // this step took the no-duplicate / no-eviction path
             bool fastm = false;                      // ... and the slab structure carries over unchanged (see phase M)
+            bool heap_kept = false;                  // ... and so does the heap: state a's child sits in slot a
             uint32_t nlead_f = 0;
             uint64_t b_h1 = 0, b_h2 = 0;             // its children's state hashes (lane = (state, partition) pair)
             uint32_t src_map = 0;                    // lane r = child lane of entry r
@@ -768,6 +769,7 @@ void beam_slab_kernel(BeamArgs g) {
                                     H.hp_hi = (uint32_t)(cs_a >> 32); H.hp_lo = (uint32_t)cs_a; H.hp_id = lane; H.len = npass;
                                     src_map = esrc_a;
                                     passmask = 0;
+                                    heap_kept = true;
 #ifdef FLORIA_PROF
                                     c_heapkeep++;
 #endif
@@ -815,7 +817,10 @@ void beam_slab_kernel(BeamArgs g) {
             const uint32_t eid = surv ? H.hp_id : 0;
             uint64_t n_q = 0, n_h1 = 0, n_h2 = 0;
             uint32_t n_m = 0, n_pk = 0;
-            if (bulk) {
+            if (heap_kept) {                    // child of state `lane` in slot `lane`: its lane and partition are known without a shuffle
+                n_h1 = shfl_u64(b_h1, (int)src_map); n_h2 = shfl_u64(b_h2, (int)src_map);
+                n_pk = lane | ((src_map - lane * psl) << 16);
+            } else if (bulk) {
                 const int esrc = (int)__shfl(src_map, (int)eid);
                 n_h1 = shfl_u64(b_h1, esrc); n_h2 = shfl_u64(b_h2, esrc);
                 n_pk = __shfl(my_sl | (my_k << 16), esrc);
@@ -832,10 +837,12 @@ void beam_slab_kernel(BeamArgs g) {
             uint32_t u_old = 0, ncopy = 0;
             uint64_t cmask = 0;
             bool lead = false;
-            s_pk[lane] = n_pk;
+            if (!heap_kept) s_pk[lane] = n_pk;
             if (fastm) {
                 // structure-preserving step (phase B): the next states' slab tables are their parents', everything else about the slabs stands
                 __syncthreads();
+                if (heap_kept) { for (uint32_t x = lane; x < nnext * p; x += 64) nx_sl[x] = st_sl[x]; }          // (child a in slot a)
+                else
                 for (uint32_t x = lane; x < nnext * p; x += 64) {
                     const uint32_t j = div_small(x, rcp_p), k = x - j * p;
                     nx_sl[x] = st_sl[(s_pk[j] & 0xffff) * p + k];
