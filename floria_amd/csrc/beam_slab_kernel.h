@@ -841,7 +841,7 @@ void beam_slab_kernel(BeamArgs g) {
             if (fastm) {
                 // structure-preserving step (phase B): the next states' slab tables are their parents', everything else about the slabs stands
                 __syncthreads();
-                if (heap_kept) { for (uint32_t x = lane; x < nnext * p; x += 64) nx_sl[x] = st_sl[x]; }          // (child a in slot a)
+                if (heap_kept) { }          // child a in slot a: the states are updated IN PLACE below (their slab tables stand, the parity of the state arrays does not flip)
                 else
                 for (uint32_t x = lane; x < nnext * p; x += 64) {
                     const uint32_t j = div_small(x, rcp_p), k = x - j * p;
@@ -888,7 +888,8 @@ void beam_slab_kernel(BeamArgs g) {
             }
             // survivor records
             if (surv) {
-                nx_q[lane] = n_q; nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; nx_m[lane] = n_m;
+                if (heap_kept) { st_q[lane] = n_q; st_h1[lane] = n_h1; st_h2[lane] = n_h2; st_m[lane] = n_m; }
+                else { nx_q[lane] = n_q; nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; nx_m[lane] = n_m; }
                 if (!fastm) nx_sl[lane * p + kj] = newid[u_old];
                 if (FLORIA_NT_AUX) __builtin_nontemporal_store(pj | (kj << 16), slot_hist + beam_hist_off(i, LM, B) + lane);
                 else slot_hist[beam_hist_off(i, LM, B) + lane] = pj | (kj << 16);
@@ -1130,7 +1131,7 @@ void beam_slab_kernel(BeamArgs g) {
             if (i + 2 < n) { cm_next = rec_cm(rec_hold); sm_next = rec_sm(rec_hold); }
             __syncthreads();
             BEAM_TICK(5);
-            cur ^= 1;
+            if (!heap_kept) cur ^= 1;
             nstates = nnext;
             nlive = nl;
             hi_rel = new_hi;
