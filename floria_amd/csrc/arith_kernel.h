@@ -1,0 +1,136 @@
+// arith_kernel.h — what the opt-in "reference arithmetic" mode (floria_hip_set_option("arith", 1)) needs beyond the kernels'
+// ARITH template flag: the ORDERS in which the reference adds its running f64 sums.
+//
+// The reference walks a read's cells as `for pos in r.positions.iter()` (utils_frags.rs:35), an FxHashSet<SnpPosition> collected from
+// the keys of an FxHashMap that the CIGAR walk filled in ascending order (file_reader.rs:661-733), and a haplotype's positions as
+// `for seq_dict in hap.values()` (local_clustering.rs:227), an FxHashMap filled read by read.  Both orders are the bucket orders of
+// std's hash table (hashbrown: 16-byte control groups, triangular probing, capacity 7/8 of the buckets, growth by re-insertion in bucket
+// order) under FxHash (key * 0x517cc1b727220a95, fxhash 0.2.1).  FxTable below restates that table for keys that are inserted once and never
+// removed — all this mode needs — in memory the caller provides (global scratch or LDS, reached through flat pointers).
+// DESIGN.md §6 "Order of the f64 additions" says what this mode is and is not.
+#pragma once
+#include "common.h"
+
+namespace fl {
+
+constexpr uint32_t FX_W = 16;                        // control bytes per probe group (the SSE2 group of the x86-64 reference builds)
+constexpr uint8_t  FX_EMPTY = 0xFF;
+
+__host__ __device__ inline uint32_t fx_cap_of(uint32_t nb) { return nb == 0 ? 0 : (nb - 1 < 8 ? nb - 1 : nb / 8 * 7); }
+__host__ __device__ inline uint32_t fx_buckets_for(uint32_t cap) {
+    if (cap < 8) return cap < 4 ? 4 : 8;
+    const uint64_t adj = (uint64_t)cap * 8 / 7;
+    uint32_t b = 1;
+    while (b < adj) b <<= 1;
+    return b;
+}
+// bytes of ONE table able to hold `cap` keys: control bytes (buckets + one mirrored group), then the keys
+__host__ __device__ inline size_t fx_table_bytes(uint32_t cap) {
+    const uint32_t nb = fx_buckets_for(cap < 1 ? 1 : cap);
+    return (((size_t)nb + FX_W + 15) & ~(size_t)15) + 4ull * nb;
+}
+
+struct FxTable {
+    uint8_t*  ctrl = nullptr;        // [buckets + FX_W]
+    uint32_t* slot = nullptr;        // [buckets]
+    uint32_t  buckets = 0, items = 0, growth_left = 0;
+
+    __device__ static uint64_t hash_of(uint32_t k) { return (uint64_t)k * 0x517cc1b727220a95ull; }
+    __device__ void bind(void* mem, uint32_t nb) {
+        ctrl = (uint8_t*)mem;
+        slot = (uint32_t*)((uint8_t*)mem + (((size_t)nb + FX_W + 15) & ~(size_t)15));
+        buckets = nb; items = 0; growth_left = fx_cap_of(nb);
+        for (uint32_t i = 0; i < nb + FX_W; ++i) ctrl[i] = FX_EMPTY;
+    }
+    __device__ void set_ctrl(uint32_t i, uint8_t c) { ctrl[i] = c; ctrl[((i - FX_W) & (buckets - 1)) + FX_W] = c; }
+    // first EMPTY control byte along the probe sequence of h (there are no DELETED bytes: nothing is ever removed)
+    __device__ uint32_t find_insert_slot(uint64_t h) const {
+        const uint32_t mask = buckets - 1;
+        uint32_t pos = (uint32_t)h & mask, stride = 0;
+        for (;;) {
+            uint32_t b = FX_W;
+            for (uint32_t x = 0; x < FX_W; ++x) if (ctrl[pos + x] & 0x80) { b = x; break; }
+            if (b < FX_W) {
+                uint32_t idx = (pos + b) & mask;
+                if (!(ctrl[idx] & 0x80)) {                   // table smaller than a group: the hit was in the mirrored tail; the real slot is in group 0
+                    for (uint32_t x = 0; x < FX_W; ++x) if (ctrl[x] & 0x80) { idx = x; break; }
+                }
+                return idx;
+            }
+            stride += FX_W; pos = (pos + stride) & mask;
+        }
+    }
+    __device__ void put(uint32_t key) {
+        const uint64_t h = hash_of(key);
+        const uint32_t idx = find_insert_slot(h);
+        --growth_left;
+        set_ctrl(idx, (uint8_t)(h >> 57));
+        slot[idx] = key;
+        ++items;
+    }
+    // RawTable::resize: a new table of buckets_for(capacity), the old one's keys re-inserted in bucket order; `spare` is the other half of the pair
+    __device__ void resize(uint32_t capacity, void*& spare) {
+        FxTable n;
+        n.bind(spare, fx_buckets_for(capacity));
+        for (uint32_t i = 0; i < buckets; ++i) if (!(ctrl[i] & 0x80)) n.put(slot[i]);
+        spare = (void*)ctrl;
+        *this = n;
+    }
+    // reserve(additional) on a table without tombstones (reserve_rehash never rehashes in place then)
+    __device__ void reserve(uint32_t additional, void*& spare) {
+        if (additional <= growth_left) return;
+        const uint32_t new_items = items + additional, full = fx_cap_of(buckets);
+        resize(new_items > full + 1 ? new_items : full + 1, spare);
+    }
+    // insert of a key that is not in the table
+    __device__ void insert_new(uint32_t key, void*& spare) {
+        if (growth_left == 0) reserve(1, spare);
+        put(key);
+    }
+};
+
+// ---- Frag.positions: for every read the permutation of its cells in the set's iteration order --------------------------------------------
+// One thread per read (the emulation is sequential); three tables per thread in global scratch: the growing seq_dict (a pair) and the set.
+struct CellOrderArgs {
+    const ContigDev* contigs;
+    const uint64_t*  read_prefix;    // [n_contigs+1] reads before contig c in this launch
+    const uint64_t*  cell_prefix;    // [n_contigs]   cells before contig c: where its part of `ord` starts
+    uint32_t n_contigs;
+    uint64_t n_reads;
+    uint32_t* ord;                   // [cells] cell index (within its contig) of the x-th cell of the read in set order
+    uint8_t*  scratch;               // [threads][3 * table_bytes]
+    uint64_t  table_bytes;
+};
+__global__ void cell_order_kernel(CellOrderArgs g) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    uint8_t* mine = g.scratch + tid * 3 * g.table_bytes;
+    for (uint64_t gr = tid; gr < g.n_reads; gr += nth) {
+        uint32_t lo = 0, hi = g.n_contigs;                                    // contig of global read gr
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
+        const ContigDev cd = g.contigs[lo];
+        const uint32_t r = (uint32_t)(gr - g.read_prefix[lo]);
+        const uint32_t cb = cd.read_off[r], L = cd.read_off[r + 1] - cb;
+        // seq_dict: an empty map, keys inserted ascending, growing as it goes
+        FxTable seq;
+        void* spare = mine + g.table_bytes;
+        seq.ctrl = mine; seq.buckets = 0; seq.items = 0; seq.growth_left = 0;
+        for (uint32_t c = 0; c < L; ++c) {
+            if (seq.buckets == 0) { seq.bind(mine, fx_buckets_for(1)); }
+            seq.insert_new(cd.cell_snp[cb + c], spare);
+        }
+        // positions = seq_dict.keys().collect(): room for all keys at once, then the keys in the map's bucket order
+        FxTable set;
+        set.bind(mine + 2 * g.table_bytes, fx_buckets_for(L));
+        for (uint32_t i = 0; i < seq.buckets; ++i) if (!(seq.ctrl[i] & 0x80)) set.put(seq.slot[i]);
+        uint32_t* out = g.ord + g.cell_prefix[lo] + cb;
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < set.buckets; ++i) if (!(set.ctrl[i] & 0x80)) {
+            const uint32_t pos = set.slot[i];
+            uint32_t a = 0, b = L;                                            // the cell that holds pos (cells are strictly ascending)
+            while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (cd.cell_snp[cb + mid] <= pos) a = mid; else b = mid; }
+            out[k++] = cb + a;
+        }
+    }
+}
+
+}  // namespace fl

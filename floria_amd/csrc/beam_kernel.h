@@ -53,6 +53,9 @@ struct BeamArgs {
     unsigned long long* steps_done;
     unsigned long long* prof;      // [32] phase cycle counters (-DFLORIA_PROF)
     uint32_t  no_bulk;             // (tests) beam_slab_kernel: no bulk-insert shortcut, every child through the entry table and the duplicate test
+    // reference-arithmetic mode (beam_kernel<A, true>, arith_kernel.h): the reads' cells in the iteration order of Frag.positions
+    const uint32_t* cell_ord;      // [cells of the call's contigs] cell index within its contig
+    const uint64_t* cell_ord_off;  // [n_contigs] where a contig's part of cell_ord starts
 };
 
 __host__ __device__ inline uint32_t beam_hist_off(uint32_t i, uint32_t LM, uint32_t B) {
@@ -63,14 +66,15 @@ __host__ __device__ inline uint32_t beam_hist_off(uint32_t i, uint32_t LM, uint3
 struct BeamLds {
     uint32_t off_cpos, off_caw, off_crp1, off_crp2;
     uint32_t off_st[2];            // state arrays x2 (current / next)
-    uint32_t off_ent, off_heap, off_efree, off_bfree, off_flag, total;
+    uint32_t off_ent, off_heap, off_efree, off_bfree, off_flag, off_ev[2], total;
 };
 // per-state record
 struct __align__(8) StateRec { uint64_t q; uint64_t h1, h2; double score; uint32_t m; uint16_t buf; uint16_t src; uint8_t k; uint8_t pad[3]; uint32_t pad2; };
 // per heap entry (a child that is currently in the next heap)
-struct __align__(8) EntryRec { double score; uint64_t h1, h2; uint64_t q; uint32_t m; uint16_t parent; uint8_t k; uint8_t pad; };
+struct __align__(8) EntryRec { double score; uint64_t h1, h2; uint64_t q; uint32_t m; uint16_t parent; uint8_t k; uint8_t pad; double df; };   // df: the child's running-sum distance (ARITH)
 
-__host__ __device__ inline BeamLds beam_lds_layout(uint32_t LM) {
+// p_arith: ploidy when the kernel keeps the reference's per-partition running sums (error_vec of SearchNode, types_structs.rs:114-125), else 0
+__host__ __device__ inline BeamLds beam_lds_layout(uint32_t LM, uint32_t p_arith = 0) {
     BeamLds L;
     uint32_t o = 0;
     L.off_cpos = o; o += BEAM_TILE * 4;
@@ -84,6 +88,8 @@ __host__ __device__ inline BeamLds beam_lds_layout(uint32_t LM) {
     L.off_efree = o; o += ((LM + 1) * 2 + 7) & ~7u;
     L.off_bfree = o; o += (LM * 2 + 7) & ~7u;
     L.off_flag = o; o += (LM + 7) & ~7u;
+    L.off_ev[0] = o; o += LM * p_arith * 8;
+    L.off_ev[1] = o; o += LM * p_arith * 8;
     L.total = o;
     return L;
 }
@@ -151,12 +157,16 @@ __device__ inline uint16_t heap_sorted_first(uint16_t* hid, const StateRec* st, 
     return hid[0];
 }
 
-template <int A>
+// ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)) — the distance of a read to a partition is the running sum
+// `diff += w` / `diff += epsilon` over the read's cells in the order of its position set (utils_frags.rs:33-72), a node carries the
+// running sum of every partition and its score is their sum in partition order (global_clustering.rs:196-202).  For a dyadic epsilon
+// both forms give the same bits; for any other epsilon they differ in the last bits and, through `as usize`, sometimes by one.
+template <int A, bool ARITH = false>
 __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t p = g.ploidy, B = g.beam, LM = p * B;
-    const BeamLds LY = beam_lds_layout(LM);
+    const BeamLds LY = beam_lds_layout(LM, ARITH ? p : 0u);
     uint32_t* c_pos = (uint32_t*)(smem + LY.off_cpos);
     uint32_t* c_aw  = (uint32_t*)(smem + LY.off_caw);
     uint64_t* c_rp1 = (uint64_t*)(smem + LY.off_crp1);
@@ -194,6 +204,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
         const uint32_t* reads = g.bs.blk_read + roff;
         const uint32_t pos0 = g.bs.blk_pos0[b];
+        const uint32_t* ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;
+        double* ev = (double*)(smem + LY.off_ev[0]);       // [state][partition] running sums of the current states (ARITH)
+        double* evn = (double*)(smem + LY.off_ev[1]);
 
         // ---- initial beam: one empty state (global_clustering.rs:31-47) -------------------------------
         int cur = 0;
@@ -203,6 +216,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
         if (lane == 0) {
             st[0].q = 0; st[0].m = 0; st[0].h1 = 0; st[0].h2 = 0; st[0].score = 0.0; st[0].buf = 0; st[0].src = 0xffff; st[0].k = 0;
             s_bfree_n = 0;
+            if (ARITH) for (uint32_t k = 0; k < p; ++k) ev[k] = 0.0;
             for (uint32_t i = LM - 1; i >= 1; --i) bfree[s_bfree_n++] = (uint16_t)i;   // stack: pops 1,2,3..
         }
         int32_t hi_rel = -1;            // highest position (relative to pos0) written in any live slab
@@ -240,8 +254,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                 for (uint32_t c = lane; c < BEAM_TILE; c += 64) {
                     uint32_t cc = t * BEAM_TILE + c;
                     if (cc < L) {
-                        uint32_t pr = G(cd.cell_snp)[cbeg + cc] - pos0;
-                        uint32_t aq = G(cd.cell_aw)[cbeg + cc];
+                        const uint32_t ci = ARITH ? ord[cbeg + cc] : cbeg + cc;         // ARITH: the lanes walk the cells in the set's order
+                        uint32_t pr = G(cd.cell_snp)[ci] - pos0;
+                        uint32_t aq = G(cd.cell_aw)[ci];
                         uint32_t al = aq >> 28;
                         c_pos[c] = pr;
                         c_aw[c] = (al << 28) | (aq & 0x0fffffffu);
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                 const bool act = lane_pair && a < nstates;
                 uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
                 uint32_t m = 0;
+                double df = 0.0;                                  // ARITH: the running `diff`
                 const uint64_t* base = slot_states + (uint64_t)(act ? st[a].buf : 0) * state_stride + my_k * A;
                 // hash of the positions that leave the window: [start_rel, first_rel) ∩ [.., hi_rel]
                 {
@@ -289,6 +305,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                             const uint64_t w = aw & 0x0fffffffu;
                             if ((int32_t)pr > hi_rel) {               // nothing written there yet: empty position
                                 m += 1; np1 += c_rp1[c]; np2 += c_rp2[c];
+                                if (ARITH) df += g.eps;
                                 continue;
                             }
                             uint64_t v[A];
@@ -298,9 +315,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                             uint64_t mx = 0, va = 0;
 #pragma unroll
                             for (int x = 0; x < A; ++x) { uint64_t qx = v[x] & QMASK63; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
-                            if (mx == 0) m += 1;                                   // :45-48  diff += epsilon
+                            if (mx == 0) { m += 1; if (ARITH) df += g.eps; }       // :45-48  diff += epsilon
                             else if ((va & QMASK63) == mx) qs += w;                // :58-68  same
-                            else qd += w;                                          // :70     diff
+                            else { qd += w; if (ARITH) df += (double)w * 0x1p-24; }   // :70     diff
                             if (!(va >> 63)) { np1 += c_rp1[c]; np2 += c_rp2[c]; }
                         }
                     }
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                 // p-value (:77-91) — stable_binom_cdf_p_rev of truncated (n, k)
                 double pv = 0.0;
                 if (act) {
-                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
+                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = ARITH ? df : qm_to_f64(qd, m, g.eps);
                     const uint64_t nn = (uint64_t)(same_f + diff_f), kk = (uint64_t)diff_f;
                     if (nn <= g.binom_nmax) pv = g.binom_tab[nn * (nn + 1) / 2 + kk];
                     else { pv = binom_device(nn, kk, g.eps, g.div_factor); n_fallback++; }
@@ -340,6 +357,11 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                     cq = st[a].q + qd;
                     cm = st[a].m + m;
                     cscore = qm_to_f64(cq, cm, g.eps);
+                    if (ARITH) {                                                    // :198-202: error_vec[k].1 (+ diff for the read's partition), summed in partition order
+                        double mec = 0.0;
+                        for (uint32_t k = 0; k < p; ++k) { const double e = ev[a * p + k]; mec += (k == my_k) ? e + df : e; }
+                        cscore = mec;
+                    }
                     ch1 = (st[a].h1 - ts1) + rk1 * (tw1 + np1);
                     ch2 = (st[a].h2 - ts2) + rk2 * (tw2 + np2);
                 }
@@ -352,6 +374,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                     const uint64_t s_h1 = shfl_u64(ch1, src), s_h2 = shfl_u64(ch2, src);
                     const uint64_t s_q = shfl_u64(cq, src);
                     const uint32_t s_m = __shfl(cm, src);
+                    const double s_df = shfl_f64(df, src);
                     const uint32_t s_a = a0 + (uint32_t)src / p, s_k = (uint32_t)src % p;
                     const uint32_t hl = s_heap_len;
                     bool dup = false;                                               // :122-127
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                         if (lane == 0) {
                             uint16_t id = efree[--s_efree_n];
                             EntryRec& E = ent[id];
-                            E.score = s_score; E.h1 = s_h1; E.h2 = s_h2; E.q = s_q; E.m = s_m; E.parent = (uint16_t)s_a; E.k = (uint8_t)s_k;
+                            E.score = s_score; E.h1 = s_h1; E.h2 = s_h2; E.q = s_q; E.m = s_m; E.parent = (uint16_t)s_a; E.k = (uint8_t)s_k; E.df = s_df;
                             uint32_t len = s_heap_len;
                             heap_push(hid, ent, len, id);                           // :130
                             if (len > limit) efree[s_efree_n++] = heap_pop(hid, ent, len);   // :132-134
@@ -396,6 +419,8 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                 }
                 s_bfree_n = bn;
             }
+            if (ARITH)                                               // the survivors' running sums: the parent's, with the read's distance added to its partition
+                for (uint32_t x = lane; x < nnext * p; x += 64) { const uint32_t e = x / p, k = x - e * p; const EntryRec& E = ent[hid[e]]; const double pe = ev[(uint32_t)E.parent * p + k]; evn[x] = (k == E.k) ? pe + E.df : pe; }
             // traceback record of every survivor: (index of parent in the current array, partition)
             {
                 uint32_t* hrow = slot_hist + beam_hist_off(i, LM, B);
@@ -439,6 +464,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
             cur ^= 1;
             st = (StateRec*)(smem + (cur ? LY.off_st[1] : LY.off_st[0]));
             nx = (StateRec*)(smem + (cur ? LY.off_st[0] : LY.off_st[1]));
+            { double* t = ev; ev = evn; evn = t; }
             nstates = nnext;
             hi_rel = new_hi;
             start_rel = first_rel;

@@ -167,6 +167,7 @@ struct Knobs {
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
+    uint32_t arith = 0;           // 1 = the reference's own running f64 sums in its own orders (arith_kernel.h; slower kernels), 0 = the canonical (Q24, #eps) form
 };
 
 struct Arena;
@@ -202,6 +203,8 @@ struct floria_hip_ctx {
     uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
     // scratch pools
     DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
+    const uint32_t* cur_ord = nullptr; const uint64_t* cur_ord_off = nullptr;      // ... of the S1 call in flight
+    DevBuf arith_ord, arith_scr, arith_tab, arith_pool;      // reference-arithmetic mode: cell orders of the call's contigs, the order kernel's tables, prefix arrays, optimise scratch
     floria_timing timing{};
     // device-resident copy of the last S1 batch (floria_hip_hap_graph)
     uint64_t batch_token = 0, token_counter = 0;
@@ -423,6 +426,11 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             case 3: q.wide = wide_ok; q.slab = q.slab && !wide_ok; break;      // wide (where it applies)
             default: break;
         }
+        if (K.arith) {                                       // the reference's running sums: the generic kernel's lanes already walk a read's cells one by one
+            q.slab = false; q.wide = false; q.beam_spec = false;
+            q.LY = fl::beam_lds_layout(LM, p);
+            q.beam_slots = std::min<uint32_t>(nj_max, ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(16, std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.LY.total + 256)))));
+        }
         // (narrow sums: low words, high bytes and code bytes over one position-index space of NS * span_pad + SLAB_PAD_IDX entries, beam_slab_kernel.h)
         const uint64_t narrow_bytes = (((uint64_t)LM * p * ((span_max + 15u) & ~15u) + fl::SLAB_PAD_IDX) * 11ull + 255ull) & ~255ull;
         if (q.slab && narrow && narrow_bytes >= 0xf0000000ull) q.slab = false;
@@ -438,7 +446,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
         const size_t hist_bytes = (size_t)span_max * p * A * 8;
         const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 12 + 15) & ~(size_t)15) : 0;
-        q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global;
+        q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global && !K.arith;
         const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
         q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0) + 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
@@ -459,7 +467,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         for (uint32_t p = 1; p <= P; ++p) if (!plan[p].shortcut && (plan[p].state_bytes + plan[p].hist_stride * 4) * plan[p].beam_slots == need && plan[p].beam_slots > 1) { plan[p].beam_slots /= 2; shrunk = true; }
         if (!shrunk) break;
     }
-    uint64_t sl_state = 0, sl_hist = 0, sl_ohist = 0, sl_odist = 0, sl_ogain = 0, sl_okey = 0, sl_omoves = 0;
+    uint64_t sl_state = 0, sl_hist = 0, sl_ohist = 0, sl_odist = 0, sl_ogain = 0, sl_okey = 0, sl_omoves = 0, sl_arith = 0;
+    const uint64_t fx_bytes = (fl::fx_table_bytes(span_max + 1) + 15) & ~(uint64_t)15;       // (+1: a full table grows once more when an insert call follows, optimize_kernel.h)
+    auto sort_cap_of = [&](uint32_t p) { uint64_t c = 1; while (c < (uint64_t)p * span_max) c <<= 1; return c; };
     auto up256 = [](uint64_t x) -> uint64_t { return (x + 255) & ~(uint64_t)255; };
     for (uint32_t p = 1; p <= P; ++p) {
         const PloidyPlan& q = plan[p];
@@ -469,6 +479,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         sl_ogain = std::max(sl_ogain, up256((uint64_t)q.opt_slots * q.cand_cap * 8));
         sl_okey = std::max(sl_okey, up256((uint64_t)q.opt_slots * q.cand_cap * 4));
         sl_omoves = std::max(sl_omoves, up256((uint64_t)q.opt_slots * n_max * 4));
+        if (K.arith) sl_arith = std::max(sl_arith, up256((uint64_t)q.opt_slots * ((uint64_t)p * span_max * 8 + sort_cap_of(p) * 12 + (uint64_t)p * 2 * fx_bytes) + 64));
     }
     {   // (a pool that has to grow is freed first: hipFree synchronises the device, and nothing of this call is in flight yet)
         int rc = ctx->state_pool.ensure(sl_state * n_lanes); if (rc) return rc;
@@ -478,6 +489,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         rc = ctx->opt_gain.ensure(sl_ogain * n_lanes); if (rc) return rc;
         rc = ctx->opt_key.ensure(sl_okey * n_lanes); if (rc) return rc;
         rc = ctx->opt_moves.ensure(sl_omoves * n_lanes); if (rc) return rc;
+        if (K.arith) { rc = ctx->arith_pool.ensure(sl_arith * n_lanes); if (rc) return rc; }
     }
     // ---- streams and events: lane (g, j) runs on its own stream; lane (0, 0) is the context's main stream ---------------------
     hipStream_t ls[floria_hip_ctx::MAX_LANES];
@@ -546,6 +558,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
                     a.prof = (unsigned long long*)(d_diag + 4);
                     a.no_bulk = K.no_bulk;
+                    a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
                     auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
                         return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
                     };
@@ -559,7 +572,10 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         HIPCHK(hipStreamWaitEvent(st, ctx->ev_gate[g], 0));
                     }
                     int t = T.begin(K_BEAM, st);
-                    if (q.wide) {
+                    if (K.arith) {
+                        HIPCHK(big_lds((const void*)fl::beam_kernel<A, true>, q.LY.total));
+                        hipLaunchKernelGGL((fl::beam_kernel<A, true>), dim3(slots), dim3(64), q.LY.total, st, a);
+                    } else if (q.wide) {
                         if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
                         else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(slots), dim3(64), q.WL.total, st, a); }
                     } else if (q.slab) {
@@ -606,6 +622,15 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
                     a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
                     // (a plan with ANY speculative stage publishes ready bits and stop_at from every stage: a later stage's stop rule compares with these MEC values)
+                    if (K.arith) {
+                        a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
+                        char* base = ctx->arith_pool.as<char>() + sl_arith * lane;
+                        a.sort_cap = sort_cap_of(p); a.fx_bytes = fx_bytes;
+                        a.fk_pool = (uint64_t*)base; base += (uint64_t)slots * p * span_max * 8;
+                        a.sk_pool = (uint64_t*)base; base += (uint64_t)slots * a.sort_cap * 8;
+                        a.sp_pool = (uint32_t*)base; base += ((uint64_t)slots * a.sort_cap * 4 + 15) & ~(uint64_t)15;
+                        a.fx_pool = (uint8_t*)base;
+                    }
                     if (W > 1) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
                     int t = T.begin(K_OPT, st);
                     auto launch = [&](auto kern) -> hipError_t {
@@ -614,7 +639,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         return hipGetLastError();
                     };
                     hipError_t le;
-                    if (q.opt_spec && threads == 1024)
+                    if (K.arith) le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512, 0, true>) : launch(fl::optimize_kernel<A, false, 128, 0, true>);
+                    else if (q.opt_spec && threads == 1024)
                         le = p == 1 ? launch(fl::optimize_kernel<2, true, 1024, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 1024, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 1024, 3>)
                            : p == 4 ? launch(fl::optimize_kernel<2, true, 1024, 4>) : launch(fl::optimize_kernel<2, true, 1024, 5>);
                     else if (q.opt_spec)
@@ -771,7 +797,7 @@ void floria_hip_destroy(floria_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     sync_all(c);
-    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->d_w24, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0, &c->graph_buf, &c->graph_hist, &c->graph_sort, &c->up_tmp}) b->release();
+    for (DevBuf* b : {&c->d_binom, &c->d_hash, &c->d_w24, &c->state_pool, &c->hist_pool, &c->opt_hist, &c->opt_dist, &c->opt_gain, &c->opt_key, &c->opt_moves, &c->misc, &c->misc0, &c->graph_buf, &c->graph_hist, &c->graph_sort, &c->up_tmp, &c->arith_ord, &c->arith_scr, &c->arith_tab, &c->arith_pool}) b->release();
     for (Arena* a : c->arena_cache) { a->buf.release(); delete a; }
     c->stage.release();
     c->box.release();
@@ -810,6 +836,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "no_bulk") K.no_bulk = value != 0;
+    else if (k == "arith") { if (value < 0 || value > 1) return fail(FLORIA_E_INVALID, "arith: 0 canonical | 1 the reference's running sums"); K.arith = (uint32_t)value; }
     else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
     else if (k == "trace") K.trace = value != 0;
@@ -1372,6 +1399,7 @@ namespace {
 // (read_off / first / last of every contig are already ordered before the context's main stream).
 struct S1Contigs {
     std::vector<fl::ContigDev> cdev;
+    std::vector<uint64_t> n_cells;     // per contig (reference-arithmetic mode: the layout of the cell orders)
     uint32_t len_max = 1, nall = 2;
     bool any_q0 = false;
     const uint32_t* contig_chunk = nullptr;
@@ -1525,6 +1553,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // -> every ploidy at once up to 18 x CUs blocks, {1,2,3} then {4..P} up to 23 x CUs, one ploidy per stage above
         if (spec < 0) spec = !(slab_path && P >= 3) ? 0 : jobs.size() <= (size_t)ctx->n_cu * 18 ? 1 : (jobs.size() <= (size_t)ctx->n_cu * 23 && P >= 4) ? 2 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
+        if (ctx->knobs.arith && ctx->knobs.speculate < 0) spec = 0;
         // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
         // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
         // (floria_hip_create measured how many streams really run side by side: hw_queues; main, copy and flatten streams take up to three of them)
@@ -1584,6 +1613,34 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     bs.blk_contig = (const uint32_t*)(M0 + s_bc.off); bs.blk_start = (const uint32_t*)(M0 + s_bs.off); bs.blk_end = (const uint32_t*)(M0 + s_be.off);
     bs.blk_pos0 = (const uint32_t*)(M0 + s_p0.off); bs.blk_span = (const uint32_t*)(M0 + s_sp.off);
     bs.blk_read_off = (const uint64_t*)(M0 + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
+
+    // ---- reference-arithmetic mode: the iteration order of every read's position set (arith_kernel.h) --------------------------------
+    ctx->cur_ord = nullptr; ctx->cur_ord_off = nullptr;
+    if (ctx->knobs.arith && n_contigs) {
+        if (SC.n_cells.size() != n_contigs || chunked) return fail(FLORIA_E_INVALID, "internal: the reference-arithmetic mode needs resident contigs");
+        std::vector<uint64_t> pre(2 * (size_t)n_contigs + 2, 0);                  // reads before contig c [n+1] | cells before contig c [n]
+        uint64_t cells = 0;
+        for (uint32_t i = 0; i < n_contigs; ++i) { pre[i + 1] = pre[i] + cdev[i].n_reads; pre[n_contigs + 1 + i] = cells; cells += SC.n_cells[i]; }
+        const uint64_t R_all = pre[n_contigs];
+        rc = ctx->arith_tab.ensure(pre.size() * 8); if (rc) return rc;
+        rc = ctx->arith_ord.ensure(4 * cells + 16); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->arith_tab.p, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));                                // (`pre` is pageable and local)
+        if (R_all) {
+            const uint64_t tb = (fl::fx_table_bytes(std::max(1u, len_max)) + 15) & ~(uint64_t)15;
+            uint64_t nth = std::min<uint64_t>((R_all + 255) & ~255ull, 131072);
+            nth = std::max<uint64_t>(256, std::min<uint64_t>(nth, ((2ull << 30) / (3 * tb)) & ~255ull));
+            rc = ctx->arith_scr.ensure(3 * tb * nth); if (rc) return rc;
+            fl::CellOrderArgs oa{};
+            oa.contigs = bs.contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+            oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint32_t>(); oa.scratch = ctx->arith_scr.as<uint8_t>(); oa.table_bytes = tb;
+            int tk = T.begin(K_SEL);
+            hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
+            T.end(tk);
+            HIPCHK(hipGetLastError());
+        }
+        ctx->cur_ord = ctx->arith_ord.as<uint32_t>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+    }
 
     // ---- result buffers (allocated first: the read-id lists are copied back while the launch loop runs) -----------------
     floria_block_result* R = (floria_block_result*)calloc(1, sizeof(floria_block_result));
@@ -1683,6 +1740,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     HIPCHK(hipSetDevice(ctx->device));
     S1Contigs SC;
     SC.cdev.resize(n_contigs);
+    SC.n_cells.assign(n_contigs, 0);
     for (uint32_t b = 0; b < n_blocks; ++b) {
         const uint32_t ci = blk_contig ? blk_contig[b] : 0;
         if (ci >= n_contigs || !contigs[ci]) return fail(FLORIA_E_INVALID, "blk_contig out of range");
@@ -1690,6 +1748,7 @@ int floria_hip_phase_blocks_batch(floria_hip_ctx* ctx, const floria_hip_contig* 
     for (uint32_t i = 0; i < n_contigs; ++i) if (contigs[i]) {
         if (contigs[i]->ctx != ctx) return fail(FLORIA_E_INVALID, "contig belongs to another context");
         SC.cdev[i] = contigs[i]->dev;
+        SC.n_cells[i] = contigs[i]->n_cells;
         SC.len_max = std::max(SC.len_max, contigs[i]->max_len);
         SC.nall = std::max(SC.nall, contigs[i]->n_alleles);
         SC.any_q0 = SC.any_q0 || contigs[i]->has_q0;
@@ -1730,7 +1789,7 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
     if (rc) return rc;
     std::vector<floria_hip_contig*> handles(n_contigs, nullptr);
     auto drop = [&](int code) { sync_all(ctx); for (auto* h : handles) if (h) { h->arena = nullptr; delete h; } arena_put(UP.A); return code; };
-    bool pipelined = UP.all_pinned && UP.n_chunks > 1;
+    bool pipelined = UP.all_pinned && UP.n_chunks > 1 && !ctx->knobs.arith;       // (the cell orders of the reference-arithmetic mode need every cell on the device)
     uint64_t pinned_b = 0, staged_b = 0;
     floria_block_result* R = nullptr;
     if (pipelined) {

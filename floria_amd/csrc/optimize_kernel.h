@@ -14,6 +14,7 @@
 // counter_id (DESIGN.md "Iteration order").
 #pragma once
 #include "common.h"
+#include "arith_kernel.h"
 
 namespace fl {
 
@@ -60,6 +61,14 @@ struct OptArgs {
     uint32_t* stop_at;
     uint32_t* ready;
     double    thresholds[FLORIA_MAX_PLOIDY + 2];      // mec_threshold of every ploidy (host libm pow)
+    // reference-arithmetic mode (optimize_kernel<.., ARITH = true>, arith_kernel.h)
+    const uint32_t* cell_ord;    // the reads' cells in the iteration order of Frag.positions
+    const uint64_t* cell_ord_off;
+    uint64_t* fk_pool;           // [slots][ploidy*span_max]  first-insertion key of every (partition, position)
+    uint64_t* sk_pool;           // [slots][sort_cap]         sort keys
+    uint32_t* sp_pool;           // [slots][sort_cap]         sorted (partition, position) entries
+    uint8_t*  fx_pool;           // [slots][ploidy][2*fx_bytes] the emulated position maps
+    uint64_t  sort_cap, fx_bytes;
 };
 // fired(q): the reference's loop breaks at ploidy q (graph_processing.rs:196-251); needs mec[q-1] (q > 1) and mec[q], num_alleles[q]
 __device__ inline bool stop_rule_fires(const OptArgs& g, uint32_t b, uint32_t q) {
@@ -119,7 +128,10 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 // MEC reductions then never leave the CU; only the reads' cells stream from HBM/L2.
 // TP: ploidy as a compile-time constant (0 = read it from the arguments): the per-partition loops of the distance pass are exact
 // instead of MAX_PLOIDY predicated iterations.
-template <int A, bool HL, int OPT_THREADS, int TP = 0>
+// ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)): a read's distance is the running sum over its cells in the order
+// of its position set (utils_frags.rs:33-72), a partition's `errors` the running sum over its positions in the bucket order of its position
+// map (local_clustering.rs:226-256), which is emulated per partition (arith_kernel.h).  HL must be false.
+template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false>
 __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
     __shared__ uint64_t s_gain[OPT_SORT_LDS];
@@ -130,6 +142,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     __shared__ uint32_t s_ncand, s_nmoves, s_job, s_skip;
     __shared__ uint32_t s_chg_lo, s_chg_hi;          // positions whose code byte changed in the last batch of moves (HL)
     __shared__ double s_score;
+    __shared__ double s_errf[MAX_PLOIDY];            // ARITH: running `errors` of every partition
+    __shared__ uint32_t s_cntk[MAX_PLOIDY + 1];      // ARITH: positions in every partition's map
+    __shared__ unsigned long long s_lastcall[MAX_PLOIDY];
     uint32_t* s_moved = (uint32_t*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -174,6 +189,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         const uint8_t* pin = g.part_in + roff;
         uint8_t* part = g.part_out + roff;
         const uint32_t ncell = span * PA;
+        const uint32_t* ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;
 #ifdef FLORIA_PROF
         unsigned long long t_last = clock64();
 #endif
@@ -267,12 +283,85 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
 
+        // ARITH: the same statistics with `errors` as the reference's running sum.  The position map of partition k is filled by its reads in ascending
+        // order, every read's cells in set order; only the FIRST insertion of a position moves anything (and one more reserve(1) if an insert call
+        // follows the one that used up the table's room).  (1) first-insertion key of every (partition, position) by atomicMin, (2) sort, (3) one
+        // thread per partition replays the insertions into the emulated table, (4) and walks its buckets adding the terms of :244-253 in that order.
+        auto mec_stats_arith = [&](bool phred) {
+            uint64_t* fk = g.fk_pool + (uint64_t)blockIdx.x * g.span_max * p;
+            uint64_t* sk = g.sk_pool + (uint64_t)blockIdx.x * g.sort_cap;
+            uint32_t* sp = g.sp_pool + (uint64_t)blockIdx.x * g.sort_cap;
+            const uint32_t M = span * p;
+            for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
+            if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; s_lastcall[tid] = 0; }
+            __syncthreads();
+            for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
+                uint32_t cb = 0, len = 0, k = 0;
+                if (i < n) { read_meta(i, cb, len, k); k = part[i]; }
+                for (uint32_t c = sub; c < len; c += 16)
+                    atomicMin((unsigned long long*)&fk[k * span + (G(cd.cell_snp)[ord[cb + c]] - pos0)], ((unsigned long long)i << 24) | c);
+                if (sub == 0 && i < n) atomicMax(&s_lastcall[k], ((unsigned long long)i << 24) | (len - 1));
+            }
+            __syncthreads();
+            uint32_t M2 = 1;
+            while (M2 < M) M2 <<= 1;
+            for (uint32_t x = tid; x < M2; x += OPT_THREADS) {
+                const uint64_t f = x < M ? fk[x] : ~0ull;
+                const uint32_t k = x < M ? x / span : 0;
+                sk[x] = f == ~0ull ? 0ull : ~(((uint64_t)k << 56) | f);          // bitonic_sort puts the largest "gain" first: the smallest (partition, first insertion)
+                sp[x] = x < M ? x : 0xffffffffu;
+                if (f != ~0ull) atomicAdd(&s_cntk[k], 1u);
+            }
+            __syncthreads();
+            bitonic_sort(sk, sp, M2, tid, OPT_THREADS);
+            if ((uint32_t)tid < p) {
+                const uint32_t k = tid;
+                uint32_t start = 0;
+                for (uint32_t q = 0; q < k; ++q) start += s_cntk[q];
+                const uint32_t D = s_cntk[k];
+                uint8_t* mem = g.fx_pool + ((uint64_t)blockIdx.x * p + k) * 2 * g.fx_bytes;
+                void* spare = mem + g.fx_bytes;
+                FxTable t;
+                if (D) t.bind(mem, fx_buckets_for(1));
+                for (uint32_t d = 0; d < D; ++d) t.insert_new(sp[start + d] - k * span + pos0, spare);
+                if (D && t.growth_left == 0 && (~sk[start + D - 1] & 0x00ffffffffffffffull) != s_lastcall[k]) t.reserve(1, spare);     // a later insert call of a position already there
+                double ef = 0.0;
+                uint64_t good = 0;
+                const uint64_t one = phred ? ONE_Q24 : 1ull;
+                const double scale = phred ? 0x1p-24 : 1.0;
+                for (uint32_t i = 0; i < t.buckets; ++i) {
+                    if (t.ctrl[i] & 0x80) continue;
+                    const uint64_t* cp = hist + (uint64_t)(t.slot[i] - pos0) * PA + k * A;
+                    uint64_t q[A];
+#pragma unroll
+                    for (int al = 0; al < A; ++al) { const uint64_t v = cp[al]; q[al] = phred ? (v & QMASK44) : (v >> CNT_SHIFT); }
+#pragma unroll
+                    for (int x = 1; x < A; ++x)                                  // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
+#pragma unroll
+                        for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
+#pragma unroll
+                    for (int x = 0; x + 1 < A; ++x) ef += (double)q[x] * scale;   // :248-250 all but the last
+                    good += q[A - 1];
+                    if (q[A - 1] <= one) ef += g.eps;                             // :251-253
+                }
+                s_errf[k] = ef; s_goodq[k] = good;
+            }
+            __syncthreads();
+            if (tid == 0 && phred) {
+                double sc = 0.0;
+                for (uint32_t k = 0; k < p; ++k) sc += s_errf[k];
+                s_score = sc * -1.0;
+            }
+            __syncthreads();
+        };
+        auto stats = [&](bool phred) { if constexpr (ARITH) mec_stats_arith(phred); else mec_stats(phred); };
+
         refresh_codes(false);
         OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
         if (not_empty) {
-            mec_stats(true);
+            stats(true);
             OPT_TICK(1);     // first stats
             double prev_score = s_score;
             for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
@@ -287,6 +376,25 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 const bool incremental = HL && meta && it > 0 && span <= 65535u;
 #endif
                 const uint32_t chg_lo = incremental ? s_chg_lo : 0u, chg_hi = incremental ? s_chg_hi : 0xffffffffu;
+                if constexpr (ARITH) {              // one thread per (read, partition): the running sum cannot be split over lanes
+                    for (uint32_t pair = tid; pair < n * p; pair += OPT_THREADS) {
+                        const uint32_t i = pair / p, k = pair - i * p;
+                        uint32_t cb = 0, len = 0, kk = 0;
+                        read_meta(i, cb, len, kk);
+                        double df = 0.0;
+                        for (uint32_t c = 0; c < len; ++c) {
+                            const uint32_t ci = ord[cb + c];
+                            const uint32_t aq = G(cd.cell_aw)[ci], al = aq >> 28;
+                            const uint64_t* row = hist + (uint64_t)(G(cd.cell_snp)[ci] - pos0) * PA + k * A;
+                            uint64_t mx = 0, va = 0;
+#pragma unroll
+                            for (int x = 0; x < A; ++x) { const uint64_t q = row[x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
+                            if (mx == 0) df += g.eps;
+                            else if (va != mx) df += (double)(aq & 0x0fffffffu) * 0x1p-24;
+                        }
+                        dist[pair] = df;
+                    }
+                } else
                 for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                     uint32_t cb = 0, len = 0, kk = 0;
                     if (i < n) read_meta(i, cb, len, kk);
@@ -412,7 +520,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 };
                 apply_moves(false);
                 OPT_TICK(6);     // moves
-                mec_stats(true);
+                stats(true);
                 OPT_TICK(7);     // round stats
                 const double new_score = s_score;
                 if (new_score > prev_score) prev_score = new_score;
@@ -426,13 +534,13 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         }
         // ---- get_mec_stats_epsilon_no_phred of the optimised partition (graph_processing.rs:156-162) -----------
         OPT_TICK(8);
-        mec_stats(false);
+        stats(false);
         OPT_TICK(9);     // final stats
         if (tid == 0) {
             double mecv = 0.0, na = 0.0;
             for (uint32_t k = 0; k < p; ++k) {
                 const double good = (double)s_goodq[k];
-                const double bad = (double)s_errq[k] + (double)s_errm[k] * g.eps;
+                const double bad = ARITH ? s_errf[k] : (double)s_errq[k] + (double)s_errm[k] * g.eps;
                 mecv += bad; na += good; na += bad;
             }
             g.mec[(uint64_t)b * g.max_ploidy + p - 1] = mecv;

@@ -1,0 +1,113 @@
+"""`-m gpu`: the opt-in reference-arithmetic mode of libfloria_hip.so (`set_option("arith", 1)`) against the oracle's
+arithmetic mode 1 — the reference's running f64 sums in the iteration orders of its hash containers — bit for bit, at the
+non-dyadic epsilons where that form and the canonical one part ways; and against the canonical mode at a dyadic epsilon, where they must not.
+"""
+import numpy as np
+import pytest
+
+from floria_amd import synth
+from tests.helpers import assert_block_results_equal, random_pileup
+
+pytestmark = pytest.mark.gpu
+NON_DYADIC = (0.04, 0.05, 0.0437)
+
+
+@pytest.fixture()
+def arith(gpu_ctx, oracle_mod):
+    gpu_ctx.set_option("arith", 1)
+    oracle_mod.set_arith_mode(1)
+    yield gpu_ctx
+    oracle_mod.set_arith_mode(0)
+    gpu_ctx.set_option("arith", 0)
+
+
+def both(ctx, hip_lib, oracle_mod, pile, s, e, eps, P=5, B=10, sens=2, stop=1):
+    ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, B, sens, stop), threads=8)
+    rg = ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, B, sens, stop))
+    return ro, rg
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_random_small_pileups_in_reference_arithmetic(arith, hip_lib, oracle_mod, seed):
+    rng = np.random.default_rng(7000 + seed)
+    alleles = 4 if seed % 3 == 2 else 2
+    pile = random_pileup(rng, int(rng.integers(5, 150)), int(rng.integers(4, 60)), int(rng.integers(1, 5)), max_len=int(rng.integers(2, 40)),
+                         alleles=alleles, q0_frac=0.1 if seed % 4 == 1 else 0.0, err=float(rng.choice([0.0, 0.05, 0.2])))
+    S = int(pile.last.max())
+    nb = int(rng.integers(1, 6))
+    s = np.sort(rng.integers(1, S + 1, size=nb))
+    e = np.minimum(S, s + rng.integers(0, 25, size=nb))
+    eps = NON_DYADIC[seed % 3]
+    ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, eps, P=int(rng.integers(1, 7)), B=int(rng.integers(1, 13)),
+                  sens=int(rng.integers(1, 4)), stop=int(rng.integers(0, 2)))
+    assert_block_results_equal(ro, rg, f"seed {seed} eps {eps}")
+    assert ro.min_prune_margin == rg.min_prune_margin
+
+
+@pytest.mark.parametrize("eps", NON_DYADIC)
+@pytest.mark.parametrize("cfg,scale", ((2, 0.05), (3, 0.1), (4, 1.0)))
+def test_config_slices_in_reference_arithmetic(arith, hip_lib, oracle_mod, cfg, scale, eps):
+    """The slices scripts/arith_sensitivity.py measures (where ~60 % of the blocks differ between the two arithmetics)."""
+    C = synth.CONFIGS[cfg]
+    for idx in range(2):
+        c = synth.make_config_contig(cfg, idx, scale)
+        s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
+        ro, rg = both(arith, hip_lib, oracle_mod, c.pileup, s, e, eps, P=C["max_ploidy"], B=C["beam"])
+        assert_block_results_equal(ro, rg, f"config {cfg} contig {idx} eps {eps}")
+        assert ro.min_prune_margin == rg.min_prune_margin
+
+
+def test_the_mode_is_not_the_canonical_form_at_a_non_dyadic_epsilon(gpu_ctx, hip_lib, oracle_mod):
+    """... otherwise the tests above would prove nothing: at eps = 0.04 the two arithmetics give different results on some block of this slice,
+    on the device exactly as in the oracle."""
+    C = synth.CONFIGS[4]
+    c = synth.make_config_contig(4, 0, 1.0)
+    s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
+    par = hip_lib.make_params(0.04, C["max_ploidy"], C["beam"])
+    r0 = gpu_ctx.phase_blocks(c.pileup, s, e, par)
+    gpu_ctx.set_option("arith", 1)
+    try:
+        r1 = gpu_ctx.phase_blocks(c.pileup, s, e, par)
+    finally:
+        gpu_ctx.set_option("arith", 0)
+    assert not (np.array_equal(r0.part, r1.part) and np.array_equal(r0.mec.view(np.uint64), r1.mec.view(np.uint64)))
+
+
+@pytest.mark.parametrize("eps", (0.03125, 0.0625))
+def test_dyadic_epsilon_both_arithmetics_agree_on_the_device(gpu_ctx, hip_lib, eps):
+    C = synth.CONFIGS[4]
+    c = synth.make_config_contig(4, 1, 1.0)
+    from floria_amd import lib
+    s, e = lib.get_range_with_lengths(c.snp_pos, C["block_length"])
+    par = hip_lib.make_params(eps, C["max_ploidy"], C["beam"])
+    r0 = gpu_ctx.phase_blocks(c.pileup, s, e, par)
+    gpu_ctx.set_option("arith", 1)
+    try:
+        r1 = gpu_ctx.phase_blocks(c.pileup, s, e, par)
+    finally:
+        gpu_ctx.set_option("arith", 0)
+    assert_block_results_equal(r0, r1, f"eps {eps}")
+    assert r0.min_prune_margin == r1.min_prune_margin
+
+
+def test_batch_of_contigs_and_the_pipelined_entry_point(arith, hip_lib, oracle_mod):
+    """Several contigs in one call (the cell orders are laid out per contig) and the host-pileup entry point (which must not pipeline in this mode)."""
+    C = synth.CONFIGS[4]
+    piles, bc, bs, be = [], [], [], []
+    for idx in range(3):
+        c = synth.make_config_contig(4, idx, 1.0)
+        s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
+        piles.append(c.pileup); bc += [idx] * len(s); bs += list(s); be += list(e)
+    par = hip_lib.make_params(0.04, C["max_ploidy"], C["beam"])
+    rg = arith.phase_pileups_batch(piles, np.asarray(bc, np.uint32), np.asarray(bs, np.uint32), np.asarray(be, np.uint32), par)
+    off = 0
+    for idx in range(3):
+        n = bc.count(idx)
+        ro = oracle_mod.phase_blocks(piles[idx], np.asarray(bs[off:off + n]), np.asarray(be[off:off + n]), oracle_mod.make_params(0.04, C["max_ploidy"], C["beam"]), threads=8)
+        for b in range(n):
+            ids_o, part_o = ro.block(b)
+            ids_g, part_g = rg.block(off + b)
+            assert np.array_equal(ids_o, ids_g) and np.array_equal(part_o, part_g), f"contig {idx} block {b}"
+            assert ro.best_ploidy[b] == rg.best_ploidy[off + b]
+            assert np.array_equal(ro.mec[b].view(np.uint64), rg.mec[off + b].view(np.uint64))
+        off += n
