@@ -24,11 +24,10 @@ __host__ __device__ inline uint32_t fx_buckets_for(uint32_t cap) {
     while (b < adj) b <<= 1;
     return b;
 }
-// bytes of ONE table able to hold `cap` keys: control bytes (buckets + one mirrored group), then the keys
-__host__ __device__ inline size_t fx_table_bytes(uint32_t cap) {
-    const uint32_t nb = fx_buckets_for(cap < 1 ? 1 : cap);
-    return (((size_t)nb + FX_W + 15) & ~(size_t)15) + 4ull * nb;
-}
+// bytes of ONE table able to hold `cap` keys: control bytes (buckets + one mirrored group) and keys — two arrays, so that the control bytes,
+// which every probe reads, can sit in LDS while the keys stay in HBM scratch
+__host__ __device__ inline size_t fx_ctrl_bytes(uint32_t cap) { return ((size_t)fx_buckets_for(cap < 1 ? 1 : cap) + FX_W + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t fx_slot_bytes(uint32_t cap) { return 4ull * fx_buckets_for(cap < 1 ? 1 : cap); }
 
 struct FxTable {
     uint8_t*  ctrl = nullptr;        // [buckets + FX_W]
@@ -36,11 +35,10 @@ struct FxTable {
     uint32_t  buckets = 0, items = 0, growth_left = 0;
 
     __device__ static uint64_t hash_of(uint32_t k) { return (uint64_t)k * 0x517cc1b727220a95ull; }
-    __device__ void bind(void* mem, uint32_t nb) {
-        ctrl = (uint8_t*)mem;
-        slot = (uint32_t*)((uint8_t*)mem + (((size_t)nb + FX_W + 15) & ~(size_t)15));
+    __device__ void bind(uint8_t* c, uint32_t* s, uint32_t nb) {
+        ctrl = c; slot = s;
         buckets = nb; items = 0; growth_left = fx_cap_of(nb);
-        for (uint32_t i = 0; i < nb + FX_W; ++i) ctrl[i] = FX_EMPTY;
+        for (uint32_t i = 0; i < (nb + FX_W) / 4; ++i) ((uint32_t*)c)[i] = 0xffffffffu;        // (nb + FX_W is a multiple of 4, c 16-byte aligned)
     }
     __device__ void set_ctrl(uint32_t i, uint8_t c) { ctrl[i] = c; ctrl[((i - FX_W) & (buckets - 1)) + FX_W] = c; }
     // first EMPTY control byte along the probe sequence of h (there are no DELETED bytes: nothing is ever removed)
@@ -48,10 +46,11 @@ struct FxTable {
         const uint32_t mask = buckets - 1;
         uint32_t pos = (uint32_t)h & mask, stride = 0;
         for (;;) {
-            uint32_t b = FX_W;
-            for (uint32_t x = 0; x < FX_W; ++x) if (ctrl[pos + x] & 0x80) { b = x; break; }
-            if (b < FX_W) {
-                uint32_t idx = (pos + b) & mask;
+            uint32_t free_bits = 0;                          // the group's 16 control bytes are requested together (one memory round trip), then examined
+#pragma unroll
+            for (uint32_t x = 0; x < FX_W; ++x) free_bits |= (uint32_t)(ctrl[pos + x] >> 7) << x;
+            if (free_bits) {
+                uint32_t idx = (pos + (uint32_t)__builtin_ctz(free_bits)) & mask;
                 if (!(ctrl[idx] & 0x80)) {                   // table smaller than a group: the hit was in the mirrored tail; the real slot is in group 0
                     for (uint32_t x = 0; x < FX_W; ++x) if (ctrl[x] & 0x80) { idx = x; break; }
                 }
@@ -69,22 +68,28 @@ struct FxTable {
         ++items;
     }
     // RawTable::resize: a new table of buckets_for(capacity), the old one's keys re-inserted in bucket order; `spare` is the other half of the pair
-    __device__ void resize(uint32_t capacity, void*& spare) {
+    __device__ void resize(uint32_t capacity, uint8_t*& spare_c, uint32_t*& spare_s) {
         FxTable n;
-        n.bind(spare, fx_buckets_for(capacity));
-        for (uint32_t i = 0; i < buckets; ++i) if (!(ctrl[i] & 0x80)) n.put(slot[i]);
-        spare = (void*)ctrl;
+        n.bind(spare_c, spare_s, fx_buckets_for(capacity));
+        for (uint32_t i0 = 0; i0 < buckets; i0 += 4) {       // (buckets is a multiple of 4; the four keys are requested together)
+            bool full[4]; uint32_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { full[u] = !(ctrl[i0 + u] & 0x80); key[u] = slot[i0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (full[u]) n.put(key[u]);
+        }
+        spare_c = ctrl; spare_s = slot;
         *this = n;
     }
     // reserve(additional) on a table without tombstones (reserve_rehash never rehashes in place then)
-    __device__ void reserve(uint32_t additional, void*& spare) {
+    __device__ void reserve(uint32_t additional, uint8_t*& spare_c, uint32_t*& spare_s) {
         if (additional <= growth_left) return;
         const uint32_t new_items = items + additional, full = fx_cap_of(buckets);
-        resize(new_items > full + 1 ? new_items : full + 1, spare);
+        resize(new_items > full + 1 ? new_items : full + 1, spare_c, spare_s);
     }
     // insert of a key that is not in the table
-    __device__ void insert_new(uint32_t key, void*& spare) {
-        if (growth_left == 0) reserve(1, spare);
+    __device__ void insert_new(uint32_t key, uint8_t*& spare_c, uint32_t*& spare_s) {
+        if (growth_left == 0) reserve(1, spare_c, spare_s);
         put(key);
     }
 };
@@ -98,12 +103,13 @@ struct CellOrderArgs {
     uint32_t n_contigs;
     uint64_t n_reads;
     uint32_t* ord;                   // [cells] cell index (within its contig) of the x-th cell of the read in set order
-    uint8_t*  scratch;               // [threads][3 * table_bytes]
-    uint64_t  table_bytes;
+    uint8_t*  scratch;               // [threads][3 * (ctrl_bytes + slot_bytes)]
+    uint64_t  ctrl_bytes, slot_bytes;
 };
 __global__ void cell_order_kernel(CellOrderArgs g) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
-    uint8_t* mine = g.scratch + tid * 3 * g.table_bytes;
+    const uint64_t tb = g.ctrl_bytes + g.slot_bytes;
+    uint8_t* mine = g.scratch + tid * 3 * tb;
     for (uint64_t gr = tid; gr < g.n_reads; gr += nth) {
         uint32_t lo = 0, hi = g.n_contigs;                                    // contig of global read gr
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
@@ -112,15 +118,12 @@ __global__ void cell_order_kernel(CellOrderArgs g) {
         const uint32_t cb = cd.read_off[r], L = cd.read_off[r + 1] - cb;
         // seq_dict: an empty map, keys inserted ascending, growing as it goes
         FxTable seq;
-        void* spare = mine + g.table_bytes;
-        seq.ctrl = mine; seq.buckets = 0; seq.items = 0; seq.growth_left = 0;
-        for (uint32_t c = 0; c < L; ++c) {
-            if (seq.buckets == 0) { seq.bind(mine, fx_buckets_for(1)); }
-            seq.insert_new(cd.cell_snp[cb + c], spare);
-        }
+        uint8_t* spare_c = mine + tb; uint32_t* spare_s = (uint32_t*)(mine + tb + g.ctrl_bytes);
+        seq.bind(mine, (uint32_t*)(mine + g.ctrl_bytes), fx_buckets_for(1));          // (a read has at least one cell)
+        for (uint32_t c = 0; c < L; ++c) seq.insert_new(cd.cell_snp[cb + c], spare_c, spare_s);
         // positions = seq_dict.keys().collect(): room for all keys at once, then the keys in the map's bucket order
         FxTable set;
-        set.bind(mine + 2 * g.table_bytes, fx_buckets_for(L));
+        set.bind(mine + 2 * tb, (uint32_t*)(mine + 2 * tb + g.ctrl_bytes), fx_buckets_for(L));
         for (uint32_t i = 0; i < seq.buckets; ++i) if (!(seq.ctrl[i] & 0x80)) set.put(seq.slot[i]);
         uint32_t* out = g.ord + g.cell_prefix[lo] + cb;
         uint32_t k = 0;

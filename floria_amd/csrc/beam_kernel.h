@@ -299,26 +299,40 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                     if (ntiles > 1) stage_tile(t);
                     const uint32_t tl = min((uint32_t)BEAM_TILE, L - t * BEAM_TILE);
                     if (act) {
-                        for (uint32_t c = 0; c < tl; ++c) {
-                            const uint32_t pr = c_pos[c], aw = c_aw[c];
-                            const uint32_t al = aw >> 28;
-                            const uint64_t w = aw & 0x0fffffffu;
-                            if ((int32_t)pr > hi_rel) {               // nothing written there yet: empty position
-                                m += 1; np1 += c_rp1[c]; np2 += c_rp2[c];
-                                if (ARITH) df += g.eps;
-                                continue;
+                        // cells in batches of CU: the histogram pieces of a batch are requested together (one memory round trip per batch instead of one
+                        // per cell), then classified one by one in the cells' order (ARITH: the running sum's order)
+                        constexpr int CU = 4;
+                        for (uint32_t c0 = 0; c0 < tl; c0 += CU) {
+                            uint32_t prs[CU], aws[CU];
+                            uint64_t vs[CU][A];
+#pragma unroll
+                            for (int u = 0; u < CU; ++u) {
+                                const uint32_t c = c0 + u < tl ? c0 + u : tl - 1;
+                                prs[u] = c_pos[c]; aws[u] = c_aw[c];
+                                const bool inw = (int32_t)prs[u] <= hi_rel;
+                                const uint64_t* cp = base + (uint64_t)(inw ? prs[u] : 0u) * PA;
+#pragma unroll
+                                for (int x = 0; x < A; x += 2) { ulonglong2 vv = *(const ulonglong2*)(cp + x); vs[u][x] = vv.x; vs[u][x + 1] = vv.y; }
                             }
-                            uint64_t v[A];
-                            const uint64_t* cp = base + (uint64_t)pr * PA;
 #pragma unroll
-                            for (int x = 0; x < A; x += 2) { ulonglong2 vv = *(const ulonglong2*)(cp + x); v[x] = vv.x; v[x + 1] = vv.y; }
-                            uint64_t mx = 0, va = 0;
+                            for (int u = 0; u < CU; ++u) {
+                                if (c0 + u >= tl) break;
+                                const uint32_t c = c0 + u, pr = prs[u], aw = aws[u];
+                                const uint32_t al = aw >> 28;
+                                const uint64_t w = aw & 0x0fffffffu;
+                                if ((int32_t)pr > hi_rel) {               // nothing written there yet: empty position
+                                    m += 1; np1 += c_rp1[c]; np2 += c_rp2[c];
+                                    if (ARITH) df += g.eps;
+                                    continue;
+                                }
+                                uint64_t mx = 0, va = 0;
 #pragma unroll
-                            for (int x = 0; x < A; ++x) { uint64_t qx = v[x] & QMASK63; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
-                            if (mx == 0) { m += 1; if (ARITH) df += g.eps; }       // :45-48  diff += epsilon
-                            else if ((va & QMASK63) == mx) qs += w;                // :58-68  same
-                            else { qd += w; if (ARITH) df += (double)w * 0x1p-24; }   // :70     diff
-                            if (!(va >> 63)) { np1 += c_rp1[c]; np2 += c_rp2[c]; }
+                                for (int x = 0; x < A; ++x) { uint64_t qx = vs[u][x] & QMASK63; mx = qx > mx ? qx : mx; va = (x == (int)al) ? vs[u][x] : va; }
+                                if (mx == 0) { m += 1; if (ARITH) df += g.eps; }       // :45-48  diff += epsilon
+                                else if ((va & QMASK63) == mx) qs += w;                // :58-68  same
+                                else { qd += w; if (ARITH) df += (double)w * 0x1p-24; }   // :70     diff
+                                if (!(va >> 63)) { np1 += c_rp1[c]; np2 += c_rp2[c]; }
+                            }
                         }
                     }
                 }

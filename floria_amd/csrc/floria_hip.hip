@@ -365,6 +365,7 @@ struct PloidyPlan {
     uint32_t threads = 128, opt_slots = 0;
     size_t opt_lds = 0;
     bool hl = false, opt_spec = false;
+    uint32_t fx_lds_off = 0;      // reference-arithmetic mode: where the emulated position maps sit in the workgroup's LDS (0 = in HBM scratch)
 };
 
 template <int A>
@@ -391,6 +392,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
 
     // ---- plan every ploidy once: kernel choice, grid, scratch per slot -------------------------------------------------------
     std::vector<PloidyPlan> plan(P + 1);
+    const uint64_t fx_ctrl = fl::fx_ctrl_bytes(span_max + 1), fx_slot = fl::fx_slot_bytes(span_max + 1), fx_bytes = fx_ctrl + fx_slot;       // (+1: a full table grows once more when an insert call follows, optimize_kernel.h)
     const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
     for (uint32_t p = 1; p <= P; ++p) {
         PloidyPlan& q = plan[p];
@@ -446,13 +448,15 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         const size_t moved_bytes = ((((size_t)n_max + 31) / 32) * 4 + 15) & ~(size_t)15;
         const size_t hist_bytes = (size_t)span_max * p * A * 8;
         const size_t meta_bytes = n_max <= (uint32_t)fl::OPT_META_MAX ? (((size_t)n_max * 12 + 15) & ~(size_t)15) : 0;
-        q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global && !K.arith;
+        q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global;
         const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
-        q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0) + 16;
+        q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0);
+        if (K.arith && q.opt_lds + (size_t)p * 2 * fx_ctrl + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * 2 * fx_ctrl; }      // (the control bytes, which every probe reads)
+        q.opt_lds += 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
         if (A == 2 && q.hl && p <= 5 && threads == 1024 && !K.opt_threads && !K.no_specialized) threads = 512;
         q.threads = threads;
-        q.opt_spec = A == 2 && q.hl && threads >= 512 && p <= 5 && !K.no_specialized;
+        q.opt_spec = A == 2 && q.hl && threads >= 512 && p <= 5 && !K.no_specialized && !K.arith;
         uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (q.opt_lds + 8 * 1024)), 2048 / threads));
         per_cu = std::min<uint32_t>(per_cu, 8);
         q.opt_slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, nj_max);
@@ -468,7 +472,6 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         if (!shrunk) break;
     }
     uint64_t sl_state = 0, sl_hist = 0, sl_ohist = 0, sl_odist = 0, sl_ogain = 0, sl_okey = 0, sl_omoves = 0, sl_arith = 0;
-    const uint64_t fx_bytes = (fl::fx_table_bytes(span_max + 1) + 15) & ~(uint64_t)15;       // (+1: a full table grows once more when an insert call follows, optimize_kernel.h)
     auto sort_cap_of = [&](uint32_t p) { uint64_t c = 1; while (c < (uint64_t)p * span_max) c <<= 1; return c; };
     auto up256 = [](uint64_t x) -> uint64_t { return (x + 255) & ~(uint64_t)255; };
     for (uint32_t p = 1; p <= P; ++p) {
@@ -625,7 +628,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     if (K.arith) {
                         a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
                         char* base = ctx->arith_pool.as<char>() + sl_arith * lane;
-                        a.sort_cap = sort_cap_of(p); a.fx_bytes = fx_bytes;
+                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off;
                         a.fk_pool = (uint64_t*)base; base += (uint64_t)slots * p * span_max * 8;
                         a.sk_pool = (uint64_t*)base; base += (uint64_t)slots * a.sort_cap * 8;
                         a.sp_pool = (uint32_t*)base; base += ((uint64_t)slots * a.sort_cap * 4 + 15) & ~(uint64_t)15;
@@ -639,7 +642,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         return hipGetLastError();
                     };
                     hipError_t le;
-                    if (K.arith) le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512, 0, true>) : launch(fl::optimize_kernel<A, false, 128, 0, true>);
+                    if (K.arith && q.hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512, 0, true>) : launch(fl::optimize_kernel<A, true, 128, 0, true>);
+                    else if (K.arith) le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512, 0, true>) : launch(fl::optimize_kernel<A, false, 128, 0, true>);
                     else if (q.opt_spec && threads == 1024)
                         le = p == 1 ? launch(fl::optimize_kernel<2, true, 1024, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 1024, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 1024, 3>)
                            : p == 4 ? launch(fl::optimize_kernel<2, true, 1024, 4>) : launch(fl::optimize_kernel<2, true, 1024, 5>);
@@ -1394,6 +1398,34 @@ extern "C" {
 
 namespace {
 
+// Reference-arithmetic mode: the cells of every read of the given contigs in the iteration order of its position set (cell_order_kernel), for
+// the call in flight: ctx->cur_ord[ctx->cur_ord_off[c] + read_off[r] + x] = cell index (within contig c) of the x-th position of read r's set.
+// Recomputed per call (one launch, tens of ms for a 300 M-cell batch): the mode is opt-in and nothing else of a contig depends on it.
+int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, uint32_t len_max) {
+    const uint32_t n_contigs = (uint32_t)cdev.size();
+    std::vector<uint64_t> pre(2 * (size_t)n_contigs + 2, 0);                  // reads before contig c [n+1] | cells before contig c [n]
+    uint64_t cells = 0;
+    for (uint32_t i = 0; i < n_contigs; ++i) { pre[i + 1] = pre[i] + cdev[i].n_reads; pre[n_contigs + 1 + i] = cells; cells += n_cells[i]; }
+    const uint64_t R_all = pre[n_contigs];
+    int rc = ctx->arith_tab.ensure(pre.size() * 8); if (rc) return rc;
+    rc = ctx->arith_ord.ensure(4 * cells + 16); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->arith_tab.p, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));                                // (`pre` is pageable and local)
+    if (R_all) {
+        const uint64_t tb = fl::fx_ctrl_bytes(std::max(1u, len_max)) + fl::fx_slot_bytes(std::max(1u, len_max));
+        uint64_t nth = std::min<uint64_t>((R_all + 255) & ~255ull, 131072);
+        nth = std::max<uint64_t>(256, std::min<uint64_t>(nth, ((2ull << 30) / (3 * tb)) & ~255ull));
+        rc = ctx->arith_scr.ensure(3 * tb * nth); if (rc) return rc;
+        fl::CellOrderArgs oa{};
+        oa.contigs = d_contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+        oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint32_t>(); oa.scratch = ctx->arith_scr.as<uint8_t>(); oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
+        hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
+        HIPCHK(hipGetLastError());
+    }
+    ctx->cur_ord = ctx->arith_ord.as<uint32_t>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+    return 0;
+}
+
 // What S1 needs to know about its contigs.  With `chunk_ev` the cell arrays of chunk g (contig_chunk[ci] == g) are still on
 // the wire: they are complete once chunk_ev[g] has fired, and the blocks of chunk g form job group g whose stream waits for it
 // (read_off / first / last of every contig are already ordered before the context's main stream).
@@ -1553,7 +1585,6 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
         // -> every ploidy at once up to 18 x CUs blocks, {1,2,3} then {4..P} up to 23 x CUs, one ploidy per stage above
         if (spec < 0) spec = !(slab_path && P >= 3) ? 0 : jobs.size() <= (size_t)ctx->n_cu * 18 ? 1 : (jobs.size() <= (size_t)ctx->n_cu * 23 && P >= 4) ? 2 : 0;
         if (P * G > floria_hip_ctx::MAX_LANES || P < 3) spec = 0;
-        if (ctx->knobs.arith && ctx->knobs.speculate < 0) spec = 0;
         // a speculative stage's lanes wait on each other's events: with more lanes than hardware queues (GPU_MAX_HW_QUEUES, 12 in our hosts, minus the main,
         // copy and flatten streams) they share queues and the gates serialise the stage (measured: 250 contigs in 3 / 4 / 5 chunk groups 94 / 141 / 187 ms against 32)
         // (floria_hip_create measured how many streams really run side by side: hw_queues; main, copy and flatten streams take up to three of them)
@@ -1618,28 +1649,10 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     ctx->cur_ord = nullptr; ctx->cur_ord_off = nullptr;
     if (ctx->knobs.arith && n_contigs) {
         if (SC.n_cells.size() != n_contigs || chunked) return fail(FLORIA_E_INVALID, "internal: the reference-arithmetic mode needs resident contigs");
-        std::vector<uint64_t> pre(2 * (size_t)n_contigs + 2, 0);                  // reads before contig c [n+1] | cells before contig c [n]
-        uint64_t cells = 0;
-        for (uint32_t i = 0; i < n_contigs; ++i) { pre[i + 1] = pre[i] + cdev[i].n_reads; pre[n_contigs + 1 + i] = cells; cells += SC.n_cells[i]; }
-        const uint64_t R_all = pre[n_contigs];
-        rc = ctx->arith_tab.ensure(pre.size() * 8); if (rc) return rc;
-        rc = ctx->arith_ord.ensure(4 * cells + 16); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->arith_tab.p, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));                                // (`pre` is pageable and local)
-        if (R_all) {
-            const uint64_t tb = (fl::fx_table_bytes(std::max(1u, len_max)) + 15) & ~(uint64_t)15;
-            uint64_t nth = std::min<uint64_t>((R_all + 255) & ~255ull, 131072);
-            nth = std::max<uint64_t>(256, std::min<uint64_t>(nth, ((2ull << 30) / (3 * tb)) & ~255ull));
-            rc = ctx->arith_scr.ensure(3 * tb * nth); if (rc) return rc;
-            fl::CellOrderArgs oa{};
-            oa.contigs = bs.contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
-            oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint32_t>(); oa.scratch = ctx->arith_scr.as<uint8_t>(); oa.table_bytes = tb;
-            int tk = T.begin(K_SEL);
-            hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
-            T.end(tk);
-            HIPCHK(hipGetLastError());
-        }
-        ctx->cur_ord = ctx->arith_ord.as<uint32_t>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+        int tk = T.begin(K_SEL);
+        rc = cell_orders(ctx, bs.contigs, cdev, SC.n_cells, len_max);
+        T.end(tk);
+        if (rc) return rc;
     }
 
     // ---- result buffers (allocated first: the read-id lists are copied back while the launch loop runs) -----------------
@@ -2336,12 +2349,19 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         a.eps = epsilon; a.queue_head = (uint32_t*)(M + s_q.off);
         a.order = read_order ? (const uint32_t*)(M + s_ord.off) : nullptr; a.order_off = (const uint64_t*)(M + s_oo.off);
         a.multi = (const uint32_t*)(M + s_mu.off); a.multi_off = (const uint64_t*)(M + s_mo.off);
+        const bool arith = ctx->knobs.arith != 0;
+        if (arith) {                                // the reference's running sums: every read's cells in the order of its position set
+            std::vector<uint64_t> ncells(n_contigs); uint32_t len_max = 1;
+            for (uint32_t ci = 0; ci < n_contigs; ++ci) { ncells[ci] = contigs[ci]->n_cells; len_max = std::max(len_max, contigs[ci]->max_len); }
+            rc = cell_orders(ctx, a.contigs, cdev, ncells, len_max); if (rc) return rc;
+            a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
+        }
         // contigs where at least 1 read in 8 has a choice take the latency-optimised chain kernel, the others the parallel one
         std::vector<uint32_t> list_par, list_chain;
         for (uint32_t ci = 0; ci < n_contigs; ++ci) {
             const uint64_t nm = multi_off_all[ci + 1] - multi_off_all[ci];
             const uint64_t nv = read_order ? order_off[ci + 1] - order_off[ci] : contigs[ci]->n_reads;
-            const bool chain = ctx->knobs.reassign_path == 2 || (ctx->knobs.reassign_path == 0 && nm * 8 >= nv && nm > 0);
+            const bool chain = !arith && (ctx->knobs.reassign_path == 2 || (ctx->knobs.reassign_path == 0 && nm * 8 >= nv && nm > 0));
             (chain ? list_chain : list_par).push_back(ci);
         }
         std::vector<uint32_t> lists(list_par);
@@ -2351,7 +2371,9 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         if (!list_par.empty()) {
             a.list = (const uint32_t*)(M + s_ls.off); a.n_list = (uint32_t)list_par.size(); a.queue_head = (uint32_t*)(M + s_q.off);
             const uint32_t grid = std::min<uint32_t>(a.n_list, (uint32_t)ctx->n_cu * 8);
-            if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+            if (arith) { if (A == 2) hipLaunchKernelGGL((fl::reassign_kernel<2, true>), dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
+                         else hipLaunchKernelGGL((fl::reassign_kernel<4, true>), dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a); }
+            else if (A == 2) hipLaunchKernelGGL(fl::reassign_kernel<2>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
             else hipLaunchKernelGGL(fl::reassign_kernel<4>, dim3(grid), dim3(fl::REASSIGN_THREADS), 0, ctx->stream, a);
         }
         if (!list_chain.empty()) {

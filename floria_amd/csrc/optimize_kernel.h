@@ -67,8 +67,9 @@ struct OptArgs {
     uint64_t* fk_pool;           // [slots][ploidy*span_max]  first-insertion key of every (partition, position)
     uint64_t* sk_pool;           // [slots][sort_cap]         sort keys
     uint32_t* sp_pool;           // [slots][sort_cap]         sorted (partition, position) entries
-    uint8_t*  fx_pool;           // [slots][ploidy][2*fx_bytes] the emulated position maps
-    uint64_t  sort_cap, fx_bytes;
+    uint8_t*  fx_pool;           // [slots][ploidy][2][fx_ctrl + fx_slot] the emulated position maps: control bytes, keys
+    uint64_t  sort_cap, fx_ctrl, fx_slot;
+    uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl])
 };
 // fired(q): the reference's loop breaks at ploidy q (graph_processing.rs:196-251); needs mec[q-1] (q > 1) and mec[q], num_alleles[q]
 __device__ inline bool stop_rule_fires(const OptArgs& g, uint32_t b, uint32_t q) {
@@ -130,7 +131,7 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 // instead of MAX_PLOIDY predicated iterations.
 // ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)): a read's distance is the running sum over its cells in the order
 // of its position set (utils_frags.rs:33-72), a partition's `errors` the running sum over its positions in the bucket order of its position
-// map (local_clustering.rs:226-256), which is emulated per partition (arith_kernel.h).  HL must be false.
+// map (local_clustering.rs:226-256), which is emulated per partition (arith_kernel.h).
 template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false>
 __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
@@ -289,22 +290,30 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         // thread per partition replays the insertions into the emulated table, (4) and walks its buckets adding the terms of :244-253 in that order.
         auto mec_stats_arith = [&](bool phred) {
             uint64_t* fk = g.fk_pool + (uint64_t)blockIdx.x * g.span_max * p;
-            uint64_t* sk = g.sk_pool + (uint64_t)blockIdx.x * g.sort_cap;
-            uint32_t* sp = g.sp_pool + (uint64_t)blockIdx.x * g.sort_cap;
             const uint32_t M = span * p;
+            uint32_t M2 = 1;
+            while (M2 < M) M2 <<= 1;
+            uint64_t* sk = M2 <= (uint32_t)OPT_SORT_LDS ? s_gain : g.sk_pool + (uint64_t)blockIdx.x * g.sort_cap;        // (the candidate sort's LDS arrays are free here)
+            uint32_t* sp = M2 <= (uint32_t)OPT_SORT_LDS ? s_key : g.sp_pool + (uint64_t)blockIdx.x * g.sort_cap;
             for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
             if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; s_lastcall[tid] = 0; }
             __syncthreads();
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                 uint32_t cb = 0, len = 0, k = 0;
                 if (i < n) { read_meta(i, cb, len, k); k = part[i]; }
-                for (uint32_t c = sub; c < len; c += 16)
-                    atomicMin((unsigned long long*)&fk[k * span + (G(cd.cell_snp)[ord[cb + c]] - pos0)], ((unsigned long long)i << 24) | c);
+                for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {              // (as the build pass: eight cells per lane requested before the first atomic)
+                    uint32_t ci[8], sn[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; ci[u] = c < len ? ord[cb + c] : 0xffffffffu; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sn[u] = ci[u] != 0xffffffffu ? G(cd.cell_snp)[ci[u]] : 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (ci[u] != 0xffffffffu) atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
+                }
                 if (sub == 0 && i < n) atomicMax(&s_lastcall[k], ((unsigned long long)i << 24) | (len - 1));
             }
             __syncthreads();
-            uint32_t M2 = 1;
-            while (M2 < M) M2 <<= 1;
             for (uint32_t x = tid; x < M2; x += OPT_THREADS) {
                 const uint64_t f = x < M ? fk[x] : ~0ull;
                 const uint32_t k = x < M ? x / span : 0;
@@ -313,40 +322,61 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 if (f != ~0ull) atomicAdd(&s_cntk[k], 1u);
             }
             __syncthreads();
+            OPT_TICK(10);    // (ARITH) first-insertion keys
             bitonic_sort(sk, sp, M2, tid, OPT_THREADS);
+            OPT_TICK(11);    // (ARITH) sort
             if ((uint32_t)tid < p) {
                 const uint32_t k = tid;
                 uint32_t start = 0;
                 for (uint32_t q = 0; q < k; ++q) start += s_cntk[q];
                 const uint32_t D = s_cntk[k];
-                uint8_t* mem = g.fx_pool + ((uint64_t)blockIdx.x * p + k) * 2 * g.fx_bytes;
-                void* spare = mem + g.fx_bytes;
+                const uint64_t fxb = g.fx_ctrl + g.fx_slot;
+                uint8_t* gmem = g.fx_pool + ((uint64_t)blockIdx.x * p + k) * 2 * fxb;
+                uint8_t* c0 = g.fx_lds_off ? smem + g.fx_lds_off + (uint64_t)k * 2 * g.fx_ctrl : gmem;
+                uint8_t* spare_c = g.fx_lds_off ? c0 + g.fx_ctrl : gmem + fxb;
+                uint32_t* spare_s = (uint32_t*)(gmem + fxb + g.fx_ctrl);
                 FxTable t;
-                if (D) t.bind(mem, fx_buckets_for(1));
-                for (uint32_t d = 0; d < D; ++d) t.insert_new(sp[start + d] - k * span + pos0, spare);
-                if (D && t.growth_left == 0 && (~sk[start + D - 1] & 0x00ffffffffffffffull) != s_lastcall[k]) t.reserve(1, spare);     // a later insert call of a position already there
+                if (D) t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1));
+                for (uint32_t d = 0; d < D; ++d) t.insert_new(sp[start + d] - k * span + pos0, spare_c, spare_s);
+                if (D && t.growth_left == 0 && (~sk[start + D - 1] & 0x00ffffffffffffffull) != s_lastcall[k]) t.reserve(1, spare_c, spare_s);     // a later insert call of a position already there
+#ifdef FLORIA_PROF
+                if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's replay
+#endif
                 double ef = 0.0;
                 uint64_t good = 0;
                 const uint64_t one = phred ? ONE_Q24 : 1ull;
                 const double scale = phred ? 0x1p-24 : 1.0;
-                for (uint32_t i = 0; i < t.buckets; ++i) {
-                    if (t.ctrl[i] & 0x80) continue;
-                    const uint64_t* cp = hist + (uint64_t)(t.slot[i] - pos0) * PA + k * A;
-                    uint64_t q[A];
+                constexpr int WU = 8;                                            // buckets per batch: control bytes, keys and histogram rows requested together
+                for (uint32_t i0 = 0; i0 < t.buckets; i0 += WU) {
+                    bool full[WU]; uint32_t key[WU]; uint64_t row[WU][A];
 #pragma unroll
-                    for (int al = 0; al < A; ++al) { const uint64_t v = cp[al]; q[al] = phred ? (v & QMASK44) : (v >> CNT_SHIFT); }
+                    for (int u = 0; u < WU; ++u) { const bool in = i0 + u < t.buckets; full[u] = in && !(t.ctrl[in ? i0 + u : 0] & 0x80); key[u] = t.slot[in ? i0 + u : 0]; }
 #pragma unroll
-                    for (int x = 1; x < A; ++x)                                  // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
+                    for (int u = 0; u < WU; ++u) {
+                        const uint64_t* cp = hist + (uint64_t)(full[u] ? key[u] - pos0 : 0u) * PA + k * A;
 #pragma unroll
-                        for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
+                        for (int al = 0; al < A; ++al) row[u][al] = cp[al];
+                    }
 #pragma unroll
-                    for (int x = 0; x + 1 < A; ++x) ef += (double)q[x] * scale;   // :248-250 all but the last
-                    good += q[A - 1];
-                    if (q[A - 1] <= one) ef += g.eps;                             // :251-253
+                    for (int u = 0; u < WU; ++u) {
+                        if (!full[u]) continue;
+                        uint64_t q[A];
+#pragma unroll
+                        for (int al = 0; al < A; ++al) q[al] = phred ? (row[u][al] & QMASK44) : (row[u][al] >> CNT_SHIFT);
+#pragma unroll
+                        for (int x = 1; x < A; ++x)                              // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
+#pragma unroll
+                            for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
+#pragma unroll
+                        for (int x = 0; x + 1 < A; ++x) ef += (double)q[x] * scale;   // :248-250 all but the last
+                        good += q[A - 1];
+                        if (q[A - 1] <= one) ef += g.eps;                         // :251-253
+                    }
                 }
                 s_errf[k] = ef; s_goodq[k] = good;
             }
             __syncthreads();
+            OPT_TICK(12);    // (ARITH) replay + walk, slowest partition
             if (tid == 0 && phred) {
                 double sc = 0.0;
                 for (uint32_t k = 0; k < p; ++k) sc += s_errf[k];
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
 #ifdef FLORIA_OPT_FULL_DIST
                 const bool incremental = false;
 #else
-                const bool incremental = HL && meta && it > 0 && span <= 65535u;
+                const bool incremental = HL && !ARITH && meta && it > 0 && span <= 65535u;
 #endif
                 const uint32_t chg_lo = incremental ? s_chg_lo : 0u, chg_hi = incremental ? s_chg_hi : 0xffffffffu;
                 if constexpr (ARITH) {              // one thread per (read, partition): the running sum cannot be split over lanes
@@ -382,15 +412,29 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         uint32_t cb = 0, len = 0, kk = 0;
                         read_meta(i, cb, len, kk);
                         double df = 0.0;
-                        for (uint32_t c = 0; c < len; ++c) {
-                            const uint32_t ci = ord[cb + c];
-                            const uint32_t aq = G(cd.cell_aw)[ci], al = aq >> 28;
-                            const uint64_t* row = hist + (uint64_t)(G(cd.cell_snp)[ci] - pos0) * PA + k * A;
-                            uint64_t mx = 0, va = 0;
+                        constexpr int DU = 4;                                    // cells per batch: order entries, cells and histogram rows requested together
+                        for (uint32_t c0 = 0; c0 < len; c0 += DU) {
+                            uint32_t ci[DU], aqs[DU], sn[DU]; uint64_t row[DU][A];
 #pragma unroll
-                            for (int x = 0; x < A; ++x) { const uint64_t q = row[x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
-                            if (mx == 0) df += g.eps;
-                            else if (va != mx) df += (double)(aq & 0x0fffffffu) * 0x1p-24;
+                            for (int u = 0; u < DU; ++u) ci[u] = ord[cb + (c0 + u < len ? c0 + u : len - 1)];
+#pragma unroll
+                            for (int u = 0; u < DU; ++u) { aqs[u] = G(cd.cell_aw)[ci[u]]; sn[u] = G(cd.cell_snp)[ci[u]]; }
+#pragma unroll
+                            for (int u = 0; u < DU; ++u) {
+                                const uint64_t* rp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
+#pragma unroll
+                                for (int x = 0; x < A; ++x) row[u][x] = rp[x];
+                            }
+#pragma unroll
+                            for (int u = 0; u < DU; ++u) {
+                                if (c0 + u >= len) break;
+                                const uint32_t al = aqs[u] >> 28;
+                                uint64_t mx = 0, va = 0;
+#pragma unroll
+                                for (int x = 0; x < A; ++x) { const uint64_t q = row[u][x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
+                                if (mx == 0) df += g.eps;
+                                else if (va != mx) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;
+                            }
                         }
                         dist[pair] = df;
                     }

@@ -35,6 +35,9 @@ struct ReassignArgs {
     uint32_t n_list;
     double eps;
     uint32_t* queue_head;
+    // reference-arithmetic mode (reassign_kernel<A, true>, arith_kernel.h): the reads' cells in the iteration order of Frag.positions
+    const uint32_t* cell_ord;
+    const uint64_t* cell_ord_off;
 };
 
 constexpr int REASSIGN_THREADS = 256;
@@ -45,7 +48,9 @@ constexpr int REASSIGN_THREADS = 256;
 // of the visiting order is added to its histogram by all lanes at once (integer atomics: the sums do not depend on the order of
 // the adds, and every read that chooses sees exactly the contributions of the reads visited before it — the result equals the
 // serial loop's for ANY visiting order).  Contigs without a multi-candidate read need no histogram at all.
-template <int A>
+// ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)): the distance is the running sum over the read's cells in the order
+// of its position set (utils_frags.rs:33-72) — lane x folds the x-th candidate group, cell by cell.
+template <int A, bool ARITH = false>
 __global__ __launch_bounds__(REASSIGN_THREADS) void reassign_kernel(ReassignArgs g) {
     __shared__ uint32_t s_ci;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -101,6 +106,37 @@ __global__ __launch_bounds__(REASSIGN_THREADS) void reassign_kernel(ReassignArgs
                 uint32_t best = r2g[c0];
                 double bd = 0.0, bsame = 0.0;
                 bool have = false;
+                if constexpr (ARITH) {
+                    const uint32_t* co = g.cell_ord + g.cell_ord_off[ci];
+                    for (uint32_t x0 = 0; x0 < nc; x0 += 64) {
+                        const uint32_t x = x0 + lane;
+                        const bool act = x < nc;
+                        const uint32_t gid = act ? r2g[c0 + x] : 0;
+                        const uint64_t* h = g.hist + g.grp_hist_off[gb + gid];
+                        const uint32_t p0 = g.grp_pos0[gb + gid];
+                        double df = 0.0; uint64_t qs = 0;
+                        if (act)
+                            for (uint32_t c = cb; c < ce; ++c) {
+                                const uint32_t cx = co[c];
+                                const uint32_t aq = G(cd.cell_aw)[cx], al = aq >> 28;
+                                const uint64_t* cp = h + (uint64_t)(G(cd.cell_snp)[cx] - p0) * A;
+                                uint64_t mx = 0, va = 0;
+#pragma unroll
+                                for (int a = 0; a < A; ++a) { const uint64_t q = __hip_atomic_load(cp + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mx = q > mx ? q : mx; va = (a == (int)al) ? q : va; }
+                                if (mx == 0) df += g.eps;
+                                else if (va == mx) qs += (aq & 0x0fffffffu);
+                                else df += (double)(aq & 0x0fffffffu) * 0x1p-24;
+                            }
+                        const double kd_l = df + 1., ks_l = (double)qs * 0x1p-24;
+                        const uint32_t cnt = nc - x0 < 64u ? nc - x0 : 64u;
+                        for (uint32_t y = 0; y < cnt; ++y) {                          // candidates in ascending id, as the reference's min_by visits them
+                            const double kd = shfl_f64(kd_l, (int)y), ks = shfl_f64(ks_l, (int)y);
+                            const uint32_t gy = (uint32_t)__shfl((int)gid, (int)y);
+                            const bool less = !have || kd < bd || (kd == bd && (gy < best || (gy == best && ks < bsame)));
+                            if (less) { have = true; bd = kd; bsame = ks; best = gy; }
+                        }
+                    }
+                } else
                 for (uint32_t x = 0; x < nc; ++x) {
                     const uint32_t gid = r2g[c0 + x];
                     const uint64_t* h = g.hist + g.grp_hist_off[gb + gid];

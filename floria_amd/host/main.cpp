@@ -101,6 +101,8 @@ int main(int argc, char** argv) {
     bool debug = false;                  // --debug / --trace: per contig, debug_graph.txt (hap graph, LP flows, joined paths) next to the outputs
     std::vector<int> devices;            // --devices: the GPUs the contigs of a batch are dealt to (empty: --device alone)
     size_t bam_window = (size_t)512 << 20;   // --bam-window-mb: inflated BAM bytes held at a time (more only when one contig alone is larger)
+    std::string arith_opt = "auto";      // --arith auto|reference|canonical: the reference's running f64 sums (device mode arith = 1) or the exact (Q24, #eps) form; auto = reference
+                                         // arithmetic exactly when epsilon is not a multiple of 2^-10 (where the two are different functions)
     bool eps_round = false;              // --epsilon-round: round an auto-estimated -e to a multiple of 2^-10 (default: used as estimated, like the reference)
     std::string run_note;                // second line of cmd.log
     std::thread freer;                   // frees the Frags of the previous batch while the next one is ingested; joined before the process leaves main
@@ -134,6 +136,7 @@ int main(int argc, char** argv) {
             else if (a == "--device") o.device = std::stoi(val());
             else if (a == "--epsilon-as-estimated") {}                          // (the default since round 4; accepted for older command lines)
             else if (a == "--epsilon-round") eps_round = true;
+            else if (a == "--arith") { arith_opt = val(); if (arith_opt != "auto" && arith_opt != "reference" && arith_opt != "canonical") throw Error(FLORIA_E_INVALID, "--arith takes auto, reference or canonical"); }
             else if (a == "--bam-window-mb") bam_window = std::max<size_t>(1, std::stoul(val())) << 20;
             else if (a == "--bam-window-kb") bam_window = std::max<size_t>(1, std::stoul(val())) << 10;       // (tests: many segments on a small file)
             else if (a == "--devices") {                                 // "0-7", "0,2,5", "0-3,6"; a device may be named twice (two contexts on it)
@@ -261,9 +264,17 @@ int main(int argc, char** argv) {
             }
             fprintf(stderr, "Estimated -l %zu, -e %g (used where not given: -l %zu, -e %.10g)\n", est.first, est.second, o.block_length, o.epsilon);
         }
-        if (!dyadic10(o.epsilon))
-            fprintf(stderr, "floria-hip: warning: -e %.17g is not a multiple of 2^-10; sums of epsilon terms are then rounded once here and term by term (in hash-map order) in floria, "
-                            "so haplosets can differ from floria's in exact ties (-e %.10g, or --epsilon-round for an estimated one, avoids that)\n", o.epsilon, std::max(1.0, std::floor(o.epsilon * 1024.0 + 0.5)) / 1024.0);
+        const bool reference_arith = arith_opt == "reference" || (arith_opt == "auto" && !dyadic10(o.epsilon));
+        if (!dyadic10(o.epsilon)) {
+            const double near = std::max(1.0, std::floor(o.epsilon * 1024.0 + 0.5)) / 1024.0;
+            if (reference_arith)
+                fprintf(stderr, "floria-hip: note: -e %.17g is not a multiple of 2^-10: phasing in floria's own running-sum arithmetic (sums of epsilon terms rounded term by term, in the "
+                                "iteration order of its hash containers; slower kernels).  --arith canonical keeps the fast kernels (every sum rounded once), -e %.10g is an epsilon at which "
+                                "the two are the same function\n", o.epsilon, near);
+            else
+                fprintf(stderr, "floria-hip: warning: -e %.17g is not a multiple of 2^-10; with --arith canonical sums of epsilon terms are rounded once here and term by term (in hash-map order) in floria, "
+                                "so haplosets can differ from floria's in exact ties (-e %.10g, or --epsilon-round for an estimated one, avoids that)\n", o.epsilon, near);
+        }
         if (!ingest_only) write_run_files(o, argc, argv, run_note);
         const std::vector<std::string> contigs = stream.target_names();                 // get_contigs_to_phase (file_reader.rs:738-746)
         tp = now_s();
@@ -275,6 +286,7 @@ int main(int argc, char** argv) {
         if (devices.empty()) devices.push_back(o.device);
         std::vector<std::unique_ptr<Session>> sessions;
         if (!ingest_only) for (int d : devices) sessions.emplace_back(new Session(d));
+        for (auto& s : sessions) if (floria_hip_set_option(s->ctx(), "arith", reference_arith ? 1 : 0) != 0) throw Error(FLORIA_E_INVALID, floria_hip_last_error());
         Session* const session_holder = sessions.empty() ? nullptr : sessions[0].get();
         fprintf(stderr, "Preprocessing: BAM header%s %.3fs, VCF + FASTA %.3fs, device %.3fs\n", (!have_e || !have_l) ? " + parameter estimate" : "", t_bam, t_vcf, now_s() - tp);
 

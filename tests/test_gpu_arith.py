@@ -111,3 +111,43 @@ def test_batch_of_contigs_and_the_pipelined_entry_point(arith, hip_lib, oracle_m
             assert ro.best_ploidy[b] == rg.best_ploidy[off + b]
             assert np.array_equal(ro.mec[b].view(np.uint64), rg.mec[off + b].view(np.uint64))
         off += n
+
+
+@pytest.mark.parametrize("eps", NON_DYADIC)
+def test_final_reassignment_in_reference_arithmetic(arith, hip_lib, oracle_mod, eps):
+    """S2 (process_reads_for_final_parts): the candidates' keys (diff + 1., id, same) from running sums in set order, ascending and caller-given visiting orders."""
+    from tests.test_gpu_parity import groups_from_blocks
+    for cfg, idx, scale, bl in ((4, 0, 0.5, 10000), (3, 0, 0.2, 500)):
+        c = synth.make_config_contig(cfg, idx, scale)
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, bl)
+        r = arith.phase_blocks(c.pileup, s, e, hip_lib.make_params(eps))
+        groups, ranges = groups_from_blocks(r, s, e)           # overlapping blocks -> reads sit in several haplogroups
+        members = np.unique(np.concatenate(groups))
+        for order in (None, members[::-1].copy(), np.random.default_rng(5).permutation(members).astype(np.uint32)):
+            go = oracle_mod.reassign(c.pileup, groups, ranges, eps, read_order=order)
+            gg = arith.reassign(c.pileup, groups, ranges, eps, read_order=order)
+            assert go.n_groups == gg.n_groups
+            assert np.array_equal(go.range, gg.range) and np.array_equal(go.grp_off, gg.grp_off) and np.array_equal(go.grp_read, gg.grp_read)
+
+
+def test_config4_64_contigs_in_reference_arithmetic(arith, hip_lib, oracle_mod):
+    """A batch the size of a small shard (64 contigs, ~460 blocks, every ploidy up to 5) at the BASELINE second pass's epsilon."""
+    C = synth.CONFIGS[4]
+    contigs = [synth.make_config_contig(4, i, 1.0) for i in range(64)]
+    handles = arith.upload_batch([c.pileup for c in contigs])
+    bc, bs, be, per = [], [], [], []
+    for i, c in enumerate(contigs):
+        s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
+        per.append((s, e)); bc += [i] * len(s); bs += list(s); be += list(e)
+    rg = arith.phase_blocks_batch(handles, np.asarray(bc, np.uint32), np.asarray(bs, np.uint32), np.asarray(be, np.uint32), hip_lib.make_params(0.04, C["max_ploidy"], C["beam"]))
+    off = 0
+    for i, c in enumerate(contigs):
+        s, e = per[i]
+        ro = oracle_mod.phase_blocks(c.pileup, s, e, oracle_mod.make_params(0.04, C["max_ploidy"], C["beam"]), threads=8)
+        for b in range(len(s)):
+            assert ro.best_ploidy[b] == rg.best_ploidy[off + b], f"contig {i} block {b}"
+            assert np.array_equal(ro.block(b)[1], rg.block(off + b)[1]), f"contig {i} block {b}"
+            assert np.array_equal(ro.mec[b].view(np.uint64), rg.mec[off + b].view(np.uint64)), f"contig {i} block {b}"
+        off += len(s)
+    for h in handles:
+        h.free()

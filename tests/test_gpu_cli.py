@@ -46,13 +46,25 @@ def parse_frag_dump(path):
     return contigs
 
 
-def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra=(), sub_rate=0.0):
+def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra=(), sub_rate=0.0, eps=EPS):
+    """An epsilon that is not a multiple of 2^-10 makes floria-hip phase in the reference's running-sum arithmetic (--arith auto): the oracle
+    chain it is compared with then runs in arithmetic mode 1."""
+    reference_arith = eps * 1024 != int(eps * 1024) and "canonical" not in extra
+    if reference_arith:
+        oracle_mod.set_arith_mode(1)
+    try:
+        return _run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra, sub_rate, eps)
+    finally:
+        oracle_mod.set_arith_mode(0)
+
+
+def _run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra, sub_rate, eps):
     from oracle import stitch
     prefix = str(tmp_path / "data")
     expect = synth_bam.write_dataset(prefix, contigs, seed=7, sub_rate=sub_rate)
     out = str(tmp_path / "out")
     dump = str(tmp_path / "frags.txt")
-    cmd = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", str(EPS), "-l", str(block_length),
+    cmd = [floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", repr(eps), "-l", str(block_length),
            "--debug", "--dump-frags", dump, *extra]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -80,7 +92,7 @@ def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra
         cdir = os.path.join(out, c.name)
         cols, flows, paths = stitch.parse_debug_graph(os.path.join(cdir, "debug_graph.txt"))
         s, e = oracle_mod.block_ranges(ex["snp_pos0"], block_length)
-        ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(EPS), threads=8)
+        ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps), threads=8)
         cov, ew = oracle_mod.hap_graph(pile, s, e, ro)
         ocols = stitch.build_hap_graph(ro, s, e, cov, ew)
         assert [len(x) for x in cols] == [len(x) for x in ocols]
@@ -91,7 +103,7 @@ def run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extra
         stitch.check_flows(cols, flows)
         assert paths == stitch.disjoint_paths(cols, flows)
         # ---- S2 + writers ----------------------------------------------------------------------------------------------------------------
-        go = oracle_mod.reassign(pile, [p[2] for p in paths], [(p[0], p[1]) for p in paths], EPS)
+        go = oracle_mod.reassign(pile, [p[2] for p in paths], [(p[0], p[1]) for p in paths], eps)
         parts = [go.group(g) for g in range(go.n_groups)]
         ranges = [tuple(int(x) for x in go.range[g]) for g in range(go.n_groups)]
         stats = [oracle_mod.haploset_stats(pile, parts[g], ranges[g][0], ranges[g][1]) for g in range(go.n_groups)]
@@ -188,6 +200,15 @@ def test_output_reads_paired(floria_hip, oracle_mod, tmp_path):
     # pairs are written whole: mate 1 as aligned, mate 2 reverse-complemented with its qualities as stored (file_writer.rs:168-217)
     c = synth.make_config_contig(3, 2, 0.3, keep_layout=True)
     run_and_check(floria_hip, oracle_mod, tmp_path, [c], 500, extra=("--output-reads",))
+
+
+@pytest.mark.parametrize("eps,extra", [(0.04, ()), (0.0437, ()), (0.04, ("--arith", "canonical")), (EPS, ("--arith", "reference"))])
+def test_non_dyadic_epsilon_is_phased_in_reference_arithmetic(floria_hip, oracle_mod, tmp_path, eps, extra):
+    # at an epsilon where the reference's running sums and the canonical exact sums part ways, the tool computes the reference's form
+    # (the whole chain equals the oracle's arithmetic mode 1: hap graph, paths, haplosets, files); --arith canonical keeps the fast kernels (== mode 0);
+    # at a dyadic epsilon --arith reference changes nothing but the kernels
+    c = synth.make_config_contig(1, 0, keep_layout=True)
+    run_and_check(floria_hip, oracle_mod, tmp_path, [c], 10000, extra=extra, eps=eps)
 
 
 def test_auto_estimated_parameters(floria_hip, tmp_path):
