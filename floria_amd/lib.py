@@ -274,7 +274,8 @@ class FloriaHip:
         _check(load().floria_hip_set_slots(self._h, C.c_uint32(n)))
 
     def set_option(self, key, value):
-        """Tuning / test knobs (floria_hip_set_option); none changes results."""
+        """floria_hip_set_option.  "arith" = 1 selects the reference's running-sum arithmetic (a different function at an epsilon that is not a
+        multiple of 2^-10, slower kernels; include/floria_hip.h); every other key is a tuning / test knob that changes no result."""
         _check(load().floria_hip_set_option(self._h, key.encode(), C.c_int64(int(value))))
 
     def selftest(self, epsilon, n_max=1024):

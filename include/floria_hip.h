@@ -323,7 +323,18 @@ int  floria_hip_selftest(floria_hip_ctx* ctx, double epsilon, uint32_t n_max, do
 /* Tuning knob (0 = default): how many (block, ploidy) jobs may be resident at once. */
 int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
 
-/* Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy stages: -1 auto,
+/* The one option that selects WHICH function is computed: "arith".
+ *   0 (default)  every weighted sum is carried as an exact (Q24 integer, number of epsilon terms) pair and rounded once;
+ *   1            the reference's own arithmetic: running f64 sums, `diff += epsilon` between `diff += w` over a read's cells in the iteration order of its
+ *                FxHashSet of positions (utils_frags.rs:33-72), one running sum per partition in a search node (global_clustering.rs:196-202), `errors +=`
+ *                over a haplotype's positions in the bucket order of its FxHashMap (local_clustering.rs:226-256), those orders emulated on the device
+ *                (csrc/arith_kernel.h).  Applies to floria_hip_phase_* (S1) and floria_hip_reassign* (S2); slower kernels (one generic beam kernel, sequential
+ *                table replays in the optimise kernel: about 20 x the time of mode 0 on BASELINE config 4), and the host-pileup entry points do not pipeline.
+ * For an epsilon that is a multiple of 2^-10 both modes return the same bits (every sum is exact in f64 in any order); for any other epsilon they are
+ * different functions (about 60 % of the blocks of the BASELINE configs come out differently at 0.04) and mode 1 is the one a Rust host's CPU path computes,
+ * as far as the emulated std hash-table orders are right.  Checked bit for bit against the oracle's arithmetic mode 1 (tests/test_gpu_arith.py).
+ *
+ * Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy stages: -1 auto,
  * 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}), "spec_gate_div" (grid divisor of the gated ploidies of a
  * speculative stage, default 2), "beam_path" (0 auto, 1 generic, 2 slab, 3 wide), "no_specialized", "no_p1_shortcut", "opt_threads"
  * (0|128|512|1024), "opt_global", "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload),
