@@ -151,3 +151,26 @@ def test_config4_64_contigs_in_reference_arithmetic(arith, hip_lib, oracle_mod):
         off += len(s)
     for h in handles:
         h.free()
+
+
+@pytest.mark.parametrize("knob,value", [("opt_global", 1), ("speculate", 0), ("speculate", 1), ("speculate", 2), ("opt_threads", 512), ("opt_threads", 1024), ("slots", 96), ("groups", 2)])
+def test_launch_knobs_do_not_change_reference_arithmetic_results(arith, hip_lib, oracle_mod, knob, value):
+    """Histogram in HBM instead of LDS, every stage plan, other workgroup sizes, a small persistent grid: the same bits (the oracle comparison of the
+    default plan is test_config_slices_in_reference_arithmetic)."""
+    piles, bc, bs, be = [], [], [], []
+    for i, (cfg, scale) in enumerate(((4, 1.0), (3, 0.1), (4, 1.0), (2, 0.05))):
+        c = synth.make_config_contig(cfg, i, scale)
+        s, e = oracle_mod.block_ranges(c.snp_pos, synth.CONFIGS[cfg]["block_length"])
+        piles.append(c.pileup); bc += [i] * len(s); bs += list(s); be += list(e)
+    hs = arith.upload_batch(piles)
+    par = hip_lib.make_params(0.0437, 5, 10)
+    args = (hs, np.asarray(bc, np.uint32), np.asarray(bs, np.uint32), np.asarray(be, np.uint32), par)
+    r0 = arith.phase_blocks_batch(*args)
+    arith.set_option(knob, value)
+    try:
+        r1 = arith.phase_blocks_batch(*args)
+    finally:
+        arith.set_option(knob, {"speculate": -1}.get(knob, 0))
+    assert_block_results_equal(r0, r1, f"{knob}={value}")
+    for h in hs:
+        h.free()
