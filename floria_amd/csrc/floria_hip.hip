@@ -1111,8 +1111,9 @@ hipError_t launch_flatten(floria_hip_ctx* ctx, UploadPlan& P, uint32_t g, hipStr
     a.contigs = (const fl::UploadContig*)(P.T + P.t_cd) + c0; a.read_prefix = (const uint64_t*)(P.T + P.t_rp) + c0; a.status = (fl::UploadStatus*)(P.T + P.t_st) + c0;
     a.w24 = ctx->d_w24.as<uint32_t>(); a.Rq1 = ctx->d_hash.as<uint64_t>(); a.Rq2 = ctx->d_hash.as<uint64_t>() + 2ull * ctx->hash_len;
     a.n_contigs = c1 - c0; a.read_base = P.rp[c0]; a.n_reads_total = nr;
-    if (P.packed) hipLaunchKernelGGL(fl::expand_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, st, a, (const fl::PackedContig*)(P.T + P.t_pk) + c0);     // compact wire form -> CSR, then as usual
-    hipLaunchKernelGGL(fl::flatten_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, st, a);
+    const unsigned wgs = (unsigned)((nr + fl::UP_READS_PER_WG - 1) / fl::UP_READS_PER_WG);
+    if (P.packed) hipLaunchKernelGGL(fl::expand_kernel, dim3(wgs), dim3(64), 0, st, a, (const fl::PackedContig*)(P.T + P.t_pk) + c0);     // compact wire form -> CSR, then as usual
+    hipLaunchKernelGGL(fl::flatten_kernel, dim3(wgs), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 // status words -> error (if any), else the contig handles
