@@ -298,6 +298,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
             if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; s_lastcall[tid] = 0; }
             __syncthreads();
+            OPT_TICK(14);    // (ARITH) key table cleared
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                 uint32_t cb = 0, len = 0, k = 0;
                 if (i < n) { read_meta(i, cb, len, k); k = part[i]; }
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 if (sub == 0 && i < n) atomicMax(&s_lastcall[k], ((unsigned long long)i << 24) | (len - 1));
             }
             __syncthreads();
+            OPT_TICK(15);    // (ARITH) atomicMin pass
             for (uint32_t x = tid; x < M2; x += OPT_THREADS) {
                 const uint64_t f = x < M ? fk[x] : ~0ull;
                 const uint32_t k = x < M ? x / span : 0;

@@ -6,6 +6,6 @@ import sys,re
 for l in sys.stdin:
     if l.startswith('arith'): print(l.strip()); continue
     d={int(a):float(b) for a,b in re.findall(r'(\d+):([0-9.]+)M',l)}
-    names=['build','stats0','dist','cand','sort','serial','moves','stats','undo','final','fk','asort','replay+walk','replay(p0)']
+    names=['build','stats0','dist','cand','sort','serial','moves','stats','undo','final','fill','asort','replay+walk','replay(p0)','clear','atomicMin']
     print('  opt phases (Mcyc): '+' '.join('%s %.0f'%(n,d.get(i,0)) for i,n in enumerate(names)))"
 make -C floria_amd/csrc -B libfloria_hip.so > /dev/null 2>&1

@@ -174,3 +174,19 @@ def test_launch_knobs_do_not_change_reference_arithmetic_results(arith, hip_lib,
     assert_block_results_equal(r0, r1, f"{knob}={value}")
     for h in hs:
         h.free()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_long_reads_in_reference_arithmetic(arith, hip_lib, oracle_mod, seed):
+    """Reads of several hundred cells: more than one LDS tile of the generic beam kernel per read (the running sum continues across tiles), position maps that
+    grow through many resizes, first-insertion keys with large cell ranks."""
+    rng = np.random.default_rng(9100 + seed)
+    pile = random_pileup(rng, 60 + 20 * seed, 900, 3, max_len=700, alleles=4 if seed == 2 else 2, err=0.05, drop=0.15)
+    S = int(pile.last.max())
+    s = np.asarray([1, S // 3, S // 2], np.uint32)
+    e = np.asarray([S, min(S, S // 3 + 400), S], np.uint32)
+    eps = NON_DYADIC[seed % 3]
+    ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, eps, P=4, B=6)
+    assert int(np.diff(pile.read_off).max()) > 256
+    assert_block_results_equal(ro, rg, f"seed {seed} eps {eps}")
+    assert ro.min_prune_margin == rg.min_prune_margin
