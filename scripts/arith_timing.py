@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """(GPU) where the time of the reference-arithmetic mode goes: kernel-family sums of one resident S1 call, canonical against arith = 1.
-usage: scripts/arith_timing.py [contigs = 250] [epsilon = 0.04] [speculate = -1]"""
+usage: scripts/arith_timing.py [contigs = 250] [epsilon = 0.04] [speculate = -1] [opt_threads = 0]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -20,6 +20,8 @@ bc, bs, be = (np.asarray(x, np.uint32) for x in (bc, bs, be))
 par = lib.make_params(eps, C["max_ploidy"], C["beam"])
 if len(sys.argv) > 3:
     ctx.set_option("speculate", int(sys.argv[3]))
+if len(sys.argv) > 4:
+    ctx.set_option("opt_threads", int(sys.argv[4]))
 for mode in (0, 1):
     ctx.set_option("arith", mode)
     ctx.phase_blocks_batch(hs, bc, bs, be, par, copy_out=False)
