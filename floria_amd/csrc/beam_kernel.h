@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                     if (act) {
                         // cells in batches of CU: the histogram pieces of a batch are requested together (one memory round trip per batch instead of one
                         // per cell), then classified one by one in the cells' order (ARITH: the running sum's order)
-                        constexpr int CU = 4;
+                        constexpr int CU = A == 2 ? 8 : 4;
                         for (uint32_t c0 = 0; c0 < tl; c0 += CU) {
                             uint32_t prs[CU], aws[CU];
                             uint64_t vs[CU][A];
