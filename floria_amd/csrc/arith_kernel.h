@@ -94,7 +94,7 @@ struct FxTable {
     }
 };
 
-// ---- Frag.positions: for every read the permutation of its cells in the set's iteration order --------------------------------------------
+// ---- Frag.positions: for every read its cells, permuted into the set's iteration order --------------------------------------------
 // One thread per read (the emulation is sequential); three tables per thread in global scratch: the growing seq_dict (a pair) and the set.
 struct CellOrderArgs {
     const ContigDev* contigs;
@@ -102,7 +102,7 @@ struct CellOrderArgs {
     const uint64_t*  cell_prefix;    // [n_contigs]   cells before contig c: where its part of `ord` starts
     uint32_t n_contigs;
     uint64_t n_reads;
-    uint32_t* ord;                   // [cells] cell index (within its contig) of the x-th cell of the read in set order
+    uint2*    ord;                   // [cells] {SNP, allele << 28 | weight} of the x-th cell of the read in set order (a permuted copy: one load per cell in the kernels)
     uint8_t*  scratch;               // [threads][3 * (ctrl_bytes + slot_bytes)]
     uint64_t  ctrl_bytes, slot_bytes;
 };
@@ -125,13 +125,13 @@ __global__ void cell_order_kernel(CellOrderArgs g) {
         FxTable set;
         set.bind(mine + 2 * tb, (uint32_t*)(mine + 2 * tb + g.ctrl_bytes), fx_buckets_for(L));
         for (uint32_t i = 0; i < seq.buckets; ++i) if (!(seq.ctrl[i] & 0x80)) set.put(seq.slot[i]);
-        uint32_t* out = g.ord + g.cell_prefix[lo] + cb;
+        uint2* out = g.ord + g.cell_prefix[lo] + cb;
         uint32_t k = 0;
         for (uint32_t i = 0; i < set.buckets; ++i) if (!(set.ctrl[i] & 0x80)) {
             const uint32_t pos = set.slot[i];
             uint32_t a = 0, b = L;                                            // the cell that holds pos (cells are strictly ascending)
             while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (cd.cell_snp[cb + mid] <= pos) a = mid; else b = mid; }
-            out[k++] = cb + a;
+            out[k++] = make_uint2(pos, cd.cell_aw[cb + a]);
         }
     }
 }

@@ -54,7 +54,7 @@ struct BeamArgs {
     unsigned long long* prof;      // [32] phase cycle counters (-DFLORIA_PROF)
     uint32_t  no_bulk;             // (tests) beam_slab_kernel: no bulk-insert shortcut, every child through the entry table and the duplicate test
     // reference-arithmetic mode (beam_kernel<A, true>, arith_kernel.h): the reads' cells in the iteration order of Frag.positions
-    const uint32_t* cell_ord;      // [cells of the call's contigs] cell index within its contig
+    const uint2*    cell_ord;      // [cells of the call's contigs] {SNP, allele << 28 | weight}, every read's cells in set order
     const uint64_t* cell_ord_off;  // [n_contigs] where a contig's part of cell_ord starts
 };
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
         const uint32_t* reads = g.bs.blk_read + roff;
         const uint32_t pos0 = g.bs.blk_pos0[b];
-        const uint32_t* ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;
+        const uint2* ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;
         double* ev = (double*)(smem + LY.off_ev[0]);       // [state][partition] running sums of the current states (ARITH)
         double* evn = (double*)(smem + LY.off_ev[1]);
 
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs g) {
                 for (uint32_t c = lane; c < BEAM_TILE; c += 64) {
                     uint32_t cc = t * BEAM_TILE + c;
                     if (cc < L) {
-                        const uint32_t ci = ARITH ? ord[cbeg + cc] : cbeg + cc;         // ARITH: the lanes walk the cells in the set's order
-                        uint32_t pr = G(cd.cell_snp)[ci] - pos0;
-                        uint32_t aq = G(cd.cell_aw)[ci];
+                        uint32_t pr, aq;
+                        if (ARITH) { const uint2 ca = ord[cbeg + cc]; pr = ca.x - pos0; aq = ca.y; }          // ARITH: the lanes walk the cells in the set's order
+                        else { pr = G(cd.cell_snp)[cbeg + cc] - pos0; aq = G(cd.cell_aw)[cbeg + cc]; }
                         uint32_t al = aq >> 28;
                         c_pos[c] = pr;
                         c_aw[c] = (al << 28) | (aq & 0x0fffffffu);

@@ -203,7 +203,7 @@ struct floria_hip_ctx {
     uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
     // scratch pools
     DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
-    const uint32_t* cur_ord = nullptr; const uint64_t* cur_ord_off = nullptr;      // ... of the S1 call in flight
+    const uint2* cur_ord = nullptr; const uint64_t* cur_ord_off = nullptr;      // ... of the S1 call in flight
     DevBuf arith_ord, arith_scr, arith_tab, arith_pool;      // reference-arithmetic mode: cell orders of the call's contigs, the order kernel's tables, prefix arrays, optimise scratch
     floria_timing timing{};
     // device-resident copy of the last S1 batch (floria_hip_hap_graph)
@@ -1400,7 +1400,7 @@ extern "C" {
 namespace {
 
 // Reference-arithmetic mode: the cells of every read of the given contigs in the iteration order of its position set (cell_order_kernel), for
-// the call in flight: ctx->cur_ord[ctx->cur_ord_off[c] + read_off[r] + x] = cell index (within contig c) of the x-th position of read r's set.
+// the call in flight: ctx->cur_ord[ctx->cur_ord_off[c] + read_off[r] + x] = {SNP, allele << 28 | weight} of the x-th position of read r's set.
 // Recomputed per call (one launch, tens of ms for a 300 M-cell batch): the mode is opt-in and nothing else of a contig depends on it.
 int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, uint32_t len_max) {
     const uint32_t n_contigs = (uint32_t)cdev.size();
@@ -1409,7 +1409,7 @@ int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::
     for (uint32_t i = 0; i < n_contigs; ++i) { pre[i + 1] = pre[i] + cdev[i].n_reads; pre[n_contigs + 1 + i] = cells; cells += n_cells[i]; }
     const uint64_t R_all = pre[n_contigs];
     int rc = ctx->arith_tab.ensure(pre.size() * 8); if (rc) return rc;
-    rc = ctx->arith_ord.ensure(4 * cells + 16); if (rc) return rc;
+    rc = ctx->arith_ord.ensure(8 * cells + 16); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->arith_tab.p, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));                                // (`pre` is pageable and local)
     if (R_all) {
@@ -1419,11 +1419,11 @@ int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::
         rc = ctx->arith_scr.ensure(3 * tb * nth); if (rc) return rc;
         fl::CellOrderArgs oa{};
         oa.contigs = d_contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
-        oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint32_t>(); oa.scratch = ctx->arith_scr.as<uint8_t>(); oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
+        oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint2>(); oa.scratch = ctx->arith_scr.as<uint8_t>(); oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
         hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
         HIPCHK(hipGetLastError());
     }
-    ctx->cur_ord = ctx->arith_ord.as<uint32_t>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+    ctx->cur_ord = ctx->arith_ord.as<uint2>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
     return 0;
 }
 

@@ -62,7 +62,7 @@ struct OptArgs {
     uint32_t* ready;
     double    thresholds[FLORIA_MAX_PLOIDY + 2];      // mec_threshold of every ploidy (host libm pow)
     // reference-arithmetic mode (optimize_kernel<.., ARITH = true>, arith_kernel.h)
-    const uint32_t* cell_ord;    // the reads' cells in the iteration order of Frag.positions
+    const uint2*    cell_ord;    // the reads' cells {SNP, allele << 28 | weight} in the iteration order of Frag.positions
     const uint64_t* cell_ord_off;
     uint64_t* fk_pool;           // [slots][ploidy*span_max]  first-insertion key of every (partition, position)
     uint64_t* sk_pool;           // [slots][sort_cap]         sort keys
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         const uint8_t* pin = g.part_in + roff;
         uint8_t* part = g.part_out + roff;
         const uint32_t ncell = span * PA;
-        const uint32_t* ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;
+        const uint2* ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;
 #ifdef FLORIA_PROF
         unsigned long long t_last = clock64();
 #endif
@@ -301,16 +301,14 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             OPT_TICK(14);    // (ARITH) key table cleared
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                 uint32_t cb = 0, len = 0, k = 0;
-                if (i < n) { read_meta(i, cb, len, k); k = part[i]; }
+                if (i < n) { read_meta(i, cb, len, k); if (!meta) k = part[i]; }
                 for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {              // (as the build pass: eight cells per lane requested before the first atomic)
-                    uint32_t ci[8], sn[8];
+                    uint32_t sn[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; ci[u] = c < len ? ord[cb + c] : 0xffffffffu; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sn[u] = ci[u] != 0xffffffffu ? G(cd.cell_snp)[ci[u]] : 0;
+                    for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; sn[u] = c < len ? ord[cb + c].x : 0u; }          // (SNP indices are 1-based: 0 = no cell)
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (ci[u] != 0xffffffffu) atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
+                        if (sn[u]) atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
                 }
                 if (sub == 0 && i < n) atomicMax(&s_lastcall[k], ((unsigned long long)i << 24) | (len - 1));
             }
@@ -416,11 +414,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         double df = 0.0;
                         constexpr int DU = 4;                                    // cells per batch: order entries, cells and histogram rows requested together
                         for (uint32_t c0 = 0; c0 < len; c0 += DU) {
-                            uint32_t ci[DU], aqs[DU], sn[DU]; uint64_t row[DU][A];
+                            uint32_t aqs[DU], sn[DU]; uint64_t row[DU][A];
 #pragma unroll
-                            for (int u = 0; u < DU; ++u) ci[u] = ord[cb + (c0 + u < len ? c0 + u : len - 1)];
-#pragma unroll
-                            for (int u = 0; u < DU; ++u) { aqs[u] = G(cd.cell_aw)[ci[u]]; sn[u] = G(cd.cell_snp)[ci[u]]; }
+                            for (int u = 0; u < DU; ++u) { const uint2 ca = ord[cb + (c0 + u < len ? c0 + u : len - 1)]; sn[u] = ca.x; aqs[u] = ca.y; }
 #pragma unroll
                             for (int u = 0; u < DU; ++u) {
                                 const uint64_t* rp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
@@ -551,6 +547,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         uint32_t from = (mvv >> 4) & 15, to = mvv & 15;
                         if (undo) { uint32_t t = from; from = to; to = t; }
                         const uint32_t r = reads[rl];
+                        if (ARITH && lane == 0 && meta) m_lk[rl] = (m_lk[rl] & 0xffffffu) | (to << 24);      // (the staged partition follows the moves: read_meta's k stays current)
                         const uint32_t cb = G(cd.read_off)[r], ce = G(cd.read_off)[r + 1];
                         for (uint32_t c = cb + lane; c < ce; c += 64) {
                             const uint32_t aq = G(cd.cell_aw)[c];

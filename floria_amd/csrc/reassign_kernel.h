@@ -36,7 +36,7 @@ struct ReassignArgs {
     double eps;
     uint32_t* queue_head;
     // reference-arithmetic mode (reassign_kernel<A, true>, arith_kernel.h): the reads' cells in the iteration order of Frag.positions
-    const uint32_t* cell_ord;
+    const uint2*    cell_ord;
     const uint64_t* cell_ord_off;
 };
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(REASSIGN_THREADS) void reassign_kernel(ReassignArgs
                 double bd = 0.0, bsame = 0.0;
                 bool have = false;
                 if constexpr (ARITH) {
-                    const uint32_t* co = g.cell_ord + g.cell_ord_off[ci];
+                    const uint2* co = g.cell_ord + g.cell_ord_off[ci];
                     for (uint32_t x0 = 0; x0 < nc; x0 += 64) {
                         const uint32_t x = x0 + lane;
                         const bool act = x < nc;
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(REASSIGN_THREADS) void reassign_kernel(ReassignArgs
                         double df = 0.0; uint64_t qs = 0;
                         if (act)
                             for (uint32_t c = cb; c < ce; ++c) {
-                                const uint32_t cx = co[c];
-                                const uint32_t aq = G(cd.cell_aw)[cx], al = aq >> 28;
-                                const uint64_t* cp = h + (uint64_t)(G(cd.cell_snp)[cx] - p0) * A;
+                                const uint2 ca = co[c];
+                                const uint32_t aq = ca.y, al = aq >> 28;
+                                const uint64_t* cp = h + (uint64_t)(ca.x - p0) * A;
                                 uint64_t mx = 0, va = 0;
 #pragma unroll
                                 for (int a = 0; a < A; ++a) { const uint64_t q = __hip_atomic_load(cp + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mx = q > mx ? q : mx; va = (a == (int)al) ? q : va; }
