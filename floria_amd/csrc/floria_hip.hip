@@ -203,6 +203,7 @@ struct floria_hip_ctx {
     uint64_t Rk1[FLORIA_MAX_PLOIDY], Rk2[FLORIA_MAX_PLOIDY];
     // scratch pools
     DevBuf state_pool, hist_pool, opt_hist, opt_dist, opt_gain, opt_key, opt_moves, misc, misc0;
+    uint32_t cur_len_max = 0;                 // longest read (cells) of the S1 call in flight
     const uint2* cur_ord = nullptr; const uint64_t* cur_ord_off = nullptr;      // ... of the S1 call in flight
     DevBuf arith_ord, arith_scr, arith_tab, arith_pool;      // reference-arithmetic mode: cell orders of the call's contigs, the order kernel's tables, prefix arrays, optimise scratch
     floria_timing timing{};
@@ -365,6 +366,7 @@ struct PloidyPlan {
     uint32_t threads = 128, opt_slots = 0;
     size_t opt_lds = 0;
     bool hl = false, opt_spec = false;
+    uint32_t fk_lds_off = 0;      // ... and the first-insertion keys as 32-bit words
     uint32_t fx_lds_off = 0;      // reference-arithmetic mode: where the emulated position maps sit in the workgroup's LDS (0 = in HBM scratch)
 };
 
@@ -452,6 +454,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
         q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0);
         if (K.arith && q.opt_lds + (size_t)p * 2 * fx_ctrl + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * 2 * fx_ctrl; }      // (the control bytes, which every probe reads)
+        if (K.arith && n_max < (1u << 20) && ctx->cur_len_max < 4096u && q.opt_lds + (size_t)p * span_max * 4 + 16 <= 60 * 1024) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += ((size_t)p * span_max * 4 + 15) & ~(size_t)15; }
         q.opt_lds += 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
         if (A == 2 && q.hl && p <= 5 && threads == 1024 && !K.opt_threads && !K.no_specialized) threads = 512;
@@ -628,7 +631,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     if (K.arith) {
                         a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
                         char* base = ctx->arith_pool.as<char>() + sl_arith * lane;
-                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off;
+                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off; a.fk_lds_off = q.fk_lds_off;
                         a.fk_pool = (uint64_t*)base; base += (uint64_t)slots * p * span_max * 8;
                         a.sk_pool = (uint64_t*)base; base += (uint64_t)slots * a.sort_cap * 8;
                         a.sp_pool = (uint32_t*)base; base += ((uint64_t)slots * a.sort_cap * 4 + 15) & ~(uint64_t)15;
@@ -1647,7 +1650,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     bs.blk_read_off = (const uint64_t*)(M0 + s_roff.off); bs.blk_read = (const uint32_t*)(M + s_rids.off); bs.n_blocks = n_blocks;
 
     // ---- reference-arithmetic mode: the iteration order of every read's position set (arith_kernel.h) --------------------------------
-    ctx->cur_ord = nullptr; ctx->cur_ord_off = nullptr;
+    ctx->cur_ord = nullptr; ctx->cur_ord_off = nullptr; ctx->cur_len_max = len_max;
     if (ctx->knobs.arith && n_contigs) {
         if (SC.n_cells.size() != n_contigs || chunked) return fail(FLORIA_E_INVALID, "internal: the reference-arithmetic mode needs resident contigs");
         int tk = T.begin(K_SEL);

@@ -70,6 +70,7 @@ struct OptArgs {
     uint8_t*  fx_pool;           // [slots][ploidy][2][fx_ctrl + fx_slot] the emulated position maps: control bytes, keys
     uint64_t  sort_cap, fx_ctrl, fx_slot;
     uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl])
+    uint32_t  fk_lds_off;        // != 0: the first-insertion keys as 32-bit words (read << 12 | cell rank: reads < 2^20, cells per read < 2^12) in LDS at this offset ([ploidy*span_max])
 };
 // fired(q): the reference's loop breaks at ploidy q (graph_processing.rs:196-251); needs mec[q-1] (q > 1) and mec[q], num_alleles[q]
 __device__ inline bool stop_rule_fires(const OptArgs& g, uint32_t b, uint32_t q) {
@@ -295,7 +296,10 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             while (M2 < M) M2 <<= 1;
             uint64_t* sk = M2 <= (uint32_t)OPT_SORT_LDS ? s_gain : g.sk_pool + (uint64_t)blockIdx.x * g.sort_cap;        // (the candidate sort's LDS arrays are free here)
             uint32_t* sp = M2 <= (uint32_t)OPT_SORT_LDS ? s_key : g.sp_pool + (uint64_t)blockIdx.x * g.sort_cap;
-            for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
+            uint32_t* fk32 = (uint32_t*)(smem + g.fk_lds_off);
+            const bool k32 = g.fk_lds_off != 0;                                 // (LDS atomics: the HBM ones were a third of this kernel's time)
+            if (k32) for (uint32_t x = tid; x < M; x += OPT_THREADS) fk32[x] = ~0u;
+            else for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
             if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; s_lastcall[tid] = 0; }
             __syncthreads();
             OPT_TICK(14);    // (ARITH) key table cleared
@@ -308,14 +312,18 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; sn[u] = c < len ? ord[cb + c].x : 0u; }          // (SNP indices are 1-based: 0 = no cell)
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (sn[u]) atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
+                        if (sn[u]) {
+                            if (k32) atomicMin(&fk32[k * span + (sn[u] - pos0)], (i << 12) | (c0 + 16 * u));
+                            else atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
+                        }
                 }
                 if (sub == 0 && i < n) atomicMax(&s_lastcall[k], ((unsigned long long)i << 24) | (len - 1));
             }
             __syncthreads();
             OPT_TICK(15);    // (ARITH) atomicMin pass
             for (uint32_t x = tid; x < M2; x += OPT_THREADS) {
-                const uint64_t f = x < M ? fk[x] : ~0ull;
+                uint64_t f = ~0ull;
+                if (x < M) { if (k32) { const uint32_t f32 = fk32[x]; f = f32 == ~0u ? ~0ull : ((uint64_t)(f32 >> 12) << 24) | (f32 & 0xfffu); } else f = fk[x]; }
                 const uint32_t k = x < M ? x / span : 0;
                 sk[x] = f == ~0ull ? 0ull : ~(((uint64_t)k << 56) | f);          // bitonic_sort puts the largest "gain" first: the smallest (partition, first insertion)
                 sp[x] = x < M ? x : 0xffffffffu;
