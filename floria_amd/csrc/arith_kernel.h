@@ -94,6 +94,81 @@ struct FxTable {
     }
 };
 
+// The same table driven by a whole WAVEFRONT (every argument and member is wave-uniform; all 64 lanes must call): a probe group's 16 control bytes are
+// one byte per lane and a ballot — what the reference's SSE2 group load and movemask do — instead of sixteen loads and a bit-gathering loop in one lane,
+// and a resize reads 64 buckets at a time.  Used where one table is replayed by a workgroup with idle lanes (optimize_kernel's position maps).
+struct FxWave {
+    uint8_t*  ctrl = nullptr;
+    uint32_t* slot = nullptr;
+    uint32_t  buckets = 0, items = 0, growth_left = 0;
+    bool      hbm = false;           // the control bytes are in HBM scratch, not LDS: one lane's stores are fenced before other lanes' loads of the next probe
+
+    __device__ void bind(uint8_t* c, uint32_t* s, uint32_t nb, uint32_t lane) {
+        ctrl = c; slot = s;
+        buckets = nb; items = 0; growth_left = fx_cap_of(nb);
+        for (uint32_t i = lane; i < (nb + FX_W) / 4; i += 64) ((uint32_t*)c)[i] = 0xffffffffu;
+        if (hbm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    __device__ uint32_t find_insert_slot(uint64_t h, uint32_t lane) const {
+        const uint32_t mask = buckets - 1;
+        uint32_t pos = (uint32_t)h & mask, stride = 0;
+        for (;;) {
+            const uint32_t c = lane < FX_W ? ctrl[pos + lane] : 0u;
+            const uint32_t free_bits = (uint32_t)__ballot((c & 0x80u) != 0u) & 0xffffu;
+            if (free_bits) {
+                uint32_t idx = (pos + (uint32_t)__builtin_ctz(free_bits)) & mask;
+                if (buckets < FX_W) {                        // table smaller than a group: a hit in the mirrored tail means the real slot is in group 0
+                    const uint32_t at = ctrl[idx];
+                    if (!(at & 0x80u)) {
+                        const uint32_t c0 = lane < FX_W ? ctrl[lane] : 0u;
+                        idx = (uint32_t)__builtin_ctz((uint32_t)__ballot((c0 & 0x80u) != 0u) & 0xffffu);
+                    }
+                }
+                return idx;
+            }
+            stride += FX_W; pos = (pos + stride) & mask;
+        }
+    }
+    __device__ void put(uint32_t key, uint32_t lane) {
+        const uint64_t h = FxTable::hash_of(key);
+        const uint32_t idx = find_insert_slot(h, lane);
+        if (lane == 0) {
+            const uint8_t h2 = (uint8_t)(h >> 57);
+            ctrl[idx] = h2; ctrl[((idx - FX_W) & (buckets - 1)) + FX_W] = h2;
+            slot[idx] = key;
+        }
+        if (hbm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        --growth_left; ++items;
+    }
+    __device__ void resize(uint32_t capacity, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+        FxWave n;
+        n.hbm = hbm;
+        n.bind(spare_c, spare_s, fx_buckets_for(capacity), lane);
+        for (uint32_t i0 = 0; i0 < buckets; i0 += 64) {
+            const bool in = i0 + lane < buckets;
+            const uint32_t c = in ? ctrl[i0 + lane] : 0xffu;
+            const uint32_t key = in ? slot[i0 + lane] : 0u;
+            uint64_t full = __ballot(!(c & 0x80u));
+            while (full) {                                   // the old table's keys in bucket order
+                const int l = __builtin_ctzll(full);
+                full &= full - 1;
+                n.put((uint32_t)__shfl((int)key, l), lane);
+            }
+        }
+        spare_c = ctrl; spare_s = slot;
+        *this = n;
+    }
+    __device__ void reserve(uint32_t additional, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+        if (additional <= growth_left) return;
+        const uint32_t new_items = items + additional, full = fx_cap_of(buckets);
+        resize(new_items > full + 1 ? new_items : full + 1, spare_c, spare_s, lane);
+    }
+    __device__ void insert_new(uint32_t key, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+        if (growth_left == 0) reserve(1, spare_c, spare_s, lane);
+        put(key, lane);
+    }
+};
+
 // ---- Frag.positions: for every read its cells, permuted into the set's iteration order --------------------------------------------
 // One thread per read (the emulation is sequential); three tables per thread in global scratch: the growing seq_dict (a pair) and the set.
 struct CellOrderArgs {

@@ -167,6 +167,7 @@ struct Knobs {
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
+    uint32_t arith_hbm = 0;       // (tests) reference arithmetic: position-map tables and first-insertion keys in HBM scratch even where they fit into LDS
     uint32_t arith = 0;           // 1 = the reference's own running f64 sums in its own orders (arith_kernel.h; slower kernels), 0 = the canonical (Q24, #eps) form
 };
 
@@ -453,8 +454,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global;
         const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
         q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0);
-        if (K.arith && q.opt_lds + (size_t)p * 2 * fx_ctrl + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * 2 * fx_ctrl; }      // (the control bytes, which every probe reads)
-        if (K.arith && n_max < (1u << 20) && ctx->cur_len_max < 4096u && q.opt_lds + (size_t)p * span_max * 4 + 16 <= 60 * 1024) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += ((size_t)p * span_max * 4 + 15) & ~(size_t)15; }
+        if (K.arith && !K.arith_hbm && q.opt_lds + (size_t)p * 2 * fx_ctrl + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * 2 * fx_ctrl; }      // (the control bytes, which every probe reads)
+        if (K.arith && !K.arith_hbm && n_max < (1u << 20) && ctx->cur_len_max < 4096u && q.opt_lds + (size_t)p * span_max * 4 + 16 <= 60 * 1024) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += ((size_t)p * span_max * 4 + 15) & ~(size_t)15; }
         q.opt_lds += 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
         if (A == 2 && q.hl && p <= 5 && threads == 1024 && !K.opt_threads && !K.no_specialized) threads = 512;
@@ -843,6 +844,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "no_bulk") K.no_bulk = value != 0;
+    else if (k == "arith_hbm") K.arith_hbm = value != 0;
     else if (k == "arith") { if (value < 0 || value > 1) return fail(FLORIA_E_INVALID, "arith: 0 canonical | 1 the reference's running sums"); K.arith = (uint32_t)value; }
     else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));

@@ -333,8 +333,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             OPT_TICK(10);    // (ARITH) first-insertion keys
             bitonic_sort(sk, sp, M2, tid, OPT_THREADS);
             OPT_TICK(11);    // (ARITH) sort
-            if ((uint32_t)tid < p) {
-                const uint32_t k = tid;
+            for (uint32_t k = wid; k < p; k += OPT_THREADS / 64) {            // a wavefront per partition: the table is driven by all 64 lanes (arith_kernel.h: FxWave)
                 uint32_t start = 0;
                 for (uint32_t q = 0; q < k; ++q) start += s_cntk[q];
                 const uint32_t D = s_cntk[k];
@@ -343,45 +342,52 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                 uint8_t* c0 = g.fx_lds_off ? smem + g.fx_lds_off + (uint64_t)k * 2 * g.fx_ctrl : gmem;
                 uint8_t* spare_c = g.fx_lds_off ? c0 + g.fx_ctrl : gmem + fxb;
                 uint32_t* spare_s = (uint32_t*)(gmem + fxb + g.fx_ctrl);
-                FxTable t;
-                if (D) t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1));
-                for (uint32_t d = 0; d < D; ++d) t.insert_new(sp[start + d] - k * span + pos0, spare_c, spare_s);
-                if (D && t.growth_left == 0 && (~sk[start + D - 1] & 0x00ffffffffffffffull) != s_lastcall[k]) t.reserve(1, spare_c, spare_s);     // a later insert call of a position already there
+                FxWave t;
+                t.hbm = g.fx_lds_off == 0;
+                if (D) t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane);
+                for (uint32_t d0 = 0; d0 < D; d0 += 64) {                    // 64 positions of the sorted first-insertion list at a time
+                    const uint32_t mine = d0 + lane < D ? sp[start + d0 + lane] - k * span + pos0 : 0u;
+                    const uint32_t cnt = D - d0 < 64u ? D - d0 : 64u;
+                    for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
+                }
+                if (D && t.growth_left == 0 && (~sk[start + D - 1] & 0x00ffffffffffffffull) != s_lastcall[k]) t.reserve(1, spare_c, spare_s, lane);     // a later insert call of a position already there
 #ifdef FLORIA_PROF
                 if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's replay
 #endif
+                // the buckets in order, 64 at a time: every lane prepares its bucket's terms, then they are added one by one (the sum is the one sequential thing here)
                 double ef = 0.0;
                 uint64_t good = 0;
                 const uint64_t one = phred ? ONE_Q24 : 1ull;
                 const double scale = phred ? 0x1p-24 : 1.0;
-                constexpr int WU = 8;                                            // buckets per batch: control bytes, keys and histogram rows requested together
-                for (uint32_t i0 = 0; i0 < t.buckets; i0 += WU) {
-                    bool full[WU]; uint32_t key[WU]; uint64_t row[WU][A];
+                for (uint32_t i0 = 0; i0 < t.buckets; i0 += 64) {
+                    const bool in = i0 + lane < t.buckets;
+                    const bool full = in && !(t.ctrl[in ? i0 + lane : 0] & 0x80);
+                    const uint32_t key = t.slot[in ? i0 + lane : 0];
+                    const uint64_t* cp = hist + (uint64_t)(full ? key - pos0 : 0u) * PA + k * A;
+                    uint64_t q[A];
 #pragma unroll
-                    for (int u = 0; u < WU; ++u) { const bool in = i0 + u < t.buckets; full[u] = in && !(t.ctrl[in ? i0 + u : 0] & 0x80); key[u] = t.slot[in ? i0 + u : 0]; }
+                    for (int al = 0; al < A; ++al) { const uint64_t v = cp[al]; q[al] = phred ? (v & QMASK44) : (v >> CNT_SHIFT); }
 #pragma unroll
-                    for (int u = 0; u < WU; ++u) {
-                        const uint64_t* cp = hist + (uint64_t)(full[u] ? key[u] - pos0 : 0u) * PA + k * A;
+                    for (int x = 1; x < A; ++x)                                  // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
 #pragma unroll
-                        for (int al = 0; al < A; ++al) row[u][al] = cp[al];
-                    }
+                        for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
+                    double term[A - 1];
 #pragma unroll
-                    for (int u = 0; u < WU; ++u) {
-                        if (!full[u]) continue;
-                        uint64_t q[A];
+                    for (int x = 0; x + 1 < A; ++x) term[x] = (double)q[x] * scale;
+                    const bool low = q[A - 1] <= one;
+                    good += full ? q[A - 1] : 0ull;
+                    uint64_t fm = __ballot(full);
+                    const uint64_t lowm = __ballot(full && low);
+                    while (fm) {
+                        const int l = __builtin_ctzll(fm);
+                        fm &= fm - 1;
 #pragma unroll
-                        for (int al = 0; al < A; ++al) q[al] = phred ? (row[u][al] & QMASK44) : (row[u][al] >> CNT_SHIFT);
-#pragma unroll
-                        for (int x = 1; x < A; ++x)                              // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
-#pragma unroll
-                            for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
-#pragma unroll
-                        for (int x = 0; x + 1 < A; ++x) ef += (double)q[x] * scale;   // :248-250 all but the last
-                        good += q[A - 1];
-                        if (q[A - 1] <= one) ef += g.eps;                         // :251-253
+                        for (int x = 0; x + 1 < A; ++x) ef += shfl_f64(term[x], l);          // :248-250 all but the last
+                        if ((lowm >> l) & 1ull) ef += g.eps;                               // :251-253
                     }
                 }
-                s_errf[k] = ef; s_goodq[k] = good;
+                good = wave_sum_u64(good);
+                if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
             }
             __syncthreads();
             OPT_TICK(12);    // (ARITH) replay + walk, slowest partition

@@ -153,7 +153,7 @@ def test_config4_64_contigs_in_reference_arithmetic(arith, hip_lib, oracle_mod):
         h.free()
 
 
-@pytest.mark.parametrize("knob,value", [("opt_global", 1), ("speculate", 0), ("speculate", 1), ("speculate", 2), ("opt_threads", 512), ("opt_threads", 1024), ("slots", 96), ("groups", 2)])
+@pytest.mark.parametrize("knob,value", [("arith_hbm", 1), ("opt_global", 1), ("speculate", 0), ("speculate", 1), ("speculate", 2), ("opt_threads", 512), ("opt_threads", 1024), ("slots", 96), ("groups", 2)])
 def test_launch_knobs_do_not_change_reference_arithmetic_results(arith, hip_lib, oracle_mod, knob, value):
     """Histogram in HBM instead of LDS, every stage plan, other workgroup sizes, a small persistent grid: the same bits (the oracle comparison of the
     default plan is test_config_slices_in_reference_arithmetic)."""
