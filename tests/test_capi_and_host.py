@@ -112,3 +112,19 @@ def test_rust_binding_sketch_covers_every_declared_symbol():
     bound = set(re.findall(r"\bpub fn (floria_hip_[a-z0-9_]+)\s*\(", sketch))
     assert declared - bound == set(), f"not bound in INTEGRATION.md: {sorted(declared - bound)}"
     assert bound - declared == set(), f"bound but not declared: {sorted(bound - declared)}"
+
+
+def test_header_documents_every_option_key():
+    # floria_hip_set_option takes string keys: the header's comment is the only place a host learns them.  Every key the library accepts must be named there
+    # (and the one key that changes results, "arith", must be described as such).
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "floria_amd", "csrc", "floria_hip.hip")).read()
+    body = src[src.index("int floria_hip_set_option("):]
+    body = body[:body.index("\n}\n")]
+    keys = set(re.findall(r'k == "([a-z_0-9]+)"', body))
+    assert {"arith", "speculate", "groups"} <= keys
+    header = open(os.path.join(root, "include", "floria_hip.h")).read()
+    doc = header[header.index('The one option that selects WHICH function is computed'):header.index("int  floria_hip_set_option(")]
+    missing = sorted(k for k in keys if f'"{k}"' not in doc)
+    assert not missing, f"option keys the header does not mention: {missing}"
