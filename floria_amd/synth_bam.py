@@ -93,6 +93,7 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
         segs = [(int(lay["start"][r]), min(int(lay["end"][r]), clen))]
         if paired:
             segs.append((int(lay["start2"][r]), min(int(lay["end2"][r]), clen)))
+        segs = [(min(b, clen - 1), e) for b, e in segs]       # (a mate that starts beyond the contig's last base is one base at its end: a record with CIGAR 1M needs one base of SEQ)
         name = f"{contig.name}_r{r}"
         lost = set()
         recs_r, quals_r = [], []
