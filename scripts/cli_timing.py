@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.5)
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
     ap.add_argument("--sub-rate", type=float, default=0.0, help="substitution errors in the reads (what realign has to absorb)")
+    ap.add_argument("--arith-compare", action="store_true", help="only: the batched flow at -e 0.04 with --arith canonical against --arith reference (the default there)")
     a = ap.parse_args()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "floria_amd", "host"), "floria-hip"], stdout=subprocess.DEVNULL)
     exe = os.path.join(ROOT, "floria_amd", "host", "floria-hip")
@@ -33,8 +34,13 @@ def main():
     print(f"data set: {a.contigs} contigs, {sum(c.pileup.n_reads for c in cs)} reads, {sum(len(c.snp_pos) for c in cs)} SNPs, "
           f"BAM {os.path.getsize(prefix + '.bam') >> 20} MiB, written in {time.time() - t:.1f}s; host cores {os.cpu_count()}", flush=True)
     base = [exe, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-e", "0.03125", "-l", "10000", "--snp-count-filter", "50"]
-    for label, extra in (("batched", ["-t", str(a.threads)]), ("batched, 1 thread", ["-t", "1"]), ("one contig per batch", ["-t", str(a.threads), "--batch-contigs", "1"]),
-                         ("ingest only: realign DP on the host", ["-t", str(a.threads), "--ingest-only"]), ("ingest only, 1 thread", ["-t", "1", "--ingest-only"])):
+    runs = (("batched", ["-t", str(a.threads)]), ("batched, 1 thread", ["-t", "1"]), ("one contig per batch", ["-t", str(a.threads), "--batch-contigs", "1"]),
+            ("ingest only: realign DP on the host", ["-t", str(a.threads), "--ingest-only"]), ("ingest only, 1 thread", ["-t", "1", "--ingest-only"]))
+    if a.arith_compare:
+        base[base.index("-e") + 1] = "0.04"
+        runs = (("e 0.04, canonical arithmetic", ["-t", str(a.threads), "--arith", "canonical"]), ("e 0.04, reference arithmetic", ["-t", str(a.threads), "--arith", "reference"]),
+                ("e 0.04, canonical arithmetic (again)", ["-t", str(a.threads), "--arith", "canonical"]), ("e 0.04, reference arithmetic (again)", ["-t", str(a.threads), "--arith", "reference"]))
+    for label, extra in runs:
         out = os.path.join(tmp, "o_" + label.replace(" ", "_").replace(",", ""))
         t = time.time()
         r = subprocess.run(base + ["-o", out] + extra, capture_output=True, text=True)
