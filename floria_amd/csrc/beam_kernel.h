@@ -56,6 +56,12 @@ struct BeamArgs {
     // reference-arithmetic mode (beam_kernel<A, true>, arith_kernel.h): the reads' cells in the iteration order of Frag.positions
     const uint2*    cell_ord;      // [cells of the call's contigs] {SNP, allele << 28 | weight}, every read's cells in set order
     const uint64_t* cell_ord_off;  // [n_contigs] where a contig's part of cell_ord starts
+    // per-block dataflow for the last ploidy stage (beam_slab_kernel<.., SPEC = true> only): the launch runs BESIDE the optimise launch of ploidy
+    // wait_tried and a job starts when that launch has decided its block — tried[b] >= wait_tried, published with release order after blk_done[b]
+    // (optimize_kernel.h) — graph_processing.rs:132-252 runs a block's ploidies back to back.  0 = the launch follows the stop rule of every block.
+    const uint32_t* tried;
+    uint32_t  wait_tried;
+    uint32_t  wait_ticks;          // give up waiting after this many ticks of the 100-MHz wall clock and run the job whether it is needed or not
 };
 
 __host__ __device__ inline uint32_t beam_hist_off(uint32_t i, uint32_t LM, uint32_t B) {

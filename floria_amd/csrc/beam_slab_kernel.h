@@ -277,6 +277,7 @@ void beam_slab_kernel(BeamArgs g) {
     unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0, c_boring = 0, c_heapkeep = 0;
 #endif
 
+    bool gave_up = false;
     for (;;) {
         uint32_t job = 0;
         if (lane == 0) job = atomicAdd(GCOLD(queue_head), 1u);
@@ -284,7 +285,27 @@ void beam_slab_kernel(BeamArgs g) {
         if (job >= GCOLD(n_jobs)) break;
         const uint32_t b = uni(GCOLD(job_block)[job]);
         if (GCOLD(blk_done)[b]) continue;
-        if (SPEC && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
+        if (SPEC && GCOLD(wait_tried)) {
+            // per-block dataflow (last ploidy stage): the optimise launch of the ploidy below runs beside this one and decides block b — done, or tried[b] = that
+            // ploidy.  One lane polls (agent-scope loads, a sleep between two), bounded by the wall clock: a job that ran without being needed is ignored.
+            const uint32_t want = GCOLD(wait_tried);
+            const unsigned long long t0 = wall_clock64(), tmax = gave_up ? 0ull : (unsigned long long)GCOLD(wait_ticks);
+            uint32_t st = 0;            // 1 = decided: go on, 2 = decided: done, 3 = waited in vain (from here on this wave does not wait)
+            for (;;) {
+                if (lane == 0) {
+                    const uint32_t tr = __hip_atomic_load(&GCOLD(tried)[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t dn = __hip_atomic_load(&GCOLD(blk_done)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st = dn ? 2u : (tr >= want ? 1u : 0u);
+                    if (st == 0 && wall_clock64() - t0 >= tmax) st = 3;
+                }
+                st = uni(__shfl(st, 0));
+                if (st) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            if (st == 2) continue;
+            if (st == 3) gave_up = true;
+        }
+        if (SPEC && GCOLD(stop_at) && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
         bool dropped = false;
         min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = GCOLD_BS(contigs)[GCOLD_BS(blk_contig)[b]];
@@ -346,7 +367,7 @@ void beam_slab_kernel(BeamArgs g) {
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            if (SPEC && (i & 63u) == 63u && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
+            if (SPEC && (i & 63u) == 63u && GCOLD(stop_at) && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
             const uint32_t cbeg = cm_cur.cbeg, L = cm_cur.L;
             const uint32_t first_rel = sm_cur.first - pos0;
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);

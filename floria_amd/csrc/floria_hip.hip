@@ -169,6 +169,9 @@ struct Knobs {
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
     uint32_t arith_hbm = 0;       // (tests) reference arithmetic: position-map tables and first-insertion keys in HBM scratch even where they fit into LDS
     uint32_t arith = 0;           // 1 = the reference's own running f64 sums in its own orders (arith_kernel.h; slower kernels), 0 = the canonical (Q24, #eps) form
+    int32_t  tail_overlap = 0;    // one ploidy per stage: the LAST ploidy's beam launch runs beside the optimise launch of the ploidy below, every job waiting for its block's
+                                  // stop rule (run_phase): 0 off (default: measured level) | 1 on
+    uint32_t tail_waves = 2;      // ... with this many waves per CU
 };
 
 struct Arena;
@@ -187,6 +190,8 @@ struct floria_hip_ctx {
     hipStream_t gstream_low[MAX_LANES] = {};      // speculative stages: the lanes of ploidy >= 4 (dispatched after the ploidies every block needs)
     hipEvent_t ev_fork[MAX_LANES] = {}, ev_join[MAX_LANES] = {};
     hipEvent_t ev_gate[MAX_GROUPS] = {};       // speculative stages: the beam search of ploidy 2 of group g has finished (ploidies >= 4 start behind it)
+    hipStream_t tstream[MAX_GROUPS] = {};      // the last ploidy's beam launch of group g when it runs beside the optimise launch below it (Knobs::tail_overlap)
+    hipEvent_t ev_tail[MAX_GROUPS] = {}, ev_tail_join[MAX_GROUPS] = {};
     hipStream_t copy_stream = nullptr;        // read-id lists go back to the host while the launch loop runs
     hipEvent_t ev_rids = nullptr;
     hipEvent_t ev_chunk[MAX_GROUPS + 1] = {};  // floria_hip_phase_pileups_batch: chunk g of the cell arrays has landed and is flattened
@@ -532,6 +537,88 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
     // chunked inputs: group g's first lane also waits until chunk g's cells have arrived and been flattened
     if (chunk_ev) for (uint32_t g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(ls[g * W], chunk_ev[g], 0));
     const uint64_t* H = ctx->d_hash.as<uint64_t>();
+    // Per-block dataflow for the tail of a one-ploidy-per-stage plan (graph_processing.rs:132-252 runs a block's ploidies back to back and stops): few blocks reach
+    // the last ploidy, so its beam launch is a handful of lone-wave chains as long as the longest block — behind the optimise launch of the ploidy below, which the
+    // same long blocks keep waiting.  With tail_p != 0 that beam launch is queued on a stream of its own right behind the beam launch of tail_p - 1: it runs BESIDE
+    // the optimise launch, a small persistent grid whose jobs each wait for their block's stop rule (tried[b] >= tail_p - 1 or blk_done[b], beam_slab_kernel.h), in
+    // the order the optimise launch works through them; it writes its partitions into a plane of its own.  Nothing waits for this launch but the last optimise launch.
+    uint32_t tail_p = 0;
+    {
+        const bool want = K.tail_overlap > 0;      // (measured on config 4: no gain — the optimise launch it hides is 1.2-1.7 ms when the chip is otherwise idle, and the waiting grid costs as much: profiles/r04_tail_overlap_ab.txt)
+        if (want && W == 1 && stages.size() >= 3 && P >= 3 && stages.back().size() == 1 && stages.back()[0] == P && stages[stages.size() - 2][0] == P - 1
+            && plan[P].slab && !plan[P].wide && !plan[P].shortcut && !plan[P - 1].shortcut && !K.arith && ctx->hw_queues >= 5 && G <= floria_hip_ctx::MAX_GROUPS) tail_p = P;
+    }
+    uint8_t* const tail_part = d_beam_part + (uint64_t)W * (tot_reads + 16);
+    // one beam launch of group g: ploidy p on stream st (scratch slice `lane`), partitions into lane_part.  wait_tried != 0: the launch of the last ploidy that runs
+    // beside the optimise launch of ploidy wait_tried (per-block dataflow, below)
+    auto beam_launch = [&](const std::vector<uint32_t>& stage, uint32_t g, uint32_t nj, const uint32_t* gjobs, uint32_t p, uint32_t lane, hipStream_t st, uint32_t* gqueue,
+                           uint8_t* lane_part, uint32_t wait_tried) -> int {
+        const PloidyPlan& q = plan[p];
+        const uint32_t slots_full = std::min(q.beam_slots, nj);
+        fl::BeamArgs a{};
+        a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
+        a.queue_head = gqueue; a.blk_done = d_done; a.stop_at = stage.size() > 1 && !wait_tried ? d_stop : nullptr;
+        a.tried = d_tried; a.wait_tried = wait_tried; a.wait_ticks = 2000000u;      // (20 ms: longer than any optimise launch takes)
+        a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane); a.state_stride = q.state_bytes;
+        a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
+        a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
+        a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
+        a.ln_eps = (float)std::log(prm->epsilon); a.ln_1meps = (float)std::log(1.0 - prm->epsilon);
+        a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
+        a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
+        a.prof = (unsigned long long*)(d_diag + 4);
+        a.no_bulk = K.no_bulk;
+        a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
+        auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
+            return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
+        };
+        const bool gated = !wait_tried && stage.size() > 1 && ((stage[0] <= 2 && p >= 4) || (stage[0] == 4 && p >= 5));      // (ungated ploidy 4 / 5 measured worse: 24.3 against 22.5 ms for the 250-contig shard)
+        // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
+        // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
+        const uint32_t slots = wait_tried ? std::max<uint32_t>(1, std::min(slots_full, (uint32_t)ctx->n_cu * K.tail_waves)) : gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
+        auto fire = [&](uint32_t slots) -> int {
+            if (K.arith) {
+                HIPCHK(big_lds((const void*)fl::beam_kernel<A, true>, q.LY.total));
+                hipLaunchKernelGGL((fl::beam_kernel<A, true>), dim3(slots), dim3(64), q.LY.total, st, a);
+            } else if (q.wide) {
+                if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
+                else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(slots), dim3(64), q.WL.total, st, a); }
+            } else if (q.slab) {
+                const bool sp = a.stop_at != nullptr || wait_tried != 0;      // speculative stage: the instances that can drop a job
+                if (any_q0) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                              else hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                else if (q.beam_spec && p == 2) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                  else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                else if (q.beam_spec && p == 3) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                  else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                else if (q.beam_spec && p == 4) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                  else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                else if (q.beam_spec && p == 5) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                                                  else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
+                else if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, false, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
+                else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), q.SL.total, st, a);
+            } else {
+                HIPCHK(big_lds((const void*)fl::beam_kernel<A>, q.LY.total));
+                hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), q.LY.total, st, a);
+            }
+            return 0;
+        };
+        if (gated) {          // ploidies few blocks need start when ploidy 2 has left the chip: by the time their jobs run, the stop rule of most
+                              // blocks is known and the jobs are dropped at dequeue or within 64 reads
+            if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_gate[g], 0));
+        }
+        const int t = T.begin(K_BEAM, st);
+        { const int frc = fire(slots); if (frc) return frc; }
+        T.end(t);
+        HIPCHK(hipGetLastError());
+        ctx->timing.beam_launches++;
+        if (!wait_tried && stage.size() > 1 && ((stage[0] <= 2 && p == 2) || (stage[0] == 4 && p == 4))) {          // (the beam search of ploidy 2 opens the gate; ploidy 3 measured worse)
+            if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
+        }
+        return 0;
+    };
     for (size_t si = 0; si < stages.size(); ++si) {
         const std::vector<uint32_t>& stage = stages[si];
         for (uint32_t g = 0; g < G; ++g) {
@@ -552,65 +639,12 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                                                                                     // loop (a memset between persistent launches is a fill KERNEL that waits for wave slots)
                 uint8_t* lane_part = d_beam_part + (uint64_t)j * (tot_reads + 16);
                 // ---- beam search -----------------------------------------------------------------------------------------
-                if (!q.shortcut) {
-                    const uint32_t slots_full = std::min(q.beam_slots, nj);
-                    fl::BeamArgs a{};
-                    a.bs = bs; a.job_block = gjobs; a.n_jobs = nj; a.ploidy = p; a.beam = B; a.span_max = span_max; a.n_max = n_max;
-                    a.queue_head = gqueue; a.blk_done = d_done; a.stop_at = stage.size() > 1 ? d_stop : nullptr;
-                    a.state_pool = (uint64_t*)(ctx->state_pool.as<char>() + sl_state * lane); a.state_stride = q.state_bytes;
-                    a.hist_pool = (uint32_t*)(ctx->hist_pool.as<char>() + sl_hist * lane); a.hist_stride = q.hist_stride;
-                    a.binom_tab = ctx->d_binom.as<double>(); a.binom_nmax = ctx->binom_nmax;
-                    a.eps = prm->epsilon; a.div_factor = DIV_FACTOR; a.cutoff = cutoff;
-                    a.ln_eps = (float)std::log(prm->epsilon); a.ln_1meps = (float)std::log(1.0 - prm->epsilon);
-                    a.Rq1 = H; a.Rp1 = H + ctx->hash_len; a.Rq2 = H + 2ull * ctx->hash_len; a.Rp2 = H + 3ull * ctx->hash_len;
-                    a.part_out = lane_part; a.job_margin = d_margin; a.max_ploidy = P; a.diag = d_diag; a.steps_done = d_steps;
-                    a.prof = (unsigned long long*)(d_diag + 4);
-                    a.no_bulk = K.no_bulk;
-                    a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
-                    auto big_lds = [&](const void* kern, uint32_t bytes) -> hipError_t {
-                        return bytes > 48 * 1024 ? hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
-                    };
-                    const bool gated = stage.size() > 1 && ((stage[0] <= 2 && p >= 4) || (stage[0] == 4 && p >= 5));      // (ungated ploidy 4 / 5 measured worse: 24.3 against 22.5 ms for the 250-contig shard)
-                    // ... and with a smaller persistent grid: the optimise workgroups of the lower ploidies (whose results decide which of these
-                    // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
-                    const uint32_t slots = gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
-                    if (gated) {          // ploidies few blocks need start when ploidy 2 has left the chip: by the time their jobs run, the stop rule of most
-                                          // blocks is known and the jobs are dropped at dequeue or within 64 reads
-                        if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
-                        HIPCHK(hipStreamWaitEvent(st, ctx->ev_gate[g], 0));
-                    }
-                    int t = T.begin(K_BEAM, st);
-                    if (K.arith) {
-                        HIPCHK(big_lds((const void*)fl::beam_kernel<A, true>, q.LY.total));
-                        hipLaunchKernelGGL((fl::beam_kernel<A, true>), dim3(slots), dim3(64), q.LY.total, st, a);
-                    } else if (q.wide) {
-                        if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
-                        else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false>), dim3(slots), dim3(64), q.WL.total, st, a); }
-                    } else if (q.slab) {
-                        const bool sp = a.stop_at != nullptr;      // speculative stage: the instances that can drop a job
-                        if (any_q0) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, true, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                                      else hipLaunchKernelGGL((fl::beam_slab_kernel<A, true>), dim3(slots), dim3(64), q.SL.total, st, a); }
-                        else if (q.beam_spec && p == 2) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 2, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
-                        else if (q.beam_spec && p == 3) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 3, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
-                        else if (q.beam_spec && p == 4) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 4, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
-                        else if (q.beam_spec && p == 5) { if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                                                          else hipLaunchKernelGGL((fl::beam_slab_kernel<2, false, 5, 10>), dim3(slots), dim3(64), q.SL.total, st, a); }
-                        else if (sp) hipLaunchKernelGGL((fl::beam_slab_kernel<A, false, 0, 0, true>), dim3(slots), dim3(64), q.SL.total, st, a);
-                        else hipLaunchKernelGGL((fl::beam_slab_kernel<A, false>), dim3(slots), dim3(64), q.SL.total, st, a);
-                    } else {
-                        HIPCHK(big_lds((const void*)fl::beam_kernel<A>, q.LY.total));
-                        hipLaunchKernelGGL(fl::beam_kernel<A>, dim3(slots), dim3(64), q.LY.total, st, a);
-                    }
-                    T.end(t);
-                    HIPCHK(hipGetLastError());
-                    ctx->timing.beam_launches++;
-                    if (stage.size() > 1 && ((stage[0] <= 2 && p == 2) || (stage[0] == 4 && p == 4))) {          // (the beam search of ploidy 2 opens the gate; ploidy 3 measured worse)
-                        if (!ctx->ev_gate[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate[g], hipEventDisableTiming));
-                        HIPCHK(hipEventRecord(ctx->ev_gate[g], st));
-                    }
+                const bool tail_here = tail_p && p == tail_p;          // this ploidy's beam launch was queued with the stage below: join it
+                if (tail_here) { HIPCHK(hipStreamWaitEvent(st, ctx->ev_tail_join[g], 0)); lane_part = tail_part; }
+                else if (!q.shortcut) { const int brc = beam_launch(stage, g, nj, gjobs, p, lane, st, gqueue, lane_part, 0); if (brc) return brc; }
+                if (tail_p && p + 1 == tail_p) {                         // the fork point: behind this ploidy's beam launch, before its optimise launch
+                    if (!ctx->ev_tail[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_tail[g], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(ctx->ev_tail[g], st));
                 }
                 // ---- optimise + MEC stats ------------------------------------------------------------------------------
                 {
@@ -660,6 +694,14 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     T.end(t);
                     if (le != hipSuccess) return fail(FLORIA_E_DEVICE, std::string("optimize_kernel launch: ") + hipGetErrorString(le));
                     ctx->timing.optimize_launches++;
+                }
+                if (tail_p && p + 1 == tail_p) {          // (queued AFTER the optimise launch it depends on: streams that share a hardware queue then still make progress)
+                    if (!ctx->tstream[g]) HIPCHK(hipStreamCreateWithFlags(&ctx->tstream[g], hipStreamNonBlocking));
+                    if (!ctx->ev_tail_join[g]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_tail_join[g], hipEventDisableTiming));
+                    HIPCHK(hipStreamWaitEvent(ctx->tstream[g], ctx->ev_tail[g], 0));
+                    const int brc = beam_launch(stages.back(), g, nj, gjobs, tail_p, lane, ctx->tstream[g], d_queue + 2 * ((size_t)lane * P + (tail_p - 1)), tail_part, p);
+                    if (brc) return brc;
+                    HIPCHK(hipEventRecord(ctx->ev_tail_join[g], ctx->tstream[g]));
                 }
             }
             // join the stage's extra lanes, then the stop rule for the stage's ploidies in ascending order (graph_processing.rs:198-251)
@@ -786,11 +828,14 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(3, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
+        if (const char* v = getenv("FLORIA_HIP_TAIL_OVERLAP")) K.tail_overlap = std::max(-1, std::min(1, atoi(v)));
+        if (const char* v = getenv("FLORIA_HIP_TAIL_WAVES")) K.tail_waves = (uint32_t)std::max(1, std::min(16, atoi(v)));
         if (const char* v = getenv("FLORIA_HIP_SPEC_GATE_DIV")) K.spec_gate_div = (uint32_t)std::max(1, std::min(16, atoi(v)));
         if (const char* v = getenv("FLORIA_HIP_STAGE_THREADS")) c->stage_threads = (uint32_t)std::max(1, std::min(16, atoi(v)));
         else c->stage_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     }
     c->hw_queues = probe_hw_queues(c);
+    if (const char* v = getenv("FLORIA_HIP_HW_QUEUES")) c->hw_queues = (uint32_t)std::max(1, std::min(64, atoi(v)));      // (measurements under a profiler, which slows the probe's launches down)
     if (c->knobs.trace) fprintf(stderr, "[floria_hip] device %d: %u streams run side by side\n", device, c->hw_queues);
     if (c->hw_queues < 5) {      // (the probe reads 6 with GPU_MAX_HW_QUEUES=12 - two rounds of its 12 spins - and 3-4 with HIP's default of 4 queues - three or four rounds)
         static std::atomic<bool> said{false};
@@ -814,6 +859,9 @@ void floria_hip_destroy(floria_hip_ctx* c) {
         if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
         if (c->gstream_low[g]) (void)hipStreamDestroy(c->gstream_low[g]);
         if (g < floria_hip_ctx::MAX_GROUPS && c->ev_gate[g]) (void)hipEventDestroy(c->ev_gate[g]);
+        if (g < floria_hip_ctx::MAX_GROUPS && c->ev_tail[g]) (void)hipEventDestroy(c->ev_tail[g]);
+        if (g < floria_hip_ctx::MAX_GROUPS && c->ev_tail_join[g]) (void)hipEventDestroy(c->ev_tail_join[g]);
+        if (g < floria_hip_ctx::MAX_GROUPS && c->tstream[g]) (void)hipStreamDestroy(c->tstream[g]);
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
         if (c->ev_fork[g]) (void)hipEventDestroy(c->ev_fork[g]);
     }
@@ -845,6 +893,8 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "no_bulk") K.no_bulk = value != 0;
+    else if (k == "tail_overlap") { if (value < -1 || value > 1) return fail(FLORIA_E_INVALID, "tail_overlap: 0 | 1"); K.tail_overlap = (int32_t)value; }
+    else if (k == "tail_waves") K.tail_waves = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "arith_hbm") K.arith_hbm = value != 0;
     else if (k == "arith") { if (value < 0 || value > 1) return fail(FLORIA_E_INVALID, "arith: 0 canonical | 1 the reference's running sums"); K.arith = (uint32_t)value; }
     else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)
@@ -1627,7 +1677,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
 
     // ---- device staging of the per-call arrays ----------------------------------------------------------------------
     cursor = 0;
-    const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg((uint64_t)stage_w * (tot + 16)),
+    const Seg s_rids = seg(4ull * tot + 4), s_jobs = seg(4ull * jobs.size() + 4), s_planes = seg((uint64_t)P * tot + 16), s_bpart = seg((uint64_t)(stage_w + 1) * (tot + 16)),        // (+1: the plane of a last-stage beam launch that runs beside the optimise launch below it)
               s_margin = seg(8ull * n_blocks * P + 16),
               // zero-initialised, contiguous (ONE memset): partition output, mec / num_alleles / iters, stop-rule state, queue counters, diagnostics
               s_out = seg(tot + 16), s_mec = seg(8ull * n_blocks * P + 8), s_na = seg(8ull * n_blocks * P + 8), s_it = seg(4ull * n_blocks * P + 4),

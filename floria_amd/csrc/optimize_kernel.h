@@ -613,8 +613,9 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                     else if (g.stopping_heuristic) { best = p - 1; stop = true; }                     // :233-238
                     if (!stop && mecv < expected) stop = true;                                         // :240-243
                 } else if (mecv < expected) stop = true;                                               // :247-250
-                g.tried[b] = p;
                 if (stop || p == g.max_ploidy) { g.blk_done_w[b] = 1; g.best_ploidy[b] = best; }
+                // (release: a beam launch of the next ploidy that runs beside this launch starts block b's job when it sees tried[b] = p, and reads blk_done[b] then)
+                __hip_atomic_store(&g.tried[b], p, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (g.stop_at) {
                 __threadfence();                                                              // mec / num_alleles of (b, p) before the ready bit

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 N=${1:-250}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/tl_shard$N; mkdir -p $O
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O -o t -- python $R/bench.py --contigs $N --steps 1 --warmup 2 --cpu-sample 0 --check 0 --pipeline 0 --resident-only --resident-steps 1 > $O/bench.log 2>&1
+FLORIA_HIP_HW_QUEUES=6 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O -o t -- python $R/bench.py --contigs $N --steps 1 --warmup 2 --cpu-sample 0 --check 0 --pipeline 0 --resident-only --resident-steps 1 > $O/bench.log 2>&1
 python - <<PY
 import csv, glob
 rows = []

@@ -428,6 +428,46 @@ def test_packed_upload_is_validated(gpu_ctx, hip_lib):
     arena.free()
 
 
+def test_last_ploidy_beside_the_optimise_launch_below_it(gpu_ctx, hip_lib):
+    # one ploidy per stage with the LAST ploidy's beam launch running beside the optimise launch of the ploidy below, every job waiting for its block's stop rule
+    # (tail_overlap, run_phase): a 120-contig config-4 shard with 1-3 job groups, few and many wave slots, small and large waiting grids; every field of every
+    # call equals the plain stage-after-stage run
+    contigs = [synth.make_config_contig(4, 1700 + i) for i in range(120)]
+    C = synth.CONFIGS[4]
+    res = gpu_ctx.upload_batch([c.pileup for c in contigs])
+    par = hip_lib.make_params(EPS, C["max_ploidy"], C["beam"])
+    bc, bs, be = [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, C["block_length"])
+        bc += [i] * len(s); bs += list(s); be += list(e)
+    try:
+        gpu_ctx.set_option("speculate", 0); gpu_ctx.set_option("tail_overlap", 0)
+        ref = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+        assert int(ref.ploidies_tried.max()) == C["max_ploidy"], "the shard must reach the last ploidy for this test to mean anything"
+        n_calls = 0
+        gpu_ctx.set_option("tail_overlap", 1)
+        for slots in (0, 37, 512):
+            for groups in (1, 2, 3):
+                for waves in (1, 2, 8):
+                    gpu_ctx.set_option("slots", slots); gpu_ctx.set_option("groups", groups); gpu_ctx.set_option("tail_waves", waves)
+                    for rep in range(2):
+                        r = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par)
+                        assert_block_results_equal(ref, r, f"tail_overlap, slots {slots}, groups {groups}, waves {waves}, rep {rep}")
+                        assert r.min_prune_margin == ref.min_prune_margin
+                        n_calls += 1
+        assert n_calls == 54
+        # a smaller max_ploidy: the last stage is one many blocks reach
+        par3 = hip_lib.make_params(EPS, 3, C["beam"])
+        gpu_ctx.set_option("slots", 0); gpu_ctx.set_option("groups", 0); gpu_ctx.set_option("tail_waves", 2); gpu_ctx.set_option("tail_overlap", 0)
+        ref3 = gpu_ctx.phase_blocks_batch(res, bc, bs, be, par3)
+        gpu_ctx.set_option("tail_overlap", 1)
+        assert_block_results_equal(ref3, gpu_ctx.phase_blocks_batch(res, bc, bs, be, par3), "tail_overlap at max_ploidy 3")
+    finally:
+        gpu_ctx.set_option("speculate", -1); gpu_ctx.set_option("slots", 0); gpu_ctx.set_option("groups", 0); gpu_ctx.set_option("tail_waves", 2); gpu_ctx.set_option("tail_overlap", 0)
+        for r in res:
+            r.free()
+
+
 def test_speculative_stages_under_stress(gpu_ctx, hip_lib):
     # race hunter for the speculative ploidy stages (the path every multi-GPU shard takes): a 250-contig config-4 shard — the per-GPU share of the
     # 8-GPU job — phased again and again with all ploidies at once / {1,2,3}{4,5}, few and many wave slots (over-subscription: jobs are dropped at dequeue
