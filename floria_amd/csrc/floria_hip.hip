@@ -168,6 +168,7 @@ struct Knobs {
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
     uint32_t arith_hbm = 0;       // (tests) reference arithmetic: position-map tables and first-insertion keys in HBM scratch even where they fit into LDS
+    uint32_t opt_block_order = 0; // (A/B, tests) optimise: the build / distance passes visit the reads in block order instead of longest first
     uint32_t arith = 0;           // 1 = the reference's own running f64 sums in its own orders (arith_kernel.h; slower kernels), 0 = the canonical (Q24, #eps) form
     int32_t  tail_overlap = 0;    // one ploidy per stage: the LAST ploidy's beam launch runs beside the optimise launch of the ploidy below, every job waiting for its block's
                                   // stop rule (run_phase): 0 off (default: measured level) | 1 on
@@ -373,6 +374,7 @@ struct PloidyPlan {
     uint32_t threads = 128, opt_slots = 0;
     size_t opt_lds = 0;
     bool hl = false, opt_spec = false;
+    uint32_t pm_lds_off = 0;      // optimise: where the visiting order of the reads (u16, longest first) sits in the workgroup's LDS (0 = none: the reads in block order)
     uint32_t fk_lds_off = 0;      // ... and the first-insertion keys as 32-bit words
     uint32_t fx_lds_off = 0;      // reference-arithmetic mode: where the emulated position maps sit in the workgroup's LDS (0 = in HBM scratch)
 };
@@ -467,7 +469,14 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         if (A == 2 && q.hl && p <= 5 && threads == 1024 && !K.opt_threads && !K.no_specialized) threads = 512;
         q.threads = threads;
         q.opt_spec = A == 2 && q.hl && threads >= 512 && p <= 5 && !K.no_specialized && !K.arith;
-        uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (q.opt_lds + 8 * 1024)), 2048 / threads));
+        auto wg_per_cu = [&](size_t lds) { return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads)); };
+        {   // the visiting order of the build / distance passes (optimize_kernel.h: u16 per read), where it costs no workgroup per CU
+            const size_t pm_bytes = (((size_t)n_max * 2) + 15) & ~(size_t)15;
+            if (!K.arith && !K.opt_block_order && meta_bytes && n_max <= 65535u && q.opt_lds + pm_bytes <= 60 * 1024 && wg_per_cu(q.opt_lds + pm_bytes) == wg_per_cu(q.opt_lds)) {
+                q.pm_lds_off = (uint32_t)q.opt_lds; q.opt_lds += pm_bytes;
+            }
+        }
+        uint32_t per_cu = wg_per_cu(q.opt_lds);
         per_cu = std::min<uint32_t>(per_cu, 8);
         q.opt_slots = std::min<uint32_t>((uint32_t)ctx->n_cu * per_cu, nj_max);
     }
@@ -663,6 +672,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.fuse_select = stage.size() == 1 ? 1 : 0;
                     a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
                     a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
+                    a.pm_lds_off = q.pm_lds_off;
                     // (a plan with ANY speculative stage publishes ready bits and stop_at from every stage: a later stage's stop rule compares with these MEC values)
                     if (K.arith) {
                         a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
@@ -826,6 +836,7 @@ int floria_hip_create(int device, floria_hip_ctx** out) {
         K.no_p1_shortcut = getenv("FLORIA_HIP_NO_P1_SHORTCUT") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_OPT_THREADS")) { const int tv = atoi(v); if (tv == 1024 || tv == 512 || tv == 128) K.opt_threads = (uint32_t)tv; }
         K.opt_global = getenv("FLORIA_HIP_OPT_GLOBAL") != nullptr;
+        K.opt_block_order = getenv("FLORIA_HIP_OPT_BLOCK_ORDER") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_SPECULATE")) K.speculate = std::max(-1, std::min(3, atoi(v)));
         K.trace = getenv("FLORIA_HIP_TRACE") != nullptr;
         if (const char* v = getenv("FLORIA_HIP_TAIL_OVERLAP")) K.tail_overlap = std::max(-1, std::min(1, atoi(v)));
@@ -893,6 +904,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "spec_gate_div") K.spec_gate_div = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "speculate") { if (value < -1 || value > 3) return fail(FLORIA_E_INVALID, "speculate: -1 auto | 0 | 1 | 2 | 3"); K.speculate = (int32_t)value; }
     else if (k == "no_bulk") K.no_bulk = value != 0;
+    else if (k == "opt_block_order") K.opt_block_order = value != 0;
     else if (k == "tail_overlap") { if (value < -1 || value > 1) return fail(FLORIA_E_INVALID, "tail_overlap: 0 | 1"); K.tail_overlap = (int32_t)value; }
     else if (k == "tail_waves") K.tail_waves = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "arith_hbm") K.arith_hbm = value != 0;

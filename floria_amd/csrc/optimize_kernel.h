@@ -24,6 +24,7 @@ constexpr int OPT_SORT_LDS = 512;
 constexpr int OPT_META_MAX = 4096;        // reads per block whose (cell offset, length, partition) are staged in LDS        // candidates sorted in LDS up to this many
 constexpr int NUM_ITER_OPTIMIZE = 20;     // constants.rs:3
 constexpr int OPT_U = 8;                  // cells per software-pipelined batch of the distance loop
+constexpr int OPT_BUCKETS = 16;           // visiting order of the build / distance passes: reads bucketed by ceil(#cells / 64) (the distance loop's trips), 16+ trips together
 
 struct OptArgs {
     BlockSet bs;
@@ -70,6 +71,7 @@ struct OptArgs {
     uint8_t*  fx_pool;           // [slots][ploidy][2][fx_ctrl + fx_slot] the emulated position maps: control bytes, keys
     uint64_t  sort_cap, fx_ctrl, fx_slot;
     uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl])
+    uint32_t  pm_lds_off;        // != 0: the visiting order of the build and distance passes (u16 read indices, longest reads first) in LDS at this offset ([n_max])
     uint32_t  fk_lds_off;        // != 0: the first-insertion keys as 32-bit words (read << 12 | cell rank: reads < 2^20, cells per read < 2^12) in LDS at this offset ([ploidy*span_max])
 };
 // fired(q): the reference's loop breaks at ploidy q (graph_processing.rs:196-251); needs mec[q-1] (q > 1) and mec[q], num_alleles[q]
@@ -133,8 +135,11 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 // ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)): a read's distance is the running sum over its cells in the order
 // of its position set (utils_frags.rs:33-72), a partition's `errors` the running sum over its positions in the bucket order of its position
 // map (local_clustering.rs:226-256), which is emulated per partition (arith_kernel.h).
+// (the ploidy 1-3 instances of 512 threads are held to the 80 VGPRs that let three workgroups share a CU: six waves per SIMD)
+constexpr int opt_min_waves(int tp, int threads, bool arith) { return (!arith && threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1; }
 template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false>
-__global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
+__global__ __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(opt_min_waves(TP, OPT_THREADS, ARITH))))
+void optimize_kernel(OptArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
     __shared__ uint64_t s_gain[OPT_SORT_LDS];
     __shared__ uint32_t s_key[OPT_SORT_LDS];
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     __shared__ uint32_t s_size[MAX_PLOIDY];
     __shared__ uint32_t s_ncand, s_nmoves, s_job, s_skip;
     __shared__ uint32_t s_chg_lo, s_chg_hi;          // positions whose code byte changed in the last batch of moves (HL)
+    __shared__ uint32_t s_bkt[OPT_BUCKETS];          // visiting order: reads per bucket of ceil(#cells / 64), then the buckets' write cursors
     __shared__ double s_score;
     __shared__ double s_errf[MAX_PLOIDY];            // ARITH: running `errors` of every partition
     __shared__ uint32_t s_cntk[MAX_PLOIDY + 1];      // ARITH: positions in every partition's map
@@ -158,6 +164,10 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
     uint32_t* m_cb = (uint32_t*)(smem + moved_bytes);
     uint32_t* m_lk = m_cb + meta_n;                                                   // cell count | partition << 24
     uint32_t* m_fl = m_lk + meta_n;                                                   // first | last << 16 position index of the read (span <= 65535)
+    // The four 16-lane groups of a wavefront walk their reads' cells in lockstep, so a pass costs the LONGEST of the four reads (config 4: 2.66 trips of the distance
+    // loop instead of the mean 1.94).  With an order table the passes visit the reads longest first, reads of equal trip count side by side (counting sort while
+    // the metadata is staged): neither the histogram (integer atomics) nor the distances (one slot per read) depend on the visiting order.
+    uint16_t* m_pm = (!ARITH && g.pm_lds_off && meta_n) ? (uint16_t*)(smem + g.pm_lds_off) : nullptr;
     uint64_t* hist = HL ? (uint64_t*)(smem + moved_bytes + meta_bytes) : g.hist_pool + (uint64_t)blockIdx.x * g.span_max * PA;
     // HL: one CODE byte per (position, partition) next to the histogram — bit a = allele a attains the position's maximal phred sum, 0 =
     // nothing observed — refreshed after the build and after every batch of moves; the distance pass (70 % of the kernel) then reads
@@ -199,6 +209,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         // ---- hap_block_from_partition (utils_frags.rs:177-184): phred sums and unit counts in one cell -----
         for (uint32_t x = tid; x < ncell; x += OPT_THREADS) hist[x] = 0;
         if (tid < MAX_PLOIDY) s_size[tid] = 0;
+        if (tid < OPT_BUCKETS) s_bkt[tid] = 0;
         __syncthreads();
         // stage (first cell, #cells, partition) of every read once: the chain reads[i] -> read_off[r] -> cells is then one hop
         const bool meta = meta_n != 0;
@@ -207,9 +218,16 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
             part[i] = (uint8_t)k;
             atomicAdd(&s_size[k], 1u);
             if (meta) { const uint4 mr = *(const uint4*)(cd.meta + 8 * (uint64_t)r);     // {cell offset, #cells, first, last}: one 16-B load
-                        m_cb[i] = mr.x; m_lk[i] = mr.y | (k << 24); m_fl[i] = (mr.z - pos0) | ((mr.w - pos0) << 16); }
+                        m_cb[i] = mr.x; m_lk[i] = mr.y | (k << 24); m_fl[i] = (mr.z - pos0) | ((mr.w - pos0) << 16);
+                        if (m_pm) atomicAdd(&s_bkt[min((mr.y + 63u) >> 6, (uint32_t)OPT_BUCKETS - 1u)], 1u); }
         }
         __syncthreads();
+        if (m_pm) {
+            if (tid == 0) { uint32_t acc = 0; for (int bk = OPT_BUCKETS - 1; bk >= 0; --bk) { const uint32_t c = s_bkt[bk]; s_bkt[bk] = acc; acc += c; } }      // longest first
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += OPT_THREADS) m_pm[atomicAdd(&s_bkt[min(((m_lk[i] & 0xffffffu) + 63u) >> 6, (uint32_t)OPT_BUCKETS - 1u)], 1u)] = (uint16_t)i;
+            __syncthreads();
+        }
         auto read_meta = [&](uint32_t i, uint32_t& cb, uint32_t& len, uint32_t& k) {
             if (meta) { cb = m_cb[i]; const uint32_t lk = m_lk[i]; len = lk & 0xffffffu; k = lk >> 24; }
             else { const uint32_t r = reads[i]; cb = G(cd.read_off)[r]; len = G(cd.read_off)[r + 1] - cb; k = part[i]; }
@@ -236,7 +254,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         // per lane loaded before the first atomic
         const uint32_t grp = tid >> 4, sub = tid & 15;
         const uint32_t n16 = (n + 15) & ~15u;
-        for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
+        for (uint32_t iv = grp; iv < n16; iv += OPT_THREADS / 16) {
+            const uint32_t i = (m_pm && iv < n) ? (uint32_t)m_pm[iv] : iv;
             uint32_t cb = 0, len = 0, k = 0;
             if (i < n) read_meta(i, cb, len, k);
             for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {
@@ -451,7 +470,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
                         dist[pair] = df;
                     }
                 } else
-                for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
+                for (uint32_t iv = grp; iv < n16; iv += OPT_THREADS / 16) {
+                    const uint32_t i = (m_pm && iv < n) ? (uint32_t)m_pm[iv] : iv;
                     uint32_t cb = 0, len = 0, kk = 0;
                     if (i < n) read_meta(i, cb, len, kk);
                     if (incremental && i < n) {             // no code changed at any position of this read: its distances stand
@@ -592,7 +612,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimize_kernel(OptArgs g) {
         // ---- get_mec_stats_epsilon_no_phred of the optimised partition (graph_processing.rs:156-162) -----------
         OPT_TICK(8);
         stats(false);
-        OPT_TICK(9);     // final stats
+        OPT_TICK(62);    // final stats (slot 62: slots 9-15 also hold the beam kernels' step counters, which made this phase look like 2.7 Gcycles in earlier profiles)
         if (tid == 0) {
             double mecv = 0.0, na = 0.0;
             for (uint32_t k = 0; k < p; ++k) {
