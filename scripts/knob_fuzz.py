@@ -13,8 +13,9 @@ ctx = lib.FloriaHip(0)
 s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 KNOBS = {"beam_path": (0, 0, 1, 2, 3), "no_bulk": (0, 0, 1), "no_specialized": (0, 1), "no_p1_shortcut": (0, 1), "opt_global": (0, 0, 1), "opt_threads": (0, 128, 512, 1024),
-         "speculate": (-1, 0, 1, 2, 3), "groups": (0, 2), "slots": (0, 0, 48)}
-DEFAULT = {"beam_path": 0, "no_bulk": 0, "no_specialized": 0, "no_p1_shortcut": 0, "opt_global": 0, "opt_threads": 0, "speculate": -1, "groups": 0, "slots": 0}
+         "speculate": (-1, 0, 0, 1, 2, 3), "groups": (0, 2), "slots": (0, 0, 48),
+         "tail_overlap": (0, 1, 1), "tail_waves": (1, 2, 8), "opt_block_order": (0, 0, 1)}
+DEFAULT = {"beam_path": 0, "no_bulk": 0, "no_specialized": 0, "no_p1_shortcut": 0, "opt_global": 0, "opt_threads": 0, "speculate": -1, "groups": 0, "slots": 0, "tail_overlap": 0, "tail_waves": 2, "opt_block_order": 0}
 bad = 0
 for seed in range(s0, s0 + cnt):
     rng = np.random.default_rng(990000 + seed)
