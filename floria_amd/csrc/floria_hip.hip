@@ -1620,7 +1620,10 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     // Chunked inputs (cells still arriving): group g = the blocks of chunk g, whose stream waits for the chunk's event.
     const bool chunked = SC.chunk_ev != nullptr && SC.n_chunks > 1;
     // (measured, config 4, resident: one group wins while a stage has less than three rounds of jobs — 750 / 1000 / 1500 contigs: 55 / 61.5 / 80.5 ms against
-    // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms)
+    // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms.  End of round 4 (profiles/r04_groups_ab.txt), ms per
+    // step with 1 / 2 / 3 / 4 groups: 7 249 blocks 51.6 / 55.2 / 51.4 / -, 10 875 blocks 67.8 / 66.7 / 65.3 / -, 14 503 blocks 81.6 / 78.8 / 75.9 or 79.3 / 78.4-79.1:
+    // three groups are 3.7 % faster in five runs of seven and level in the other two (the three chains interleave in one of two patterns); the pipelined call,
+    // which has its own three chunk groups, does not change, and every launch shares the chip three ways, so the default stays at two)
     uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 48 ? 2 : 1);
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
     if (ctx->hw_queues < 5 && !ctx->knobs.groups) G = std::min<uint32_t>(G, 2);
