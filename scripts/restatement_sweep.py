@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""(CPU) the C++ oracle against the independent Python restatement of seam S1 (oracle/py_restatement.py) on many more random pileups than tests/test_py_restatement.py holds:
+dyadic epsilon in the canonical arithmetic, 0.04 / 0.05 / 0.0437 in the running-sum mode with ascending orders.   usage: scripts/restatement_sweep.py [first seed = 100000] [count = 2000] [workers = 6]"""
+import sys
+sys.path.insert(0, ".")
+from multiprocessing import Pool
+
+
+def run(seed):
+    from tests.test_py_restatement import case, compare
+    try:
+        p, n_snps, P, B = case(seed)
+        compare(p, n_snps, P, B, 0.03125 if seed % 2 else 0.0625, 0)
+        compare(p, n_snps, P, B, (0.04, 0.05, 0.0437)[seed % 3], 2)
+        return None
+    except AssertionError as e:
+        return f"seed {seed}: {str(e)[:300]}"
+
+
+if __name__ == "__main__":
+    from oracle import oracle
+    oracle.build()
+    s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+    cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    workers = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    with Pool(workers) as pool:
+        bad = [r for r in pool.imap_unordered(run, range(s0, s0 + cnt), chunksize=8) if r]
+    for b in bad:
+        print("MISMATCH", b)
+    print(f"seeds {s0}..{s0 + cnt - 1}, each in both arithmetics (dyadic epsilon: canonical; 0.04 / 0.05 / 0.0437: running sums, ascending orders): {len(bad)} disagreements between the two restatements")
