@@ -72,6 +72,10 @@ constexpr int SLAB_NS_MAX = 512;
 constexpr int SLAB_PAD_IDX = 64;     // dummy position indices behind a slot's slabs (narrow-sum layout)
 constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
 constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
+// ARITH instances (the reference's running f64 sums, below): the distance terms of a step wait in LDS for the sequential folds — SLAB_TERM_CAP f64 per wave —
+// so LDS allows two waves per SIMD at most and the register budget is that of two
+constexpr int SLAB_TERM_CAP = 768;
+constexpr int SLAB_WAVES_ARITH = 2;
 template <int N> struct IC { static constexpr int value = N; };
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) { if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); } }
 // value of lane (segment base + J) for aligned segments of PS = 2 or 4 lanes: one DPP quad_perm move, no LDS crossbar round trip
@@ -168,9 +172,10 @@ struct SlabLds {
     uint32_t off_q[2], off_h1[2], off_h2[2], off_m[2], off_sl[2];     // state arrays (SoA) x2
     uint32_t off_live, off_ref, off_leader, off_newid, off_free, off_pk;
     uint32_t off_rqs, off_rqd, off_rm, off_rt1, off_rt2, off_rnp1, off_rnp2;
+    uint32_t off_ev[2], off_term;     // ARITH: error_vec of every state (p f64, x2 parities), the step's distance terms
     uint32_t total;
 };
-__host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool q0) {
+__host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool q0, bool arith = false) {
     SlabLds L;
     const uint32_t NS = LM * p;
     uint32_t o = 0;
@@ -190,6 +195,8 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
     // the materialisation tables are only live between phase B and the next phase A: they alias the r_qs array
     // (leader 4 B + newid 2 B + ref 1 B = 7 B per slab <= 8 B)
     L.off_leader = L.off_rqs; L.off_newid = L.off_rqs + NS * 4; L.off_ref = L.off_rqs + NS * 6;
+    L.off_ev[0] = take(arith ? LM * p * 8 : 0); L.off_ev[1] = take(arith ? LM * p * 8 : 0);
+    L.off_term = take(arith ? SLAB_TERM_CAP * 8 : 0);
     L.total = o;
     return L;
 }
@@ -207,17 +214,31 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 // TP / TB: ploidy and beam width as compile-time constants (0 = read them from the arguments): LDS offsets become immediates, the
 // per-partition loops unroll and divisions by p turn into multiplications; the host picks TP = p, TB = 10 for the CLI's default beam.
 // SPEC: the launch belongs to a speculative stage (stop_at is set): only that instance carries the checks that drop a job whose ploidy turned out not to be needed
-template <int A, bool Q0, int TP = 0, int TB = 0, bool SPEC = false>
+// ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)) on the shared slabs.  What changes against the canonical (Q24, #eps) form:
+//   * a read's cells are staged in the iteration order of Frag.positions (BeamArgs::cell_ord, arith_kernel.h: {SNP, attribute word} pairs, so the LDS image is
+//     interleaved and "beyond the written window" is a test per cell, not a prefix);
+//   * phase A classifies lane-parallel as always, but instead of summing it leaves one f64 TERM per (live slab, cell) in LDS — 0.0 same, eps empty / beyond the window,
+//     w * 2^-24 different — and then ONE lane per live slab folds its row in cell order: `diff += ..` of utils_frags.rs:32-75 term by term (x + 0.0 == x, so the
+//     `same` cells cost nothing but do not perturb the sum); `same` stays an exact integer sum;
+//   * a state carries error_vec (global_clustering.rs:196-202) as p f64 in LDS, a child's score is their sum in partition order with the read's diff added to its
+//     partition first; the survivors' vectors are the parents' with that one element replaced.
+// Slabs, hash, heap, pruning screen, traceback: unchanged.  Biallelic or not, but no q = 0 cells (those pileups keep the generic kernel in this mode).
+template <int A, bool Q0, int TP = 0, int TB = 0, bool SPEC = false, bool ARITH = false>
 // waves per SIMD: four for the ploidy 2 and 3 instances (126-128 VGPRs, < 10 KB of LDS per wave), SLAB_WAVES = 3 where LDS limits (ploidy >= 4, runtime-parameter
 // instances).  Measured and left alone: five waves spill 17-29 VGPRs and starve the co-running optimise kernels.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(slab_waves(TP), slab_waves(TP))))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ARITH ? 1 : slab_waves(TP), ARITH ? SLAB_WAVES_ARITH : slab_waves(TP))))
 void beam_slab_kernel(BeamArgs g) {
+    static_assert(!ARITH || !Q0, "the reference-arithmetic instances classify from the code bytes");
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
     const uint32_t p = TP ? (uint32_t)TP : g.ploidy, B = TB ? (uint32_t)TB : g.beam, LM = p * B, NS = LM * p;
-    const SlabLds LY = slab_lds_layout(LM, p, Q0);
+    const SlabLds LY = slab_lds_layout(LM, p, Q0, ARITH);
+    // cells of the current / next read: two arrays (SNP index, attribute word) x two buffers; ARITH: ONE interleaved {SNP, attribute} image per buffer,
+    // buffer 0 where the SNP arrays would be, buffer 1 where the attribute arrays would be (same bytes), indexed with stride CST = 2
+    constexpr uint32_t CST = ARITH ? 2u : 1u;
     uint32_t* const c_snp_base = (uint32_t*)(smem + LY.off_coff);
-    uint32_t* const c_aw_base  = (uint32_t*)(smem + LY.off_caw);
+    uint32_t* const c_aw_base  = ARITH ? c_snp_base + 1 : (uint32_t*)(smem + LY.off_caw);
+    constexpr uint32_t CBUF = ARITH ? 2u * SLAB_TILE : (uint32_t)SLAB_TILE;      // words between the two buffers
     uint64_t* const c_rp1 = (uint64_t*)(smem + LY.off_crp1);       // q=0 pileups only: presence-hash words of the current tile
     uint64_t* const c_rp2 = (uint64_t*)(smem + LY.off_crp2);
     uint16_t* live_id = (uint16_t*)(smem + LY.off_live);
@@ -231,6 +252,8 @@ void beam_slab_kernel(BeamArgs g) {
     uint32_t* r_m = (uint32_t*)(smem + LY.off_rm);
     uint64_t* r_np1 = (uint64_t*)(smem + LY.off_rnp1);
     uint64_t* r_np2 = (uint64_t*)(smem + LY.off_rnp2);
+    double* const r_fd = (double*)r_qd;                             // ARITH: running `diff` of the read against every live slab (the (Q24, #eps) tables are not used)
+    double* const terms = (double*)(smem + LY.off_term);
 
     constexpr bool CODES = !Q0;
     constexpr bool NARROW = CODES && A == 2;
@@ -313,6 +336,7 @@ void beam_slab_kernel(BeamArgs g) {
         const uint32_t n = (uint32_t)(GCOLD_BS(blk_read_off)[b + 1] - roff);
         const uint32_t* reads = GCOLD_BS(blk_read) + roff;
         const uint32_t pos0 = GCOLD_BS(blk_pos0)[b];
+        const uint2* const ord = ARITH ? GCOLD(cell_ord) + GCOLD(cell_ord_off)[GCOLD_BS(blk_contig)[b]] : nullptr;     // the contig's cells, every read's in set order
 
         int cur = 0;
         // (select between the two static carve-outs; indexing LY.off_*[cur] dynamically would put LY in scratch)
@@ -321,10 +345,12 @@ void beam_slab_kernel(BeamArgs g) {
         auto ST_h2 = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_h2[1] : LY.off_h2[0])); };
         auto ST_m = [&](int w) { return (uint32_t*)(smem + (w ? LY.off_m[1] : LY.off_m[0])); };
         auto ST_sl = [&](int w) { return (uint16_t*)(smem + (w ? LY.off_sl[1] : LY.off_sl[0])); };
+        auto ST_ev = [&](int w) { return (double*)(smem + (w ? LY.off_ev[1] : LY.off_ev[0])); };
         uint32_t nstates = 1, nlive = 1;
         // root: every partition points at slab 0, which is logically empty (nothing written: hi_rel = -1)
         if (lane == 0) { ST_q(0)[0] = 0; ST_h1(0)[0] = 0; ST_h2(0)[0] = 0; ST_m(0)[0] = 0; live_id[0] = 0; }
         if (lane < p) ST_sl(0)[lane] = 0;
+        if (ARITH && lane < p) ST_ev(0)[lane] = 0.0;              // error_vec: vec![(0.0, 0.0); ploidy] (global_clustering.rs:37)
         int32_t hi_rel = -1;
         uint32_t start_rel = 0;
         RegHeap H; H.hp_hi = 0; H.hp_lo = 0; H.hp_id = 0; H.len = 0;
@@ -345,6 +371,12 @@ void beam_slab_kernel(BeamArgs g) {
         // lane l moves cells 4l..4l+3 (16 B) of each array; the LDS image is lane-linear = cell order.  The last lane may read up to
         // 3 cells past the read (the next read's cells or the arrays' 16-B tail padding, see floria_hip_contig_upload); never used.
         auto dma_cells = [&](uint32_t w, const CellMeta& m) {
+            if constexpr (ARITH) {                 // lane l moves the pairs of cells 2l, 2l+1 and 128+2l, 128+2l+1 (16 B each); the last lane may read one pair past the read (padding)
+                if (m.L <= (uint32_t)SLAB_TILE) {
+                    if (2 * lane < m.L) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(ord) + m.cbeg + 2 * lane), (lds_void*)(c_snp_base + w * CBUF), 16, 0, FLORIA_NT_AUX);
+                    if (128 + 2 * lane < m.L) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(ord) + m.cbeg + 128 + 2 * lane), (lds_void*)(c_snp_base + w * CBUF + SLAB_TILE), 16, 0, FLORIA_NT_AUX);
+                }
+            } else
             if (m.L <= (uint32_t)SLAB_TILE && 4 * lane < m.L) {
                 __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_snp) + m.cbeg + 4 * lane), (lds_void*)(c_snp_base + w * SLAB_TILE), 16, 0, FLORIA_NT_AUX);
                 __builtin_amdgcn_global_load_lds((gbl_cvoid*)(G(cd.cell_aw) + m.cbeg + 4 * lane), (lds_void*)(c_aw_base + w * SLAB_TILE), 16, 0, FLORIA_NT_AUX);
@@ -378,13 +410,14 @@ void beam_slab_kernel(BeamArgs g) {
             const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
             uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);
             uint32_t* st_m = ST_m(cur); uint16_t* st_sl = ST_sl(cur);
-            uint32_t* const c_snp = c_snp_base + (i & 1) * SLAB_TILE;
-            uint32_t* const c_aw  = c_aw_base + (i & 1) * SLAB_TILE;
+            uint32_t* const c_snp = c_snp_base + (i & 1) * CBUF;        // cell c: c_snp[c * CST], c_aw[c * CST]
+            uint32_t* const c_aw  = c_aw_base + (i & 1) * CBUF;
 
             uint32_t nin = 0;
             // number of the tile's cells at written positions (<= hi_rel; a prefix, cells ascend) and, for q=0 pileups,
             // the presence-hash words of the cells (LDS) and their sum over the cells beyond hi_rel
             auto scan_tile = [&](uint32_t tl) {
+                if constexpr (ARITH) return;        // (set order: the cells inside the written window are not a prefix; phase A tests every cell)
                 uint32_t cnt_in = 0;
                 uint64_t b1 = 0, b2 = 0;
                 uint32_t snps[SLAB_TILE / 64];
@@ -415,6 +448,8 @@ void beam_slab_kernel(BeamArgs g) {
                 for (int u = 0; u < SLAB_TILE / 64; ++u) {
                     const uint32_t c = lane + 64 * u;
                     const uint32_t cc = t * SLAB_TILE + c;
+                    if constexpr (ARITH) { if (cc < L) { const uint64_t ca = G((const uint64_t*)ord)[cbeg + cc]; c_snp[2 * c] = (uint32_t)ca; c_aw[2 * c] = (uint32_t)(ca >> 32); } }
+                    else
                     if (cc < L) { c_snp[c] = G(cd.cell_snp)[cbeg + cc]; c_aw[c] = G(cd.cell_aw)[cbeg + cc]; }
                 }
                 __syncthreads();
@@ -575,6 +610,79 @@ void beam_slab_kernel(BeamArgs g) {
                         if (act && sub == 0) { const uint32_t sidr = live_id[li]; r_t1[sidr] = t1; r_t2[sidr] = t2; }
                     }
                 }
+                // (2, ARITH) the reference's running `diff` (utils_frags.rs:32-75): the lanes classify as below — Gl lanes per slab, batches of independent byte loads —
+                // but leave one f64 term per (slab, cell) in LDS, rows of RS = tl rounded up to 8 (padding: 0.0), for as many live slabs as SLAB_TERM_CAP holds at a
+                // time; then one lane per slab adds its row in cell order onto the slab's running sum (continued across the tiles of a long read).  `same` is an exact
+                // integer sum as ever.
+                if constexpr (ARITH) {
+                    for (uint32_t x = lane; x < nlive; x += 64) r_qs[live_id[x]] = 0;
+                    for (uint32_t t = 0; t < ntiles; ++t) {
+                        if (ntiles > 1) stage_tile(t);
+                        const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                        const uint32_t RS = (tl + 7u) & ~7u;
+                        const uint32_t cap_s = div_small((uint32_t)SLAB_TERM_CAP, __builtin_amdgcn_rcpf((float)RS));          // rows that fit (>= 3: RS <= SLAB_TILE)
+                        const uint32_t spp = min(nlive, min(64u, cap_s));
+                        for (uint32_t l0 = 0; l0 < nlive; l0 += spp) {
+                            const uint32_t ns = min(spp, nlive - l0);
+                            const uint32_t Gl = div_small(64u, __builtin_amdgcn_rcpf((float)ns));
+                            const float rcp_gl = __builtin_amdgcn_rcpf((float)Gl);
+                            const uint32_t lsl = div_small(lane, rcp_gl), sub = lane - lsl * Gl;
+                            const bool act = lsl < ns;
+                            const uint32_t sidr = act ? (uint32_t)live_id[l0 + lsl] : 0u;
+                            const uint8_t* const cbase = codes + sidr * span_pad;
+                            double* const trow = terms + lsl * RS;
+                            uint64_t qs = 0;
+                            auto batch = [&](auto NC, uint32_t u0) {
+                                constexpr int N = decltype(NC)::value;
+                                uint32_t offs[N], aws[N], cdb[N], cc[N]; bool vs[N], ins[N];
+#pragma unroll
+                                for (int u = 0; u < N; ++u) {
+                                    cc[u] = sub + (u0 + (uint32_t)u) * Gl; vs[u] = cc[u] < tl; const uint32_t cx = vs[u] ? cc[u] : 0u;
+                                    const uint32_t o = c_snp[cx * CST] - pos0; aws[u] = c_aw[cx * CST];
+                                    ins[u] = vs[u] && (int32_t)o <= hi_rel;                     // a position beyond the written window is not in the haplotype: empty (:36-48)
+                                    offs[u] = ins[u] ? o : 0u;
+                                }
+#pragma unroll
+                                for (int u = 0; u < N; ++u) cdb[u] = cbase[offs[u]];
+                                uint32_t ps = 0;
+#pragma unroll
+                                for (int u = 0; u < N; ++u) {
+                                    const uint32_t w = aws[u] & 0x0fffffffu;
+                                    const uint32_t code = ins[u] ? cdb[u] : 0u;
+                                    const uint32_t sm = (uint32_t)__builtin_amdgcn_sbfe((int)code, aws[u] >> 28, 1u);        // all ones <=> same
+                                    ps += w & sm;
+                                    double tv = code ? (double)w * 0x1p-24 : g.eps;             // :70 diff += w  |  :45-48 diff += epsilon
+                                    tv = sm ? 0.0 : tv;                                         // :54-67 same: nothing is added to diff
+                                    tv = vs[u] ? tv : 0.0;                                      // row padding
+                                    if (cc[u] < RS) trow[cc[u]] = tv;
+                                }
+                                qs += ps;
+                            };
+                            if (act) {
+                                const uint32_t U = div_small(RS + Gl - 1u, rcp_gl);             // rounds of Gl cells
+                                for (uint32_t u0 = 0; u0 < U; u0 += 8u) {
+                                    const uint32_t r = U - u0;
+                                    if (r >= 7u) batch(IC<8>{}, u0); else if (r >= 5u) batch(IC<6>{}, u0); else if (r >= 3u) batch(IC<4>{}, u0); else batch(IC<2>{}, u0);
+                                }
+                                if (ntiles == 1) atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs);
+                                else atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs);
+                            }
+                            __syncthreads();
+                            if (lane < ns) {
+                                const uint32_t sidf = live_id[l0 + lane];
+                                double d = t == 0 ? 0.0 : r_fd[sidf];
+                                const double2* row = (const double2*)(terms + lane * RS);
+                                for (uint32_t c8 = 0; c8 < RS; c8 += 8u) {
+                                    const double2 t0 = row[0], t1 = row[1], t2 = row[2], t3 = row[3];
+                                    row += 4;
+                                    d += t0.x; d += t0.y; d += t1.x; d += t1.y; d += t2.x; d += t2.y; d += t3.x; d += t3.y;
+                                }
+                                r_fd[sidf] = d;
+                            }
+                            __syncthreads();
+                        }
+                    }
+                } else {
                 // (2) distances from the code bytes.  Gl = 64 / nlive lanes per slab (any integer, not a power of two: 6 live slabs get 10 lanes each, not 8),
                 // every lane walks ceil(nin / Gl) cells in batches of 2 / 4 / 6 / 8 independent byte loads chosen by the exact count, sums in 32 bits inside a
                 // batch, and the lanes of a slab combine through LDS atomics (3 instructions instead of a 4-stage DPP butterfly on three values)
@@ -627,6 +735,7 @@ void beam_slab_kernel(BeamArgs g) {
                         atomicAdd(&r_m[sidr], m);
                     }
                 }
+                }      // (!ARITH)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of the next read has landed (hipcc does not track it)
             // Pin the record's wait HERE, where nothing younger is in flight: consumed at the end of the step, hipcc would wait
@@ -654,13 +763,15 @@ void beam_slab_kernel(BeamArgs g) {
                 uint32_t m = 0;
                 uint32_t nn = 0, kk = 0;
                 float pvf = 0.f;
+                double df = 0.0, e_own = 0.0;            // ARITH: the read's running diff against this lane's slab; error_vec[my_k].1 of state a
                 if (act) {
                     const uint32_t li = st_sl[a * p + my_k];          // (the per-slab tables of phase A are indexed by slab id)
                     const uint64_t qs = r_qs[li];
-                    qd = r_qd[li]; m = r_m[li];
+                    if constexpr (ARITH) { df = r_fd[li]; e_own = ST_ev(cur)[a * p + my_k]; }
+                    else { qd = r_qd[li]; m = r_m[li]; }
                     if (trunc) { t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2; }
                     if (Q0) { np1 = r_np1[li]; np2 = r_np2[li]; }
-                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
+                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = ARITH ? df : qm_to_f64(qd, m, g.eps);
                     // `as usize` of the two sums: both are < 2^32 (a read has < 2^32 cells of weight <= 1), so the 1-instruction u32 conversion is exact
                     nn = (uint32_t)(same_f + diff_f); kk = (uint32_t)diff_f;
                     pvf = binom_screen_f32(nn, kk, g.ln_eps, g.ln_1meps, eps_f, rdiv_f);
@@ -714,10 +825,20 @@ void beam_slab_kernel(BeamArgs g) {
                 pass = pass && act;
                 uint64_t ch1 = 0, ch2 = 0, cq = 0, cs = 0;
                 uint32_t cm = 0;
+                if constexpr (ARITH) {
+                    // read_to_node_value (global_clustering.rs:196-202): error_vec with the read's diff added to its partition, summed in partition order
+                    const double ed = e_own + df;
+                    double mec = 0.0;
+                    if constexpr (DPPSEG) static_for<0, TP>([&](auto J) { constexpr int j = decltype(J)::value; const double ej = seg_get_f64<PSC, j>(e_own); mec += ((uint32_t)j == my_k) ? ed : ej; });
+                    else for (uint32_t j = 0; j < p; ++j) { const double ej = shfl_f64(e_own, seg0 + (int)j); mec += (j == my_k) ? ed : ej; }
+                    cs = (uint64_t)__double_as_longlong(mec);
+                }
                 if (act) {
+                    if constexpr (!ARITH) {
                     cq = st_q[a] + qd;
                     cm = st_m[a] + m;
                     cs = (uint64_t)__double_as_longlong(qm_to_f64(cq, cm, g.eps));
+                    }
                     ch1 = (st_h1[a] - ts1) + rk1 * (tw1 + (Q0 ? np1 : 0));
                     ch2 = (st_h2[a] - ts2) + rk2 * (tw2 + (Q0 ? np2 : 0));
                 }
@@ -849,10 +970,11 @@ void beam_slab_kernel(BeamArgs g) {
                 n_h1 = E_h1[eid]; n_h2 = E_h2[eid]; n_pk = E_pk[eid];
             }
             const uint32_t pj = n_pk & 0xffff, kj = n_pk >> 16;
-            if (surv) {                            // the child's (sum of diffs, #eps) = its parent's + the read's distance to the extended slab
+            if (!ARITH && surv) {                  // the child's (sum of diffs, #eps) = its parent's + the read's distance to the extended slab
                 const uint32_t li = st_sl[pj * p + kj];
                 n_q = st_q[pj] + r_qd[li]; n_m = st_m[pj] + r_m[li];
             }
+            double* const st_ev = ST_ev(cur); double* const nx_ev = ST_ev(cur ^ 1);      // ARITH: error_vec of the current / next states
             uint64_t* nx_q = ST_q(cur ^ 1); uint64_t* nx_h1 = ST_h1(cur ^ 1); uint64_t* nx_h2 = ST_h2(cur ^ 1);
             uint32_t* nx_m = ST_m(cur ^ 1); uint16_t* nx_sl = ST_sl(cur ^ 1);
             uint32_t u_old = 0, ncopy = 0;
@@ -866,7 +988,10 @@ void beam_slab_kernel(BeamArgs g) {
                 else
                 for (uint32_t x = lane; x < nnext * p; x += 64) {
                     const uint32_t j = div_small(x, rcp_p), k = x - j * p;
-                    nx_sl[x] = st_sl[(s_pk[j] & 0xffff) * p + k];
+                    const uint32_t pk = s_pk[j];
+                    const uint32_t sid = st_sl[(pk & 0xffff) * p + k];
+                    nx_sl[x] = (uint16_t)sid;
+                    if constexpr (ARITH) { const double pe = st_ev[(pk & 0xffff) * p + k]; nx_ev[x] = (k == (pk >> 16)) ? pe + r_fd[sid] : pe; }
                 }
             } else {
             for (uint32_t x = lane; x < NS; x += 64) { ref[x] = 0; leader[x] = 0xffffffffu; }
@@ -878,6 +1003,7 @@ void beam_slab_kernel(BeamArgs g) {
                 const uint32_t sid = st_sl[(pk & 0xffff) * p + k];
                 nx_sl[x] = (uint16_t)sid;
                 if (k != (pk >> 16)) ref[sid] = 1;
+                if constexpr (ARITH) { const double pe = st_ev[(pk & 0xffff) * p + k]; nx_ev[x] = (k == (pk >> 16)) ? pe + r_fd[sid] : pe; }
             }
             u_old = surv ? st_sl[pj * p + kj] : 0;
             if (surv) atomicMin(&leader[u_old], lane);
@@ -909,6 +1035,10 @@ void beam_slab_kernel(BeamArgs g) {
             }
             // survivor records
             if (surv) {
+                if constexpr (ARITH) {
+                    if (heap_kept) { st_h1[lane] = n_h1; st_h2[lane] = n_h2; const uint32_t ix = lane * p + kj; st_ev[ix] = st_ev[ix] + r_fd[st_sl[ix]]; }     // (pj == lane)
+                    else { nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; }
+                } else
                 if (heap_kept) { st_q[lane] = n_q; st_h1[lane] = n_h1; st_h2[lane] = n_h2; st_m[lane] = n_m; }
                 else { nx_q[lane] = n_q; nx_h1[lane] = n_h1; nx_h2[lane] = n_h2; nx_m[lane] = n_m; }
                 if (!fastm) nx_sl[lane * p + kj] = newid[u_old];
@@ -1019,9 +1149,9 @@ void beam_slab_kernel(BeamArgs g) {
                     const float rcp_tl = __builtin_amdgcn_rcpf((float)tl);
                     auto addr_of = [&](uint32_t x, uint32_t& w) -> uint64_t* {
                         const uint32_t e = div_small(x, rcp_tl), c = x - e * tl;
-                        const uint32_t aw = c_aw[c];
+                        const uint32_t aw = c_aw[c * CST];
                         w = aw & 0x0fffffffu;
-                        return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + (c_snp[c] - pos0) * pos_bytes + (aw >> 28) * 8));
+                        return (uint64_t*)(pool + ((uint32_t)freelist[e] * slab_bytes + (c_snp[c * CST] - pos0) * pos_bytes + (aw >> 28) * 8));
                     };
                     // read-modify-writes in flight per lane, branch-free: the tail slots go to the lane's dummy words in the slot's
                     // scratch.  (A load left unconsumed on some path makes hipcc wait vmcnt(0) at the top of the next step, i.e.
@@ -1040,8 +1170,8 @@ void beam_slab_kernel(BeamArgs g) {
                                 const uint32_t cc = lane + 64u * c;
                                 okc[c] = cc < tl;
                                 const uint32_t cx = okc[c] ? cc : 0u;
-                                const uint32_t aw = c_aw[cx];
-                                pr[c] = c_snp[cx] - pos0; w[c] = aw & 0x0fffffffu; al[c] = aw >> 28;
+                                const uint32_t aw = c_aw[cx * CST];
+                                pr[c] = c_snp[cx * CST] - pos0; w[c] = aw & 0x0fffffffu; al[c] = aw >> 28;
                             }
                             uint32_t idx[AU]; uint2 lo[AU]; uint32_t hv[AU];
 #pragma unroll
@@ -1085,7 +1215,7 @@ void beam_slab_kernel(BeamArgs g) {
                                 const bool ok = xx < items;
                                 const uint32_t xs = ok ? xx : 0;
                                 const uint32_t e = div_small(xs, rcp_tl), c = xs - e * tl;
-                                const uint32_t aw = c_aw[c], pr = c_snp[c] - pos0, sl = (uint32_t)freelist[e];
+                                const uint32_t aw = c_aw[c * CST], pr = c_snp[c * CST] - pos0, sl = (uint32_t)freelist[e];
                                 w[u] = aw & 0x0fffffffu; al[u] = aw >> 28;
                                 base[u] = ok ? (uint64_t*)(pool + (sl * slab_bytes + pr * pos_bytes)) : dummy + lane * A;
                                 cptr[u] = ok ? codes + (sl * span_pad + pr) : dummy_code + lane;

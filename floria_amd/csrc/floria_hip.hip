@@ -403,7 +403,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
 
     // ---- plan every ploidy once: kernel choice, grid, scratch per slot -------------------------------------------------------
     std::vector<PloidyPlan> plan(P + 1);
-    const uint64_t fx_ctrl = fl::fx_ctrl_bytes(span_max + 1), fx_slot = fl::fx_slot_bytes(span_max + 1), fx_bytes = fx_ctrl + fx_slot;       // (+1: a full table grows once more when an insert call follows, optimize_kernel.h)
+    const uint64_t fx_ctrl = fl::fx_ctrl_bytes(span_max + 1), fx_slot = fl::fx_slot_bytes(span_max + 1), fx_bytes = fx_ctrl + fx_slot;       // (+1: slack)
     const uint32_t mean_n = (uint32_t)(tot_reads / std::max<uint32_t>(1, n_jobs));
     for (uint32_t p = 1; p <= P; ++p) {
         PloidyPlan& q = plan[p];
@@ -416,7 +416,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.state_bytes = (uint64_t)LM * span_max * p * A * 8;
         // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
         q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + fl::SLAB_DUMMY_WORDS + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + the dummy words of beam_slab_kernel's branch-free tails
-        q.SL = fl::slab_lds_layout(LM, p, any_q0);
+        const bool arith_slab = K.arith && !any_q0 && K.beam_path != 1;      // the reference's running sums on the shared slabs (beam_slab_kernel<.., ARITH = true>)
+        q.SL = fl::slab_lds_layout(LM, p, any_q0, arith_slab);
         q.WL = fl::wide_lds_layout(LM, p, any_q0);
         q.LY = fl::beam_lds_layout(LM);
         q.beam_spec = A == 2 && !any_q0 && B == 10 && p >= 2 && p <= 5 && !K.no_specialized;
@@ -439,7 +440,10 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             case 3: q.wide = wide_ok; q.slab = q.slab && !wide_ok; break;      // wide (where it applies)
             default: break;
         }
-        if (K.arith) {                                       // the reference's running sums: the generic kernel's lanes already walk a read's cells one by one
+        if (K.arith && q.slab && arith_slab) {               // the reference's running sums on the shared slabs: LDS (the terms of a step) allows two waves per SIMD
+            q.wide = false;
+            q.beam_slots = std::min<uint32_t>(nj_max, ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * fl::SLAB_WAVES_ARITH, by_lds));
+        } else if (K.arith) {                                // ... or the generic kernel, whose lanes walk a read's cells one by one (q = 0 pileups, beams too wide for the register heap)
             q.slab = false; q.wide = false; q.beam_spec = false;
             q.LY = fl::beam_lds_layout(LM, p);
             q.beam_slots = std::min<uint32_t>(nj_max, ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(16, std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.LY.total + 256)))));
@@ -586,7 +590,16 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         // jobs are needed at all) find room on the chip, and jobs that are dequeued later are dropped more often
         const uint32_t slots = wait_tried ? std::max<uint32_t>(1, std::min(slots_full, (uint32_t)ctx->n_cu * K.tail_waves)) : gated ? std::max<uint32_t>(1, std::min(slots_full, std::max<uint32_t>((uint32_t)ctx->n_cu, slots_full / K.spec_gate_div))) : slots_full;
         auto fire = [&](uint32_t slots) -> int {
-            if (K.arith) {
+            if (K.arith && q.slab) {
+                const bool sp = a.stop_at != nullptr || wait_tried != 0;
+                auto L = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(slots), dim3(64), q.SL.total, st, a); };
+                if (q.beam_spec && p == 2) { if (sp) L(fl::beam_slab_kernel<2, false, 2, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 2, 10, false, true>); }
+                else if (q.beam_spec && p == 3) { if (sp) L(fl::beam_slab_kernel<2, false, 3, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 3, 10, false, true>); }
+                else if (q.beam_spec && p == 4) { if (sp) L(fl::beam_slab_kernel<2, false, 4, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 4, 10, false, true>); }
+                else if (q.beam_spec && p == 5) { if (sp) L(fl::beam_slab_kernel<2, false, 5, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 5, 10, false, true>); }
+                else if (sp) L(fl::beam_slab_kernel<A, false, 0, 0, true, true>);
+                else L(fl::beam_slab_kernel<A, false, 0, 0, false, true>);
+            } else if (K.arith) {
                 HIPCHK(big_lds((const void*)fl::beam_kernel<A, true>, q.LY.total));
                 hipLaunchKernelGGL((fl::beam_kernel<A, true>), dim3(slots), dim3(64), q.LY.total, st, a);
             } else if (q.wide) {

@@ -152,7 +152,6 @@ void optimize_kernel(OptArgs g) {
     __shared__ double s_score;
     __shared__ double s_errf[MAX_PLOIDY];            // ARITH: running `errors` of every partition
     __shared__ uint32_t s_cntk[MAX_PLOIDY + 1];      // ARITH: positions in every partition's map
-    __shared__ unsigned long long s_lastcall[MAX_PLOIDY];
     uint32_t* s_moved = (uint32_t*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -305,8 +304,8 @@ void optimize_kernel(OptArgs g) {
         };
 
         // ARITH: the same statistics with `errors` as the reference's running sum.  The position map of partition k is filled by its reads in ascending
-        // order, every read's cells in set order; only the FIRST insertion of a position moves anything (and one more reserve(1) if an insert call
-        // follows the one that used up the table's room).  (1) first-insertion key of every (partition, position) by atomicMin, (2) sort, (3) one
+        // order, every read's cells in set order, through `hap_map.entry(*pos).or_insert(..)` (utils_frags.rs:165): std looks the key up first and reserves
+        // room only for a key that is not there, so only the FIRST insertion of a position moves anything.  (1) first-insertion key of every (partition, position) by atomicMin, (2) sort, (3) one
         // thread per partition replays the insertions into the emulated table, (4) and walks its buckets adding the terms of :244-253 in that order.
         auto mec_stats_arith = [&](bool phred) {
             uint64_t* fk = g.fk_pool + (uint64_t)blockIdx.x * g.span_max * p;
@@ -319,7 +318,7 @@ void optimize_kernel(OptArgs g) {
             const bool k32 = g.fk_lds_off != 0;                                 // (LDS atomics: the HBM ones were a third of this kernel's time)
             if (k32) for (uint32_t x = tid; x < M; x += OPT_THREADS) fk32[x] = ~0u;
             else for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
-            if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; s_lastcall[tid] = 0; }
+            if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; }
             __syncthreads();
             OPT_TICK(14);    // (ARITH) key table cleared
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
@@ -336,7 +335,6 @@ void optimize_kernel(OptArgs g) {
                             else atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
                         }
                 }
-                if (sub == 0 && i < n) atomicMax(&s_lastcall[k], ((unsigned long long)i << 24) | (len - 1));
             }
             __syncthreads();
             OPT_TICK(15);    // (ARITH) atomicMin pass
@@ -369,7 +367,6 @@ void optimize_kernel(OptArgs g) {
                     const uint32_t cnt = D - d0 < 64u ? D - d0 : 64u;
                     for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
                 }
-                if (D && t.growth_left == 0 && (~sk[start + D - 1] & 0x00ffffffffffffffull) != s_lastcall[k]) t.reserve(1, spare_c, spare_s, lane);     // a later insert call of a position already there
 #ifdef FLORIA_PROF
                 if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's replay
 #endif

@@ -165,6 +165,18 @@ struct FxSet {
         set_ctrl(idx, h2(h)); slot[idx] = key; ++items;
         return true;
     }
+    // HashMap::entry(key).or_insert(..) (std's rustc_entry): the key is looked up FIRST and room for one more is reserved only on the Vacant
+    // path, so touching a key that is already there never grows a full table — unlike insert above, which reserves before it looks
+    // (hashbrown's find_or_find_insert_slot).  set_to_seq_dict fills its position map this way (utils_frags.rs:165).
+    bool entry_insert(uint64_t key) {
+        if (find(key) >= 0) return false;
+        reserve(1);
+        const uint64_t h = hash_of(key);
+        const size_t idx = find_insert_slot(h);
+        if (ctrl[idx] == EMPTY) --growth_left;
+        set_ctrl(idx, h2(h)); slot[idx] = key; ++items;
+        return true;
+    }
     bool remove(uint64_t key) {
         const long f = find(key);
         if (f < 0) return false;
@@ -591,7 +603,7 @@ std::vector<QM> mec_stats_of_block(const HapBlock& hb, uint64_t one, const Pile*
         if (P && P->order && part_order) {
             FxSet pos_map;
             for (uint32_t r : (*part_order)[pi])
-                for (uint32_t cc = P->beg(r); cc < P->end(r); ++cc) pos_map.insert(P->p->snp[P->order[cc]]);
+                for (uint32_t cc = P->beg(r); cc < P->end(r); ++cc) pos_map.entry_insert(P->p->snp[P->order[cc]]);      // hap_map.entry(*pos).or_insert(..) (utils_frags.rs:165)
             if (g_arith_mode.load(std::memory_order_relaxed) == 2) {       // ascending positions
                 std::vector<uint32_t> ps;
                 pos_map.for_each([&](uint64_t pos) { ps.push_back((uint32_t)pos); });
