@@ -26,7 +26,9 @@ __host__ __device__ inline uint32_t fx_buckets_for(uint32_t cap) {
 }
 // bytes of ONE table able to hold `cap` keys: control bytes (buckets + one mirrored group) and keys — two arrays, so that the control bytes,
 // which every probe reads, can sit in LDS while the keys stay in HBM scratch
-__host__ __device__ inline size_t fx_ctrl_bytes(uint32_t cap) { return ((size_t)fx_buckets_for(cap < 1 ? 1 : cap) + FX_W + 15) & ~(size_t)15; }
+// (+16: FxWave::probe16 reads the group at an unaligned position as five aligned words)
+__host__ __device__ inline size_t fx_ctrl_bytes(uint32_t cap) { return (((size_t)fx_buckets_for(cap < 1 ? 1 : cap) + FX_W + 15) & ~(size_t)15) + 16; }
+constexpr uint32_t FX_TAGS = 128;                    // FxWave::insert_batch: words of the conflict-detection table
 __host__ __device__ inline size_t fx_slot_bytes(uint32_t cap) { return 4ull * fx_buckets_for(cap < 1 ? 1 : cap); }
 
 struct FxTable {
@@ -166,6 +168,102 @@ struct FxWave {
     __device__ void insert_new(uint32_t key, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
         if (growth_left == 0) reserve(1, spare_c, spare_s, lane);
         put(key, lane);
+    }
+
+    // ---- many insertions per round (control bytes in LDS, tables of at least one full group) -------------------------------------------------
+    // Sequential insertion puts key e into the first EMPTY byte along ITS probe sequence given what keys 0..e-1 filled.  If every key of a batch
+    // computes that byte from the state BEFORE the batch and the results are pairwise distinct, they are the sequential result: a byte that an earlier
+    // key of the batch fills cannot lie before key e's own choice on e's probe sequence (it was EMPTY, e would have chosen it), so it can only
+    // matter by BEING e's choice.  Hence: every lane probes for its key at once (its group = five aligned LDS words, funnel-shifted), the lanes
+    // claim their byte in a small tag table with an LDS atomic min on their sequence rank, and the longest prefix of ranks without a lost claim
+    // is committed; the rest goes again.  A round places ~10 keys in the time the one-by-one form places one or two.
+    __device__ void bind_lds(uint8_t* c, uint32_t* s, uint32_t nb, uint32_t lane) {        // bind with the control bytes in LDS, written with DS stores like every later access
+        ctrl = c; slot = s; hbm = false;
+        buckets = nb; items = 0; growth_left = fx_cap_of(nb);
+        __attribute__((address_space(3))) uint32_t* const lc = (__attribute__((address_space(3))) uint32_t*)c;
+        for (uint32_t i = lane; i < (nb + FX_W) / 4; i += 64) lc[i] = 0xffffffffu;
+    }
+    // put() for a table smaller than a group, control bytes in LDS (the group at any position reaches the always-EMPTY padding, so the first probe decides)
+    __device__ void put_small_lds(uint32_t key, uint32_t lane) {
+        __attribute__((address_space(3))) uint8_t* const lc = (__attribute__((address_space(3))) uint8_t*)ctrl;
+        const uint64_t h = FxTable::hash_of(key);
+        const uint32_t mask = buckets - 1, pos = (uint32_t)h & mask;
+        const uint32_t c = lane < FX_W ? lc[pos + lane] : 0u;
+        uint32_t idx = (pos + (uint32_t)__builtin_ctz((uint32_t)__ballot((c & 0x80u) != 0u) & 0xffffu)) & mask;
+        if (!(lc[idx] & 0x80u)) {                                 // the hit was in the padding: the real slot is the first EMPTY one from 0
+            const uint32_t c0 = lane < FX_W ? lc[lane] : 0u;
+            idx = (uint32_t)__builtin_ctz((uint32_t)__ballot((c0 & 0x80u) != 0u) & 0xffffu);
+        }
+        if (lane == 0) { const uint8_t h2 = (uint8_t)(h >> 57); lc[idx] = h2; lc[((idx - FX_W) & mask) + FX_W] = h2; slot[idx] = key; }
+        --growth_left; ++items;
+    }
+    // this lane's key: first EMPTY byte along the probe sequence of h (per-lane loop; buckets >= FX_W)
+    __device__ uint32_t probe16(uint64_t h) const {
+        const uint32_t mask = buckets - 1;
+        uint32_t pos = (uint32_t)h & mask, stride = 0;
+        for (;;) {
+            const __attribute__((address_space(3))) uint32_t* w = (const __attribute__((address_space(3))) uint32_t*)(ctrl + (pos & ~3u));      // (LDS, not flat)
+            const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+            const uint32_t sh = (pos & 3u) * 8u;
+            const uint64_t lo = (uint64_t)(__builtin_amdgcn_alignbit(d1, d0, sh) & 0x80808080u) | ((uint64_t)(__builtin_amdgcn_alignbit(d2, d1, sh) & 0x80808080u) << 32);
+            const uint64_t hi = (uint64_t)(__builtin_amdgcn_alignbit(d3, d2, sh) & 0x80808080u) | ((uint64_t)(__builtin_amdgcn_alignbit(d4, d3, sh) & 0x80808080u) << 32);
+            if (lo | hi) {
+                const uint32_t bit = lo ? (uint32_t)__builtin_ctzll(lo) >> 3 : 8u + ((uint32_t)__builtin_ctzll(hi) >> 3);
+                return (pos + bit) & mask;
+            }
+            stride += FX_W; pos = (pos + stride) & mask;
+        }
+    }
+    // keys of the lanes with `valid`, in the order of their ranks r = 0..cnt-1 (ascending with the lane); grow = may this table grow (false inside a resize).
+    // tag: FX_TAGS LDS words, all ones between calls.
+    __device__ void insert_batch(uint32_t key, bool valid, uint32_t r, uint32_t cnt, uint32_t* tag, bool grow, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+        uint32_t done = 0;
+        const uint64_t h = FxTable::hash_of(key);
+        while (done < cnt) {
+            if (grow && growth_left == 0) grow_batched(tag, spare_c, spare_s, lane);
+            if (buckets < FX_W) {                           // tables smaller than a group (the first seven keys): one by one
+                const uint64_t at = __ballot(valid && r == done);
+                put_small_lds((uint32_t)__shfl((int)key, (int)__builtin_ctzll(at)), lane);
+                ++done;
+                continue;
+            }
+            const uint32_t lim = cnt < done + growth_left ? cnt : done + growth_left;
+            const bool act = valid && r >= done && r < lim;
+            const uint32_t target = act ? probe16(h) : 0u;
+            const uint32_t tg = target & (FX_TAGS - 1u);
+            __attribute__((address_space(3))) uint32_t* const tp = (__attribute__((address_space(3))) uint32_t*)tag + tg;
+            if (act) (void)__hip_atomic_fetch_min(tp, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t won = act ? __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : r;
+            const uint64_t lm = __ballot(act && won != r);
+            const uint32_t lstar = lm ? (uint32_t)__shfl((int)r, (int)__builtin_ctzll(lm)) : lim;
+            if (act && r < lstar) {
+                const uint8_t h2 = (uint8_t)(h >> 57);
+                __attribute__((address_space(3))) uint8_t* const lc = (__attribute__((address_space(3))) uint8_t*)ctrl;
+                lc[target] = h2; lc[((target - FX_W) & (buckets - 1)) + FX_W] = h2;
+                slot[target] = key;
+            }
+            if (act) __hip_atomic_store(tp, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t nn = lstar - done;
+            growth_left -= nn; items += nn; done = lstar;
+        }
+    }
+    // reserve(1) on a full table, the old table's keys re-inserted in bucket order, 64 buckets at a time
+    __device__ void grow_batched(uint32_t* tag, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+        const uint32_t full_cap = fx_cap_of(buckets), want = items + 1 > full_cap + 1 ? items + 1 : full_cap + 1;
+        FxWave n;
+        n.bind_lds(spare_c, spare_s, fx_buckets_for(want), lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");               // the keys (HBM scratch) were stored by other lanes of this wave
+        for (uint32_t i0 = 0; i0 < buckets; i0 += 64) {
+            const bool in = i0 + lane < buckets;
+            const uint32_t c = in ? ((const __attribute__((address_space(3))) uint8_t*)ctrl)[i0 + lane] : 0xffu;
+            const uint32_t key = in ? slot[i0 + lane] : 0u;
+            const bool fullb = !(c & 0x80u);
+            const uint64_t fm = __ballot(fullb);
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            n.insert_batch(key, fullb, r, (uint32_t)__popcll(fm), tag, false, spare_c, spare_s, lane);
+        }
+        spare_c = ctrl; spare_s = slot;
+        *this = n;
     }
 };
 

@@ -466,7 +466,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global;
         const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
         q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0);
-        if (K.arith && !K.arith_hbm && q.opt_lds + (size_t)p * 2 * fx_ctrl + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * 2 * fx_ctrl; }      // (the control bytes, which every probe reads)
+        if (K.arith && !K.arith_hbm && q.opt_lds + (size_t)p * (2 * fx_ctrl + 4 * fl::FX_TAGS) + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * (2 * fx_ctrl + 4 * fl::FX_TAGS); }      // (the control bytes, which every probe reads)
         if (K.arith && !K.arith_hbm && n_max < (1u << 20) && ctx->cur_len_max < 4096u && q.opt_lds + (size_t)p * span_max * 4 + 16 <= 60 * 1024) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += ((size_t)p * span_max * 4 + 15) & ~(size_t)15; }
         q.opt_lds += 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
@@ -505,7 +505,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         sl_ogain = std::max(sl_ogain, up256((uint64_t)q.opt_slots * q.cand_cap * 8));
         sl_okey = std::max(sl_okey, up256((uint64_t)q.opt_slots * q.cand_cap * 4));
         sl_omoves = std::max(sl_omoves, up256((uint64_t)q.opt_slots * n_max * 4));
-        if (K.arith) sl_arith = std::max(sl_arith, up256((uint64_t)q.opt_slots * ((uint64_t)p * span_max * 8 + sort_cap_of(p) * 12 + (uint64_t)p * 2 * fx_bytes) + 64));
+        if (K.arith) sl_arith = std::max(sl_arith, up256((uint64_t)q.opt_slots * ((uint64_t)p * span_max * 8 + sort_cap_of(p) * 12 + (uint64_t)p * 2 * fx_bytes + 16 + (uint64_t)p * span_max * 8) + 64));
     }
     {   // (a pool that has to grow is freed first: hipFree synchronises the device, and nothing of this call is in flight yet)
         int rc = ctx->state_pool.ensure(sl_state * n_lanes); if (rc) return rc;
@@ -694,7 +694,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         a.fk_pool = (uint64_t*)base; base += (uint64_t)slots * p * span_max * 8;
                         a.sk_pool = (uint64_t*)base; base += (uint64_t)slots * a.sort_cap * 8;
                         a.sp_pool = (uint32_t*)base; base += ((uint64_t)slots * a.sort_cap * 4 + 15) & ~(uint64_t)15;
-                        a.fx_pool = (uint8_t*)base;
+                        a.fx_pool = (uint8_t*)base; base += (((uint64_t)slots * p * 2 * fx_bytes) + 15) & ~(uint64_t)15;
+                        a.ol_pool = (uint32_t*)base;
                     }
                     if (W > 1) { a.stop_at = d_stop; a.ready = d_ready; for (uint32_t q2 = 2; q2 <= P; ++q2) a.thresholds[q2] = mec_threshold(prm, q2); }
                     int t = T.begin(K_OPT, st);

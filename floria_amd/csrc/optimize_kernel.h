@@ -69,8 +69,9 @@ struct OptArgs {
     uint64_t* sk_pool;           // [slots][sort_cap]         sort keys
     uint32_t* sp_pool;           // [slots][sort_cap]         sorted (partition, position) entries
     uint8_t*  fx_pool;           // [slots][ploidy][2][fx_ctrl + fx_slot] the emulated position maps: control bytes, keys
+    uint32_t* ol_pool;           // [slots][2][ploidy][span_max] every partition's positions (block-relative) in the bucket order of its map, two parities
     uint64_t  sort_cap, fx_ctrl, fx_slot;
-    uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl])
+    uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl], then [ploidy][FX_TAGS] words)
     uint32_t  pm_lds_off;        // != 0: the visiting order of the build and distance passes (u16 read indices, longest reads first) in LDS at this offset ([n_max])
     uint32_t  fk_lds_off;        // != 0: the first-insertion keys as 32-bit words (read << 12 | cell rank: reads < 2^20, cells per read < 2^12) in LDS at this offset ([ploidy*span_max])
 };
@@ -152,6 +153,7 @@ void optimize_kernel(OptArgs g) {
     __shared__ double s_score;
     __shared__ double s_errf[MAX_PLOIDY];            // ARITH: running `errors` of every partition
     __shared__ uint32_t s_cntk[MAX_PLOIDY + 1];      // ARITH: positions in every partition's map
+    __shared__ uint32_t s_cnt2[2][MAX_PLOIDY];       // ... of the two position lists
     uint32_t* s_moved = (uint32_t*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -305,9 +307,62 @@ void optimize_kernel(OptArgs g) {
 
         // ARITH: the same statistics with `errors` as the reference's running sum.  The position map of partition k is filled by its reads in ascending
         // order, every read's cells in set order, through `hap_map.entry(*pos).or_insert(..)` (utils_frags.rs:165): std looks the key up first and reserves
-        // room only for a key that is not there, so only the FIRST insertion of a position moves anything.  (1) first-insertion key of every (partition, position) by atomicMin, (2) sort, (3) one
-        // thread per partition replays the insertions into the emulated table, (4) and walks its buckets adding the terms of :244-253 in that order.
-        auto mec_stats_arith = [&](bool phred) {
+        // room only for a key that is not there, so only the FIRST insertion of a position moves anything.  (1) first-insertion key of every (partition,
+        // position) by atomicMin — behind a plain read: the reads are visited in ascending order, so most keys lose against what is already there and
+        // never issue the atomic; (2) sort; (3) one WAVEFRONT per partition replays the insertions into the emulated table, many per round
+        // (arith_kernel.h: FxWave::insert_batch); (4) and walks its buckets, adding the terms of :244-253 in that order — and writing the positions down
+        // in that order (`olist`, two parities): the statistics of the same partition in the other weighting (the final unit-count pass, :187-215) or
+        // after a rejected round walk the list again instead of replaying the map.
+        // par = which list is written (reuse = false) or walked again (reuse = true).
+        auto mec_stats_arith = [&](bool phred, uint32_t par, bool reuse) {
+            uint32_t* const olist = g.ol_pool + ((uint64_t)blockIdx.x * 2 + par) * g.span_max * p;          // [partition][span_max]
+            const uint64_t one = phred ? ONE_Q24 : 1ull;
+            const double scale = phred ? 0x1p-24 : 1.0;
+            // the terms of 64 listed positions (lane = entry; `have` = this lane holds one), added in lane order onto ef; returns the lanes' consensus counts
+            auto fold64 = [&](uint32_t k, uint32_t posrel, bool have, double& ef) -> uint64_t {
+                const uint64_t* cp = hist + (uint64_t)(have ? posrel : 0u) * PA + k * A;
+                uint64_t q[A];
+#pragma unroll
+                for (int al = 0; al < A; ++al) { const uint64_t v = cp[al]; q[al] = phred ? (v & QMASK44) : (v >> CNT_SHIFT); }
+#pragma unroll
+                for (int x = 1; x < A; ++x)                                  // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
+#pragma unroll
+                    for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
+                double term[A];                                              // [A - 1]: errors += epsilon if cons_bases <= 1 (:251-253), else + 0.0
+#pragma unroll
+                for (int x = 0; x + 1 < A; ++x) term[x] = (double)q[x] * scale;
+                term[A - 1] = q[A - 1] <= one ? g.eps : 0.0;
+                uint64_t hm = __ballot(have);
+                while (hm) {                                                 // (wave-uniform: the sum is the one sequential thing here)
+                    const uint32_t l = (uint32_t)__builtin_ctzll(hm);
+                    hm &= hm - 1;
+#pragma unroll
+                    for (int x = 0; x < A; ++x) {
+                        const uint64_t tb = (uint64_t)__double_as_longlong(term[x]);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb, (int)l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb >> 32), (int)l);
+                        ef += __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));          // :248-250 all but the last, then :251-253
+                    }
+                }
+                return have ? q[A - 1] : 0ull;
+            };
+            if (reuse) {
+                for (uint32_t k = wid; k < p; k += OPT_THREADS / 64) {
+                    const uint32_t D = s_cnt2[par][k];
+                    double ef = 0.0;
+                    uint64_t good = 0;
+                    for (uint32_t d0 = 0; d0 < D; d0 += 64) {
+                        const bool have = d0 + lane < D;
+                        const uint32_t posrel = have ? olist[(uint64_t)k * g.span_max + d0 + lane] : 0u;
+                        good += fold64(k, posrel, have, ef);
+                    }
+                    good = wave_sum_u64(good);
+                    if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
+                }
+                __syncthreads();
+                if (tid == 0 && phred) { double sc = 0.0; for (uint32_t k = 0; k < p; ++k) sc += s_errf[k]; s_score = sc * -1.0; }
+                __syncthreads();
+                return;
+            }
             uint64_t* fk = g.fk_pool + (uint64_t)blockIdx.x * g.span_max * p;
             const uint32_t M = span * p;
             uint32_t M2 = 1;
@@ -319,6 +374,7 @@ void optimize_kernel(OptArgs g) {
             if (k32) for (uint32_t x = tid; x < M; x += OPT_THREADS) fk32[x] = ~0u;
             else for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
             if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; }
+            if (g.fx_lds_off) for (uint32_t x = tid; x < p * FX_TAGS; x += OPT_THREADS) ((uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl))[x] = 0xffffffffu;
             __syncthreads();
             OPT_TICK(14);    // (ARITH) key table cleared
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
@@ -331,8 +387,9 @@ void optimize_kernel(OptArgs g) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         if (sn[u]) {
-                            if (k32) atomicMin(&fk32[k * span + (sn[u] - pos0)], (i << 12) | (c0 + 16 * u));
-                            else atomicMin((unsigned long long*)&fk[k * span + (sn[u] - pos0)], ((unsigned long long)i << 24) | (c0 + 16 * u));
+                            // (a stale value can only be larger than the current one: then the atomic is issued needlessly, never skipped wrongly)
+                            if (k32) { const uint32_t key = (i << 12) | (c0 + 16 * u); uint32_t* const a = &fk32[k * span + (sn[u] - pos0)]; if (*(volatile uint32_t*)a > key) atomicMin(a, key); }
+                            else { const unsigned long long key = ((unsigned long long)i << 24) | (c0 + 16 * u); unsigned long long* const a = (unsigned long long*)&fk[k * span + (sn[u] - pos0)]; if (*(volatile unsigned long long*)a > key) atomicMin(a, key); }
                         }
                 }
             }
@@ -359,51 +416,36 @@ void optimize_kernel(OptArgs g) {
                 uint8_t* c0 = g.fx_lds_off ? smem + g.fx_lds_off + (uint64_t)k * 2 * g.fx_ctrl : gmem;
                 uint8_t* spare_c = g.fx_lds_off ? c0 + g.fx_ctrl : gmem + fxb;
                 uint32_t* spare_s = (uint32_t*)(gmem + fxb + g.fx_ctrl);
+                uint32_t* const tag = (uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl) + k * FX_TAGS;        // (LDS tables only)
                 FxWave t;
                 t.hbm = g.fx_lds_off == 0;
-                if (D) t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane);
+                if (D) { if (g.fx_lds_off) t.bind_lds(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane); else t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane); }
                 for (uint32_t d0 = 0; d0 < D; d0 += 64) {                    // 64 positions of the sorted first-insertion list at a time
                     const uint32_t mine = d0 + lane < D ? sp[start + d0 + lane] - k * span + pos0 : 0u;
                     const uint32_t cnt = D - d0 < 64u ? D - d0 : 64u;
-                    for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
+                    if (g.fx_lds_off) t.insert_batch(mine, lane < cnt, lane, cnt, tag, true, spare_c, spare_s, lane);
+                    else for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");           // the keys (HBM scratch) were stored lane by lane; the walk reads them bucket by bucket
 #ifdef FLORIA_PROF
                 if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's replay
 #endif
-                // the buckets in order, 64 at a time: every lane prepares its bucket's terms, then they are added one by one (the sum is the one sequential thing here)
+                // the buckets in order, 64 at a time: every lane prepares its bucket's terms, then they are added one by one
                 double ef = 0.0;
                 uint64_t good = 0;
-                const uint64_t one = phred ? ONE_Q24 : 1ull;
-                const double scale = phred ? 0x1p-24 : 1.0;
-                for (uint32_t i0 = 0; i0 < t.buckets; i0 += 64) {
+                uint32_t written = 0;
+                for (uint32_t i0 = 0; i0 < (D ? t.buckets : 0u); i0 += 64) {
                     const bool in = i0 + lane < t.buckets;
                     const bool full = in && !(t.ctrl[in ? i0 + lane : 0] & 0x80);
                     const uint32_t key = t.slot[in ? i0 + lane : 0];
-                    const uint64_t* cp = hist + (uint64_t)(full ? key - pos0 : 0u) * PA + k * A;
-                    uint64_t q[A];
-#pragma unroll
-                    for (int al = 0; al < A; ++al) { const uint64_t v = cp[al]; q[al] = phred ? (v & QMASK44) : (v >> CNT_SHIFT); }
-#pragma unroll
-                    for (int x = 1; x < A; ++x)                                  // allele_counts.sort_by(count) (:244): ascending, absent alleles are zeros (x + 0.0 == x)
-#pragma unroll
-                        for (int y = A - 1; y >= x; --y) if (q[y] < q[y - 1]) { const uint64_t tq = q[y]; q[y] = q[y - 1]; q[y - 1] = tq; }
-                    double term[A - 1];
-#pragma unroll
-                    for (int x = 0; x + 1 < A; ++x) term[x] = (double)q[x] * scale;
-                    const bool low = q[A - 1] <= one;
-                    good += full ? q[A - 1] : 0ull;
-                    uint64_t fm = __ballot(full);
-                    const uint64_t lowm = __ballot(full && low);
-                    while (fm) {
-                        const int l = __builtin_ctzll(fm);
-                        fm &= fm - 1;
-#pragma unroll
-                        for (int x = 0; x + 1 < A; ++x) ef += shfl_f64(term[x], l);          // :248-250 all but the last
-                        if ((lowm >> l) & 1ull) ef += g.eps;                               // :251-253
-                    }
+                    const uint32_t posrel = full ? key - pos0 : 0u;
+                    const uint64_t fm = __ballot(full);
+                    if (full) olist[(uint64_t)k * g.span_max + written + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = posrel;
+                    written += (uint32_t)__popcll(fm);
+                    good += fold64(k, posrel, full, ef);
                 }
                 good = wave_sum_u64(good);
-                if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
+                if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = D; }
             }
             __syncthreads();
             OPT_TICK(12);    // (ARITH) replay + walk, slowest partition
@@ -414,14 +456,15 @@ void optimize_kernel(OptArgs g) {
             }
             __syncthreads();
         };
-        auto stats = [&](bool phred) { if constexpr (ARITH) mec_stats_arith(phred); else mec_stats(phred); };
+        uint32_t best_par = 0;                                 // ARITH: the list of the accepted partition
+        auto stats = [&](bool phred, uint32_t par, bool reuse) { if constexpr (ARITH) mec_stats_arith(phred, par, reuse); else mec_stats(phred); };
 
         refresh_codes(false);
         OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
         if (not_empty) {
-            stats(true);
+            stats(true, 0, false);
             OPT_TICK(1);     // first stats
             double prev_score = s_score;
             for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
@@ -433,7 +476,7 @@ void optimize_kernel(OptArgs g) {
 #ifdef FLORIA_OPT_FULL_DIST
                 const bool incremental = false;
 #else
-                const bool incremental = HL && !ARITH && meta && it > 0 && span <= 65535u;
+                const bool incremental = HL && meta && it > 0 && span <= 65535u;
 #endif
                 const uint32_t chg_lo = incremental ? s_chg_lo : 0u, chg_hi = incremental ? s_chg_hi : 0xffffffffu;
                 if constexpr (ARITH) {              // one thread per (read, partition): the running sum cannot be split over lanes
@@ -441,12 +484,25 @@ void optimize_kernel(OptArgs g) {
                         const uint32_t i = pair / p, k = pair - i * p;
                         uint32_t cb = 0, len = 0, kk = 0;
                         read_meta(i, cb, len, kk);
+                        if (incremental) { const uint32_t fl = m_fl[i]; if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) continue; }      // no code changed at any position of this read: its distances stand
                         double df = 0.0;
                         constexpr int DU = 4;                                    // cells per batch: order entries, cells and histogram rows requested together
                         for (uint32_t c0 = 0; c0 < len; c0 += DU) {
                             uint32_t aqs[DU], sn[DU]; uint64_t row[DU][A];
 #pragma unroll
                             for (int u = 0; u < DU; ++u) { const uint2 ca = ord[cb + (c0 + u < len ? c0 + u : len - 1)]; sn[u] = ca.x; aqs[u] = ca.y; }
+                            if constexpr (HL) {                                  // the code byte says it all: 0 = nothing observed, bit a = allele a attains the maximal sum
+                                uint32_t cds[DU];
+#pragma unroll
+                                for (int u = 0; u < DU; ++u) cds[u] = codes[(sn[u] - pos0) * p + k];
+#pragma unroll
+                                for (int u = 0; u < DU; ++u) {
+                                    if (c0 + u >= len) break;
+                                    if (cds[u] == 0u) df += g.eps;
+                                    else if (!((cds[u] >> (aqs[u] >> 28)) & 1u)) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;
+                                }
+                                continue;
+                            }
 #pragma unroll
                             for (int u = 0; u < DU; ++u) {
                                 const uint64_t* rp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
@@ -594,10 +650,10 @@ void optimize_kernel(OptArgs g) {
                 };
                 apply_moves(false);
                 OPT_TICK(6);     // moves
-                stats(true);
+                stats(true, best_par ^ 1u, false);
                 OPT_TICK(7);     // round stats
                 const double new_score = s_score;
-                if (new_score > prev_score) prev_score = new_score;
+                if (new_score > prev_score) { prev_score = new_score; best_par ^= 1u; }
                 else {                                   // rejected: keep best_part / prev_hap_block
                     apply_moves(true);
                     if (tid == 0) for (uint32_t x = 0; x < nm; ++x) { const uint32_t mvv = moves[x]; s_size[(mvv >> 4) & 15] += 1; s_size[mvv & 15] -= 1; }
@@ -608,7 +664,7 @@ void optimize_kernel(OptArgs g) {
         }
         // ---- get_mec_stats_epsilon_no_phred of the optimised partition (graph_processing.rs:156-162) -----------
         OPT_TICK(8);
-        stats(false);
+        stats(false, best_par, true);          // (ARITH: the accepted partition's position maps were replayed by the statistics call that accepted it)
         OPT_TICK(62);    // final stats (slot 62: slots 9-15 also hold the beam kernels' step counters, which made this phase look like 2.7 Gcycles in earlier profiles)
         if (tid == 0) {
             double mecv = 0.0, na = 0.0;
