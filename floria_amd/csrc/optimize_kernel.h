@@ -380,6 +380,17 @@ void optimize_kernel(OptArgs g) {
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                 uint32_t cb = 0, len = 0, k = 0;
                 if (i < n) { read_meta(i, cb, len, k); if (!meta) k = part[i]; }
+                // A read can only win a position that no earlier read of its partition holds.  The reads are sorted by their first position, so for most of
+                // them every position of their span is already taken when their turn comes: 16 lanes look at the span's keys in LDS first and skip the read's
+                // cells (the global loads this pass waits for) unless some key could still lose.  (Keys only ever decrease: a stale look errs towards loading.)
+                if (k32 && meta && span <= 65535u) {
+                    bool open = false;
+                    if (i < n) {
+                        const uint32_t fl = m_fl[i], thr = i << 12;
+                        for (uint32_t pr = (fl & 0xffffu) + sub; pr <= (fl >> 16); pr += 16) open |= *(volatile uint32_t*)&fk32[k * span + pr] >= thr;
+                    }
+                    if (!((__ballot(open) >> (lane & 48)) & 0xffffull)) len = 0;
+                }
                 for (uint32_t c0 = sub; c0 < len; c0 += 16 * 8) {              // (as the build pass: eight cells per lane requested before the first atomic)
                     uint32_t sn[8];
 #pragma unroll
