@@ -386,8 +386,14 @@ void optimize_kernel(OptArgs g) {
                 if (k32 && meta && span <= 65535u) {
                     bool open = false;
                     if (i < n) {
-                        const uint32_t fl = m_fl[i], thr = i << 12;
-                        for (uint32_t pr = (fl & 0xffffu) + sub; pr <= (fl >> 16); pr += 16) open |= *(volatile uint32_t*)&fk32[k * span + pr] >= thr;
+                        const uint32_t fl = m_fl[i], thr = i << 12, lastp = fl >> 16;
+                        for (uint32_t pr0 = (fl & 0xffffu) + sub; pr0 <= lastp; pr0 += 128) {          // eight keys per lane and round trip
+                            uint32_t v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const uint32_t pr = pr0 + 16u * u; v[u] = pr <= lastp ? fk32[k * span + pr] : 0u; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) open |= v[u] >= thr;
+                        }
                     }
                     if (!((__ballot(open) >> (lane & 48)) & 0xffffull)) len = 0;
                 }
@@ -395,17 +401,26 @@ void optimize_kernel(OptArgs g) {
                     uint32_t sn[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + 16 * u; sn[u] = c < len ? ord[cb + c].x : 0u; }          // (SNP indices are 1-based: 0 = no cell)
+                    uint32_t curv[8];                                          // (a stale value can only be larger than the current one: then the atomic is issued needlessly, never skipped wrongly)
+                    if (k32) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) curv[u] = sn[u] ? fk32[k * span + (sn[u] - pos0)] : 0u;
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         if (sn[u]) {
-                            // (a stale value can only be larger than the current one: then the atomic is issued needlessly, never skipped wrongly)
-                            if (k32) { const uint32_t key = (i << 12) | (c0 + 16 * u); uint32_t* const a = &fk32[k * span + (sn[u] - pos0)]; if (*(volatile uint32_t*)a > key) atomicMin(a, key); }
+                            if (k32) { const uint32_t key = (i << 12) | (c0 + 16 * u); if (curv[u] > key) atomicMin(&fk32[k * span + (sn[u] - pos0)], key); }
                             else { const unsigned long long key = ((unsigned long long)i << 24) | (c0 + 16 * u); unsigned long long* const a = (unsigned long long*)&fk[k * span + (sn[u] - pos0)]; if (*(volatile unsigned long long*)a > key) atomicMin(a, key); }
                         }
                 }
             }
             __syncthreads();
             OPT_TICK(15);    // (ARITH) atomicMin pass
+            // (2) the order of the first insertions.  Keys in LDS and at most 256 positions (every BASELINE config): partition k's wavefront ranks its own row by
+            // counting — key e's rank = the number of smaller keys, every key read by all lanes at once — and writes the positions back IN PLACE in that order
+            // (a wave's LDS operations execute in order: every read of the row precedes the first write).  No workgroup-wide sort, no barrier.
+            const bool wave_sort = k32 && span <= 1024u;
+            if (!wave_sort) {
             for (uint32_t x = tid; x < M2; x += OPT_THREADS) {
                 uint64_t f = ~0ull;
                 if (x < M) { if (k32) { const uint32_t f32 = fk32[x]; f = f32 == ~0u ? ~0ull : ((uint64_t)(f32 >> 12) << 24) | (f32 & 0xfffu); } else f = fk[x]; }
@@ -417,11 +432,32 @@ void optimize_kernel(OptArgs g) {
             __syncthreads();
             OPT_TICK(10);    // (ARITH) first-insertion keys
             bitonic_sort(sk, sp, M2, tid, OPT_THREADS);
+            }
             OPT_TICK(11);    // (ARITH) sort
             for (uint32_t k = wid; k < p; k += OPT_THREADS / 64) {            // a wavefront per partition: the table is driven by all 64 lanes (arith_kernel.h: FxWave)
-                uint32_t start = 0;
-                for (uint32_t q = 0; q < k; ++q) start += s_cntk[q];
-                const uint32_t D = s_cntk[k];
+                uint32_t start = 0, D = 0;
+                uint32_t* const row = fk32 + k * span;
+                if (wave_sort) {
+                    uint32_t mykey[16], rk[16];                                // lane l owns the keys l, l + 64, ...: four per sweep over the row
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { const uint32_t e = lane + 64u * j; mykey[j] = e < span ? row[e] : ~0u; rk[j] = 0; }
+#pragma unroll
+                    for (int j0 = 0; j0 < 16; j0 += 4) {
+                        if (64u * j0 < span)
+                            for (uint32_t x = 0; x < span; ++x) {
+                                const uint32_t o = row[x];
+#pragma unroll
+                                for (int j = j0; j < j0 + 4; ++j) rk[j] += o < mykey[j] ? 1u : 0u;
+                            }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) D += (uint32_t)__popcll(__ballot(mykey[j] != ~0u));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if (mykey[j] != ~0u) row[rk[j]] = lane + 64u * j;          // (keys are distinct: (read, cell rank) of one first insertion each)
+                } else {
+                    for (uint32_t q = 0; q < k; ++q) start += s_cntk[q];
+                    D = s_cntk[k];
+                }
                 const uint64_t fxb = g.fx_ctrl + g.fx_slot;
                 uint8_t* gmem = g.fx_pool + ((uint64_t)blockIdx.x * p + k) * 2 * fxb;
                 uint8_t* c0 = g.fx_lds_off ? smem + g.fx_lds_off + (uint64_t)k * 2 * g.fx_ctrl : gmem;
@@ -432,7 +468,7 @@ void optimize_kernel(OptArgs g) {
                 t.hbm = g.fx_lds_off == 0;
                 if (D) { if (g.fx_lds_off) t.bind_lds(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane); else t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane); }
                 for (uint32_t d0 = 0; d0 < D; d0 += 64) {                    // 64 positions of the sorted first-insertion list at a time
-                    const uint32_t mine = d0 + lane < D ? sp[start + d0 + lane] - k * span + pos0 : 0u;
+                    const uint32_t mine = d0 + lane < D ? (wave_sort ? row[d0 + lane] : sp[start + d0 + lane] - k * span) + pos0 : 0u;
                     const uint32_t cnt = D - d0 < 64u ? D - d0 : 64u;
                     if (g.fx_lds_off) t.insert_batch(mine, lane < cnt, lane, cnt, tag, true, spare_c, spare_s, lane);
                     else for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
@@ -497,7 +533,7 @@ void optimize_kernel(OptArgs g) {
                         read_meta(i, cb, len, kk);
                         if (incremental) { const uint32_t fl = m_fl[i]; if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) continue; }      // no code changed at any position of this read: its distances stand
                         double df = 0.0;
-                        constexpr int DU = 4;                                    // cells per batch: order entries, cells and histogram rows requested together
+                        constexpr int DU = HL ? 8 : 4;                           // cells per batch: order entries, cells and histogram rows / code bytes requested together
                         for (uint32_t c0 = 0; c0 < len; c0 += DU) {
                             uint32_t aqs[DU], sn[DU]; uint64_t row[DU][A];
 #pragma unroll
