@@ -305,6 +305,57 @@ void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
 
+        // ARITH, opt_iterate's distances (local_clustering.rs:292-326): one thread per (read, partition) — the running sum cannot be split over lanes —, threads t0,
+        // t0 + 1, .. of nt.  They depend on the histogram only, so the pass for round r + 1 runs on the wavefronts that have no position map to replay while
+        // the statistics of round r are computed (a rejected round r makes them useless, and is the last).  inc: only the reads that reach into the interval of
+        // positions whose code byte changed in the last batch of moves.
+        auto dist_arith = [&](uint32_t t0, uint32_t nt, bool inc) {
+            const uint32_t chg_lo = inc ? s_chg_lo : 0u, chg_hi = inc ? s_chg_hi : 0xffffffffu;
+            // (measured: a thread per read folding up to four partitions at once - the cells loaded once for all of them - is slower, 274 against 250 ms per call: half as many
+            // threads have work)
+            for (uint32_t pair = t0; pair < n * p; pair += nt) {
+                const uint32_t i = pair / p, k = pair - i * p;
+                uint32_t cb = 0, len = 0, kk = 0;
+                read_meta(i, cb, len, kk);
+                if (inc) { const uint32_t fl = m_fl[i]; if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) continue; }      // no code changed at any position of this read: its distances stand
+                double df = 0.0;
+                constexpr int DU = HL ? 8 : 4;                           // cells per batch: order entries, cells and histogram rows / code bytes requested together
+                for (uint32_t c0 = 0; c0 < len; c0 += DU) {
+                    uint32_t aqs[DU], sn[DU]; uint64_t row[DU][A];
+#pragma unroll
+                    for (int u = 0; u < DU; ++u) { const uint2 ca = ord[cb + (c0 + u < len ? c0 + u : len - 1)]; sn[u] = ca.x; aqs[u] = ca.y; }
+                    if constexpr (HL) {                                  // the code byte says it all: 0 = nothing observed, bit a = allele a attains the maximal sum
+                        uint32_t cds[DU];
+#pragma unroll
+                        for (int u = 0; u < DU; ++u) cds[u] = codes[(sn[u] - pos0) * p + k];
+#pragma unroll
+                        for (int u = 0; u < DU; ++u) {
+                            if (c0 + u >= len) break;
+                            if (cds[u] == 0u) df += g.eps;                                                      // :45-48
+                            else if (!((cds[u] >> (aqs[u] >> 28)) & 1u)) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;      // :70
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int u = 0; u < DU; ++u) {
+                        const uint64_t* rp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
+#pragma unroll
+                        for (int x = 0; x < A; ++x) row[u][x] = rp[x];
+                    }
+#pragma unroll
+                    for (int u = 0; u < DU; ++u) {
+                        if (c0 + u >= len) break;
+                        const uint32_t al = aqs[u] >> 28;
+                        uint64_t mx = 0, va = 0;
+#pragma unroll
+                        for (int x = 0; x < A; ++x) { const uint64_t q = row[u][x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
+                        if (mx == 0) df += g.eps;
+                        else if (va != mx) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;
+                    }
+                }
+                dist[pair] = df;
+            }
+        };
         // ARITH: the same statistics with `errors` as the reference's running sum.  The position map of partition k is filled by its reads in ascending
         // order, every read's cells in set order, through `hap_map.entry(*pos).or_insert(..)` (utils_frags.rs:165): std looks the key up first and reserves
         // room only for a key that is not there, so only the FIRST insertion of a position moves anything.  (1) first-insertion key of every (partition,
@@ -314,7 +365,7 @@ void optimize_kernel(OptArgs g) {
         // in that order (`olist`, two parities): the statistics of the same partition in the other weighting (the final unit-count pass, :187-215) or
         // after a rejected round walk the list again instead of replaying the map.
         // par = which list is written (reuse = false) or walked again (reuse = true).
-        auto mec_stats_arith = [&](bool phred, uint32_t par, bool reuse) {
+        auto mec_stats_arith = [&](bool phred, uint32_t par, bool reuse, bool with_dist, bool dist_inc) {
             uint32_t* const olist = g.ol_pool + ((uint64_t)blockIdx.x * 2 + par) * g.span_max * p;          // [partition][span_max]
             const uint64_t one = phred ? ONE_Q24 : 1ull;
             const double scale = phred ? 0x1p-24 : 1.0;
@@ -444,10 +495,14 @@ void optimize_kernel(OptArgs g) {
 #pragma unroll
                     for (int j0 = 0; j0 < 16; j0 += 4) {
                         if (64u * j0 < span)
-                            for (uint32_t x = 0; x < span; ++x) {
-                                const uint32_t o = row[x];
+                            for (uint32_t x = 0; x < span; x += 4) {          // four keys per round trip (the sweep waits for LDS, not for the compares)
+                                uint32_t o[4];
 #pragma unroll
-                                for (int j = j0; j < j0 + 4; ++j) rk[j] += o < mykey[j] ? 1u : 0u;
+                                for (int u = 0; u < 4; ++u) o[u] = x + u < span ? row[x + u] : ~0u;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                    for (int j = j0; j < j0 + 4; ++j) rk[j] += o[u] < mykey[j] ? 1u : 0u;
                             }
                     }
 #pragma unroll
@@ -494,7 +549,10 @@ void optimize_kernel(OptArgs g) {
                 good = wave_sum_u64(good);
                 if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = D; }
             }
+            // the next round's distances on the wavefronts without a map to replay (dist_arith); with as many partitions as wavefronts, by everybody afterwards
+            if (with_dist && (uint32_t)(OPT_THREADS / 64) > p && wid >= p) dist_arith(tid - 64u * p, OPT_THREADS - 64u * p, dist_inc);
             __syncthreads();
+            if (with_dist && (uint32_t)(OPT_THREADS / 64) <= p) { dist_arith(tid, OPT_THREADS, dist_inc); __syncthreads(); }
             OPT_TICK(12);    // (ARITH) replay + walk, slowest partition
             if (tid == 0 && phred) {
                 double sc = 0.0;
@@ -504,14 +562,14 @@ void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
         uint32_t best_par = 0;                                 // ARITH: the list of the accepted partition
-        auto stats = [&](bool phred, uint32_t par, bool reuse) { if constexpr (ARITH) mec_stats_arith(phred, par, reuse); else mec_stats(phred); };
+        auto stats = [&](bool phred, uint32_t par, bool reuse, bool with_dist = false, bool dist_inc = false) { if constexpr (ARITH) mec_stats_arith(phred, par, reuse, with_dist, dist_inc); else mec_stats(phred); };
 
         refresh_codes(false);
         OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
         if (not_empty) {
-            stats(true, 0, false);
+            stats(true, 0, false, p > 1, false);
             OPT_TICK(1);     // first stats
             double prev_score = s_score;
             for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
@@ -526,50 +584,7 @@ void optimize_kernel(OptArgs g) {
                 const bool incremental = HL && meta && it > 0 && span <= 65535u;
 #endif
                 const uint32_t chg_lo = incremental ? s_chg_lo : 0u, chg_hi = incremental ? s_chg_hi : 0xffffffffu;
-                if constexpr (ARITH) {              // one thread per (read, partition): the running sum cannot be split over lanes
-                    for (uint32_t pair = tid; pair < n * p; pair += OPT_THREADS) {
-                        const uint32_t i = pair / p, k = pair - i * p;
-                        uint32_t cb = 0, len = 0, kk = 0;
-                        read_meta(i, cb, len, kk);
-                        if (incremental) { const uint32_t fl = m_fl[i]; if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) continue; }      // no code changed at any position of this read: its distances stand
-                        double df = 0.0;
-                        constexpr int DU = HL ? 8 : 4;                           // cells per batch: order entries, cells and histogram rows / code bytes requested together
-                        for (uint32_t c0 = 0; c0 < len; c0 += DU) {
-                            uint32_t aqs[DU], sn[DU]; uint64_t row[DU][A];
-#pragma unroll
-                            for (int u = 0; u < DU; ++u) { const uint2 ca = ord[cb + (c0 + u < len ? c0 + u : len - 1)]; sn[u] = ca.x; aqs[u] = ca.y; }
-                            if constexpr (HL) {                                  // the code byte says it all: 0 = nothing observed, bit a = allele a attains the maximal sum
-                                uint32_t cds[DU];
-#pragma unroll
-                                for (int u = 0; u < DU; ++u) cds[u] = codes[(sn[u] - pos0) * p + k];
-#pragma unroll
-                                for (int u = 0; u < DU; ++u) {
-                                    if (c0 + u >= len) break;
-                                    if (cds[u] == 0u) df += g.eps;
-                                    else if (!((cds[u] >> (aqs[u] >> 28)) & 1u)) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;
-                                }
-                                continue;
-                            }
-#pragma unroll
-                            for (int u = 0; u < DU; ++u) {
-                                const uint64_t* rp = hist + (uint64_t)(sn[u] - pos0) * PA + k * A;
-#pragma unroll
-                                for (int x = 0; x < A; ++x) row[u][x] = rp[x];
-                            }
-#pragma unroll
-                            for (int u = 0; u < DU; ++u) {
-                                if (c0 + u >= len) break;
-                                const uint32_t al = aqs[u] >> 28;
-                                uint64_t mx = 0, va = 0;
-#pragma unroll
-                                for (int x = 0; x < A; ++x) { const uint64_t q = row[u][x] & QMASK44; mx = q > mx ? q : mx; va = (x == (int)al) ? q : va; }
-                                if (mx == 0) df += g.eps;
-                                else if (va != mx) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;
-                            }
-                        }
-                        dist[pair] = df;
-                    }
-                } else
+                if constexpr (ARITH) { /* the distances of this round were computed beside the last statistics call (dist_arith) */                } else
                 for (uint32_t iv = grp; iv < n16; iv += OPT_THREADS / 16) {
                     const uint32_t i = (m_pm && iv < n) ? (uint32_t)m_pm[iv] : iv;
                     uint32_t cb = 0, len = 0, kk = 0;
@@ -697,7 +712,7 @@ void optimize_kernel(OptArgs g) {
                 };
                 apply_moves(false);
                 OPT_TICK(6);     // moves
-                stats(true, best_par ^ 1u, false);
+                stats(true, best_par ^ 1u, false, true, HL && meta && span <= 65535u);
                 OPT_TICK(7);     // round stats
                 const double new_score = s_score;
                 if (new_score > prev_score) { prev_score = new_score; best_par ^= 1u; }
