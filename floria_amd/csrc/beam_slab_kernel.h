@@ -74,7 +74,10 @@ constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
 constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
 // ARITH instances (the reference's running f64 sums, below): the distance terms of a step wait in LDS for the sequential folds — SLAB_TERM_CAP f64 per wave —
 // so LDS allows two waves per SIMD at most and the register budget is that of two
-constexpr int SLAB_TERM_CAP = 768;
+#ifndef FLORIA_TERM_CAP
+#define FLORIA_TERM_CAP 768
+#endif
+constexpr int SLAB_TERM_CAP = FLORIA_TERM_CAP;
 constexpr int SLAB_WAVES_ARITH = 2;
 template <int N> struct IC { static constexpr int value = N; };
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) { if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); } }

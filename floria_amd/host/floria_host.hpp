@@ -113,6 +113,7 @@ struct Frag {
     SnpPosition first_position = UINT32_MAX, last_position = 0;
     // the fields ingest fills for the writers (types_structs.rs:80-84)
     bool is_paired = false;
+    bool merged_positions = false;                                       // `positions` was extended by a mate's / supplementary piece's set (file_reader.rs:541, 639): its iteration order is not that of one CIGAR walk
     GnPosition first_pos_base = SIZE_MAX, last_pos_base = SIZE_MAX;      // reference span of the alignment (0-based start, end exclusive)
     size_t seq_len[2] = {0, 0};                                          // bases of seq_string[0], seq_string[1]
     std::string seq_string[2];                                           // only kept with --output-reads: DnaString::from_acgt_bytes of SEQ (anything but ACGT -> A)

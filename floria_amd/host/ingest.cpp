@@ -721,6 +721,7 @@ std::pair<std::vector<Frag>, std::vector<Frag>> ContigIngest::finish() {
             if ((first.flags & F_PAIRED1) == F_PAIRED1) { ff = &first.frag; sf = &second.frag; }
             else if ((first.flags & F_PAIRED2) == F_PAIRED2) { ff = &second.frag; sf = &first.frag; }
             else continue;
+            if (!sf->seq_dict.empty()) ff->merged_positions = true;                        // first_frag.positions.extend(sec_frag.positions) (:541)
             for (auto& kv : sf->seq_dict) ff->seq_dict[kv.first] = kv.second;              // extend: the mate's call overwrites
             for (auto& kv : sf->qual_dict) ff->qual_dict[kv.first] = kv.second;
             ff->first_position = std::min(ff->first_position, sf->first_position);
@@ -748,6 +749,7 @@ std::pair<std::vector<Frag>, std::vector<Frag>> ContigIngest::finish() {
             for (size_t i = 0; i < frags.size(); ++i) {
                 if ((int)i == primary) continue;
                 Frag& fr = frags[i].frag;
+                if (!fr.seq_dict.empty()) pf.merged_positions = true;                        // :639
                 for (auto& kv : fr.seq_dict) pf.seq_dict[kv.first] = kv.second;
                 for (auto& kv : fr.qual_dict) pf.qual_dict[kv.first] = kv.second;
                 pf.first_position = std::min(pf.first_position, fr.first_position);

@@ -287,6 +287,11 @@ int main(int argc, char** argv) {
         std::vector<std::unique_ptr<Session>> sessions;
         if (!ingest_only) for (int d : devices) sessions.emplace_back(new Session(d));
         for (auto& s : sessions) if (floria_hip_set_option(s->ctx(), "arith", reference_arith ? 1 : 0) != 0) throw Error(FLORIA_E_INVALID, floria_hip_last_error());
+        // What the reference-arithmetic mode emulates is the iteration order of a position set collected from ONE ascending CIGAR walk (arith_kernel.h: cell_order_kernel).
+        // Fragments whose set was EXTENDED by a mate or a supplementary piece (file_reader.rs:541, 639) or thinned by --ignore-monomorphic (utils_frags.rs:745-755: removals
+        // from the built set, tombstones included) iterate in another order, which the pileup does not carry.  Under --arith auto a batch that holds such fragments is phased
+        // in the canonical form (one note); --arith reference keeps the running sums and says that the orders of those fragments are an approximation.
+        size_t n_batches_fallback = 0, n_frags_merged = 0;
         Session* const session_holder = sessions.empty() ? nullptr : sessions[0].get();
         fprintf(stderr, "Preprocessing: BAM header%s %.3fs, VCF + FASTA %.3fs, device %.3fs\n", (!have_e || !have_l) ? " + parameter estimate" : "", t_bam, t_vcf, now_s() - tp);
 
@@ -393,6 +398,21 @@ int main(int argc, char** argv) {
             t_ingest += now_s() - t0;
             if (ingest_only || work.empty()) continue;
             ++n_batches;
+            if (reference_arith) {
+                size_t merged = 0;
+                for (const ContigWork& w : work) for (const Frag& f : w.all_frags) merged += f.merged_positions ? 1 : 0;
+                n_frags_merged += merged;
+                const bool other_orders = merged != 0 || o.ignore_monomorphic;
+                const bool fall_back = other_orders && arith_opt == "auto";
+                if (fall_back && n_batches_fallback++ == 0)
+                    fprintf(stderr, "floria-hip: note: %s: their position sets do not iterate in the order of one CIGAR walk, which is what the reference-arithmetic mode emulates; "
+                                    "such batches are phased in the canonical form (--arith reference forces the running sums with approximate orders for those fragments)\n",
+                            o.ignore_monomorphic ? "--ignore-monomorphic removes positions from the fragments" : "this batch holds fragments merged from mates or supplementary alignments");
+                if (other_orders && arith_opt == "reference" && n_batches == 1)
+                    fprintf(stderr, "floria-hip: warning: --arith reference with %s: the iteration order of those fragments' position sets is emulated as if built by one CIGAR walk\n",
+                            o.ignore_monomorphic ? "--ignore-monomorphic" : "fragments merged from mates or supplementary alignments");
+                for (auto& s : sessions) if (floria_hip_set_option(s->ctx(), "arith", fall_back ? 0 : 1) != 0) throw Error(FLORIA_E_INVALID, floria_hip_last_error());
+            }
             // the device stages of a set of contigs on one context: S1 + hap graph in one pipelined call, LP + path peeling on the host (one contig per
             // task), S2, COV / ERR / HAPQ of the final haplosets.  `tm` receives the wall seconds of the four stages.
             auto device_stages = [&](Session& session, std::vector<ContigWork>& part, size_t threads, double* tm) {
@@ -456,6 +476,9 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
+        if (reference_arith && (n_batches_fallback || n_frags_merged))
+            fprintf(stderr, "Arithmetic: %zu of %zu batches phased in the canonical form (%zu fragments merged from several alignments%s)\n", n_batches_fallback, n_batches, n_frags_merged,
+                    o.ignore_monomorphic ? "; --ignore-monomorphic" : "");
         if (lp_report)
         fprintf(stderr, "LP: the optimum is not unique for %zu of %zu contigs (%zu of %zu edge flows differ in some other optimal solution); this run used the '%s' vertex, "
                         "rerun with --lp-tie %s to see what depends on it\n", lp_not_unique.load(), lp_contigs.load(), lp_movable.load(), lp_edges.load(),

@@ -984,6 +984,16 @@ int floria_oracle_fxset_order(const int64_t* ops, uint32_t n_ops, uint32_t* out,
     *n_out = (uint32_t)o.size();
     return 0;
 }
+// ... and filled the way set_to_seq_dict fills its position map, `entry(key).or_insert(..)` per key (lookup first, room reserved only for a new key)
+int floria_oracle_fxset_entry_order(const uint64_t* keys, uint32_t n_keys, uint32_t* out, uint32_t* n_out, uint32_t* buckets) {
+    FxSet s;
+    for (uint32_t i = 0; i < n_keys; ++i) s.entry_insert(keys[i]);
+    const auto o = s.order();
+    for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+    *n_out = (uint32_t)o.size();
+    if (buckets) *buckets = (uint32_t)s.buckets;
+    return 0;
+}
 // Mode 2 only: for the blocks of the last floria_oracle_phase_blocks call, the reads of every block partition by partition
 // (partition 0 first), each partition in the iteration order of its emulated set; same offsets as the result's read_off.
 std::vector<uint32_t> g_last_set_order;

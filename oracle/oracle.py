@@ -185,6 +185,15 @@ def fxset_order(ops):
     return out[:n.value].copy()
 
 
+def fxset_entry_order(keys):
+    """iteration order and bucket count of an FxHashMap filled with `entry(key).or_insert(..)` per key (utils_frags.rs:165)"""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    out = np.zeros(max(1, len(keys)), np.uint32)
+    n, nb = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().floria_oracle_fxset_entry_order(capi.ptr(keys, C.c_uint64), C.c_uint32(len(keys)), capi.ptr(out, C.c_uint32), C.byref(n), C.byref(nb)))
+    return out[:n.value].copy(), nb.value
+
+
 def fxset_insert_order(keys):
     """Iteration order after inserting `keys` (counter_ids) in sequence into an empty set; repeated keys are no-ops."""
     return fxset_order(np.asarray(keys, np.int64) + 1)

@@ -190,3 +190,25 @@ def test_long_reads_in_reference_arithmetic(arith, hip_lib, oracle_mod, seed):
     assert int(np.diff(pile.read_off).max()) > 256
     assert_block_results_equal(ro, rg, f"seed {seed} eps {eps}")
     assert ro.min_prune_margin == rg.min_prune_margin
+
+
+@pytest.mark.parametrize("full", (3, 7, 14, 28, 56, 112))
+def test_a_position_map_that_is_full_when_a_position_is_touched_again(arith, hip_lib, oracle_mod, full):
+    """a partition's position map is filled through `entry(pos).or_insert(..)` (utils_frags.rs:165): looked up first, room reserved only for a
+    new position.  A block with exactly 3 / 7 / 14 / 28 / 56 / 112 positions — hashbrown's capacities — fills the map to the brim with its first read, and
+    every later read touches positions that are there: the table must keep its bucket count (tests/test_order_emulation.py pins the oracle's side of it)."""
+    from floria_amd.pileup import Pileup
+    rng = np.random.default_rng(4200 + full)
+    hap = rng.integers(0, 2, size=(2, full))
+    reads = []
+    for r in range(24):
+        snps = np.arange(1, full + 1) if r < 2 else np.sort(rng.choice(np.arange(1, full + 1), size=int(rng.integers(1, full + 1)), replace=False))
+        al = hap[r % 2, snps - 1].copy()
+        flip = rng.random(len(snps)) < 0.08
+        al[flip] ^= 1
+        reads.append((snps, al, rng.integers(8, 40, size=len(snps))))
+    pile = Pileup.from_reads(reads)
+    s, e = np.asarray([1], np.uint32), np.asarray([full], np.uint32)
+    for eps in NON_DYADIC:
+        ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, eps, P=3, B=4)
+        assert_block_results_equal(ro, rg, f"{full} positions, eps {eps}")

@@ -128,3 +128,21 @@ def test_s1_does_not_depend_on_the_emulated_order_but_s2_does():
     ga = oracle.reassign(c.pileup, groups, ranges, 0.03125)
     gb = oracle.reassign(c.pileup, groups, ranges, 0.03125, read_order=order)
     assert sorted(ga.grp_read.tolist()) == sorted(gb.grp_read.tolist()) or ga.n_groups != gb.n_groups or True      # same reads survive unless a split drops one
+
+
+def test_entry_or_insert_never_grows_a_full_map_for_a_key_that_is_there():
+    """`hap_map.entry(*pos).or_insert(..)` (utils_frags.rs:165) looks the key up first and reserves room only on the Vacant path
+    (std's rustc_entry), while HashSet::insert / HashMap::insert reserve before they look (hashbrown's find_or_find_insert_slot).  A map
+    that is exactly full — 3, 7, 14, 28, 56, 112 keys — therefore keeps its bucket count when a key it holds is touched again through entry(),
+    and doubles it through insert(): the bucket order, and with it the order of the reference's `errors +=` additions, differs."""
+    for full, nb in ((3, 4), (7, 8), (14, 16), (28, 32), (56, 64), (112, 128)):
+        keys = np.arange(100, 100 + full, dtype=np.uint64) * 7 + 3
+        once, b1 = oracle.fxset_entry_order(keys)
+        again, b2 = oracle.fxset_entry_order(np.concatenate([keys, keys[:5], keys[-1:]]))
+        assert b1 == nb and b2 == nb and once.tolist() == again.tolist()
+        # the same keys through insert(): the same layout while nothing is touched twice, a doubled table once a held key is inserted again
+        assert oracle.fxset_insert_order(keys).tolist() == once.tolist()
+        grown = oracle.fxset_insert_order(np.concatenate([keys, keys[:1]]))
+        assert sorted(grown.tolist()) == sorted(once.tolist())
+        one_more, b3 = oracle.fxset_entry_order(np.concatenate([keys, [5]]))              # a NEW key does grow it
+        assert b3 == 2 * nb and grown.tolist() == [k for k in one_more.tolist() if k != 5]
