@@ -832,11 +832,28 @@ void remove_read_from_block(const Pile& P, Hap& h, uint32_t r) {                
     }
 }
 
-void separate_broken_haplogroups(const Pile& P, std::vector<std::vector<uint32_t>>& parts,
-                                 std::vector<std::pair<uint32_t, uint32_t>>& ranges) {     // part_block_manip.rs:27-98
+// Which read a split DROPS (:69-84: the first read behind a coverage gap trips the split and is inserted nowhere) depends on the order of the reads that share
+// its first_position: the reference iterates an FxHashSet and stable-sorts by first_position only (:34-35, :62-63).  Test-only modes to measure how much that
+// matters: 0 = ascending counter_id (the canonical order, what the product does), 1 = descending counter_id among equal first positions,
+// 2 = the iteration order of an FxHashSet filled in the order process_reads_for_final_parts re-inserted the reads (:219 — an approximation: the reference's set
+// still has the buckets and tombstones of the haplogroup it was before its reads were removed, :195-200, which the seam does not carry).
+std::atomic<int> g_a14_tie_mode{0};
+uint64_t g_a14_dropped = 0;        // reads dropped by splits since the last reset (diagnostic)
+void separate_broken_haplogroups(const Pile& P, std::vector<std::vector<uint32_t>>& parts_in,
+                                 std::vector<std::pair<uint32_t, uint32_t>>& ranges, uint64_t* n_dropped = nullptr) {     // part_block_manip.rs:27-98
+    // parts_in[i]: the reads of haplogroup i in the order they were inserted; `parts` = the order the reference's loops see: set order, stable-sorted by first_position
+    const int tie_mode = g_a14_tie_mode.load();
+    std::vector<std::vector<uint32_t>> parts(parts_in.size());
+    for (size_t i = 0; i < parts_in.size(); ++i) {
+        std::vector<uint32_t> v = parts_in[i];
+        if (tie_mode == 2) { FxSet fs; for (uint32_t r : v) fs.insert(r); v = fs.order(); }
+        else { std::sort(v.begin(), v.end()); if (tie_mode == 1) std::reverse(v.begin(), v.end()); }
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return P.p->first[a] < P.p->first[b]; });
+        parts[i] = std::move(v);
+        std::sort(parts_in[i].begin(), parts_in[i].end());
+    }
     std::vector<std::pair<size_t, std::vector<uint32_t>>> all_breaks;
     for (size_t i = 0; i < ranges.size(); ++i) {
-        // ascending id is already sorted by first_position (Frag::cmp); stable sort keeps it (canonical (2))
         uint32_t current_lastest_pos = 0;
         std::vector<uint32_t> breaks;
         for (uint32_t r : parts[i]) {
@@ -857,6 +874,7 @@ void separate_broken_haplogroups(const Pile& P, std::vector<std::vector<uint32_t
         for (uint32_t r : parts[bi.first]) {
             if (P.p->last[r] <= end_spot) new_part.push_back(r);
             else {                                                   // :69-84 — the read that trips the split is dropped
+                if (n_dropped) ++*n_dropped;
                 new_parts.push_back(new_part);
                 new_ranges.push_back({break_start, end_spot});
                 break_start = end_spot + 1;
@@ -869,8 +887,8 @@ void separate_broken_haplogroups(const Pile& P, std::vector<std::vector<uint32_t
         new_parts.push_back(new_part);
         new_ranges.push_back({break_start, ranges[bi.first].second});
     }
-    for (auto& bi : all_breaks) parts[bi.first].clear();
-    for (size_t i = 0; i < new_parts.size(); ++i) { parts.push_back(new_parts[i]); ranges.push_back(new_ranges[i]); }
+    for (auto& bi : all_breaks) parts_in[bi.first].clear();
+    for (size_t i = 0; i < new_parts.size(); ++i) { std::sort(new_parts[i].begin(), new_parts[i].end()); parts_in.push_back(new_parts[i]); ranges.push_back(new_ranges[i]); }
 }
 
 void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32_t>>& parts,
@@ -901,8 +919,7 @@ void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32
         parts[bid].push_back(r);
         add_read_to_block(P, block.blocks[bid], r);
     }
-    for (auto& pp : parts) std::sort(pp.begin(), pp.end());                                   // (no-op in canonical mode)
-    separate_broken_haplogroups(P, parts, ranges);                                            // :231-233
+    separate_broken_haplogroups(P, parts, ranges, &g_a14_dropped);                            // :231-233 (sorts every haplogroup by read id on its way out)
     // sort_parts :276-288 — stable sort by range
     std::vector<size_t> idx(parts.size());
     for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
@@ -971,6 +988,8 @@ extern "C" {
 
 const char* floria_oracle_last_error(void) { return g_err.c_str(); }
 void floria_oracle_set_order_mode(int m) { g_order_mode.store(m); }
+void floria_oracle_set_a14_tie_mode(int m) { g_a14_tie_mode.store(m); }
+uint64_t floria_oracle_a14_dropped(int reset) { const uint64_t v = g_a14_dropped; if (reset) g_a14_dropped = 0; return v; }
 void floria_oracle_set_arith_mode(int m) { g_arith_mode.store(m); }
 int floria_oracle_get_arith_mode(void) { return g_arith_mode.load(); }
 

@@ -149,6 +149,14 @@ def _run_and_check(floria_hip, oracle_mod, tmp_path, contigs, block_length, extr
             assert 1 <= lo <= hi <= ex["contig_len"] and 0 <= int(hapq_p.search(ln).group(1)) <= 60
         vt = open(os.path.join(cdir, f"{c.name}.vartigs")).read().splitlines()
         assert len(vt) == 2 * len(heads) and all(set(x) <= set("0123?") for x in vt[1::2])
+        # ... and so can the loader that would compare a capture of the real binary with these files (tests/capture_loader.py, docs/golden.md)
+        from tests import capture_loader as cl
+        hs, vs = cl.parse_haplosets(os.path.join(cdir, f"{c.name}.haplosets")), cl.parse_vartigs(os.path.join(cdir, f"{c.name}.vartigs"))
+        live = [g for g in range(go.n_groups) if len(parts[g])]
+        assert [h["index"] for h in hs] == live == [v["index"] for v in vs]
+        for h, g in zip(hs, live):
+            assert h["snp_range"] == ranges[g] and sorted(n for n, _, _ in h["reads"]) == sorted(ex["names"][int(r)] for r in parts[g])
+        assert cl.parse_ploidy_info(os.path.join(out, "contig_ploidy_info.tsv"))[1][c.name] == want["ploidy_row"].rstrip("\n").split("\t")[1:]
     return expect
 
 
