@@ -169,6 +169,7 @@ struct Knobs {
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
     uint32_t arith_hbm = 0;       // (tests) reference arithmetic: position-map tables and first-insertion keys in HBM scratch even where they fit into LDS
     uint32_t opt_block_order = 0; // (A/B, tests) optimise: the build / distance passes visit the reads in block order instead of longest first
+    uint32_t s2_assign_only = 0;  // S2 returns the haplogroups as re-inserted (input order): separate_broken_haplogroups and sort_parts are left to a host that iterates its own sets
     uint32_t arith = 0;           // 1 = the reference's own running f64 sums in its own orders (arith_kernel.h; slower kernels), 0 = the canonical (Q24, #eps) form
     int32_t  tail_overlap = 0;    // one ploidy per stage: the LAST ploidy's beam launch runs beside the optimise launch of the ploidy below, every job waiting for its block's
                                   // stop rule (run_phase): 0 off (default: measured level) | 1 on
@@ -922,6 +923,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "tail_overlap") { if (value < -1 || value > 1) return fail(FLORIA_E_INVALID, "tail_overlap: 0 | 1"); K.tail_overlap = (int32_t)value; }
     else if (k == "tail_waves") K.tail_waves = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "arith_hbm") K.arith_hbm = value != 0;
+    else if (k == "s2_assign_only") K.s2_assign_only = value != 0;
     else if (k == "arith") { if (value < 0 || value > 1) return fail(FLORIA_E_INVALID, "arith: 0 canonical | 1 the reference's running sums"); K.arith = (uint32_t)value; }
     else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)
     else if (k == "upload_chunks") K.upload_chunks = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, floria_hip_ctx::MAX_GROUPS));
@@ -2497,7 +2499,10 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         for (uint32_t lg = 0; lg < ng; ++lg) ranges[lg] = {grp_range[2 * cg[ci][lg]], grp_range[2 * cg[ci][lg] + 1]};
         const int32_t* as = assign.data() + assign_base[ci];
         for (uint32_t r = 0; r < N; ++r) if (as[r] >= 0) parts[as[r]].push_back(r);       // ascending id
-        {
+        // Which read a split drops depends on the iteration order of the reference's FxHashSet among reads that share a first_position (:34-35, :62-63; measured:
+        // every short-read contig of scripts/a14_sensitivity.py changes with it, no long-read one).  Here: ascending counter_id.  A host that wants its own sets'
+        // order sets "s2_assign_only": it gets the haplogroups as re-inserted and runs these two cheap integer steps on its own sets.
+        if (!ctx->knobs.s2_assign_only) {
             const auto& F = c->h_first; const auto& L = c->h_last;
             std::vector<std::pair<size_t, std::vector<uint32_t>>> all_breaks;
             const size_t n0 = ranges.size();
@@ -2534,7 +2539,7 @@ int floria_hip_reassign_batch(floria_hip_ctx* ctx, const floria_hip_contig* cons
         }
         std::vector<size_t> idx(parts.size());
         std::iota(idx.begin(), idx.end(), 0);
-        std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return ranges[x] < ranges[y]; });
+        if (!ctx->knobs.s2_assign_only) std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return ranges[x] < ranges[y]; });
         floria_groups* G = (floria_groups*)calloc(1, sizeof(floria_groups));
         if (!G) { floria_hip_groups_array_free(arr, n_contigs); return fail(FLORIA_E_NOMEM, "calloc"); }
         arr[ci] = G;

@@ -328,11 +328,20 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
  *   1            the reference's own arithmetic: running f64 sums, `diff += epsilon` between `diff += w` over a read's cells in the iteration order of its
  *                FxHashSet of positions (utils_frags.rs:33-72), one running sum per partition in a search node (global_clustering.rs:196-202), `errors +=`
  *                over a haplotype's positions in the bucket order of its FxHashMap (local_clustering.rs:226-256), those orders emulated on the device
- *                (csrc/arith_kernel.h).  Applies to floria_hip_phase_* (S1) and floria_hip_reassign* (S2); slower kernels (one generic beam kernel, sequential
- *                table replays in the optimise kernel: about 15 x the time of mode 0 on BASELINE config 4), and the host-pileup entry points do not pipeline.
+ *                (csrc/arith_kernel.h).  Applies to floria_hip_phase_* (S1) and floria_hip_reassign* (S2).  Biallelic-or-not pileups without q = 0 cells run the
+ *                shared-slab beam kernel with the running sums folded per live slab (beam_slab_kernel<.., ARITH>); the optimise kernel replays the
+ *                partitions' position maps per statistics call: about 4 x the time of mode 0 on BASELINE config 4 (250 against 64 ms at -e 0.04); the
+ *                host-pileup entry points do not pipeline in this mode.
  * For an epsilon that is a multiple of 2^-10 both modes return the same bits (every sum is exact in f64 in any order); for any other epsilon they are
  * different functions (about 60 % of the blocks of the BASELINE configs come out differently at 0.04) and mode 1 is the one a Rust host's CPU path computes,
  * as far as the emulated std hash-table orders are right.  Checked bit for bit against the oracle's arithmetic mode 1 (tests/test_gpu_arith.py).
+ *
+ * "s2_assign_only" = 1: floria_hip_reassign* stop behind the greedy re-insertion (part_block_manip.rs:203-222) and return the haplogroups as re-inserted —
+ * input group order, input ranges, reads ascending — WITHOUT separate_broken_haplogroups (:27-98) and sort_parts (:276-288).  The read a split drops is the
+ * first one behind a coverage gap in the iteration order of the reference's FxHashSet among reads that share a first_position; with the default (0) that
+ * order is ascending counter_id, and which read goes changes the output of every short-read contig measured (scripts/a14_sensitivity.py; no long-read
+ * one).  A Rust host that wants its own sets' order inserts the returned reads into its sets and keeps calling its own two functions: they are integer
+ * bookkeeping, a few microseconds per contig.
  *
  * Tuning / test knobs; none changes results.  Keys: "groups" (job groups on separate streams, 0 = auto), "speculate" (ploidy stages: -1 auto,
  * 0 one ploidy at a time, 1 all ploidies of a block at once, 2 {1,2,3} then {4..P}), "spec_gate_div" (grid divisor of the gated ploidies of a

@@ -919,6 +919,7 @@ void process_reads_for_final_parts(const Pile& P, std::vector<std::vector<uint32
         parts[bid].push_back(r);
         add_read_to_block(P, block.blocks[bid], r);
     }
+    if (g_a14_tie_mode.load() < 0) { for (auto& pp : parts) std::sort(pp.begin(), pp.end()); return; }      // (tests: the haplogroups as re-inserted, before :231-233 and sort_parts)
     separate_broken_haplogroups(P, parts, ranges, &g_a14_dropped);                            // :231-233 (sorts every haplogroup by read id on its way out)
     // sort_parts :276-288 — stable sort by range
     std::vector<size_t> idx(parts.size());

@@ -167,6 +167,20 @@ def set_order_mode(mode):
     lib().floria_oracle_set_order_mode(C.c_int(mode))
 
 
+def set_a14_tie_mode(mode):
+    """separate_broken_haplogroups (part_block_manip.rs:27-98): the order of the reads that share a first_position, which decides the read a split drops.
+    0 = ascending counter_id (canonical), 1 = descending, 2 = an FxHashSet filled in the re-insertion order of S2 (an approximation, see the C++ comment);
+    -1 = stop before the splits: the haplogroups as re-inserted, in input order (what floria_hip_set_option("s2_assign_only", 1) returns)."""
+    lib().floria_oracle_set_a14_tie_mode(C.c_int(mode))
+
+
+def a14_dropped(reset=True):
+    """reads dropped by haplogroup splits since the last reset"""
+    f = lib().floria_oracle_a14_dropped
+    f.restype = C.c_uint64
+    return int(f(C.c_int(1 if reset else 0)))
+
+
 def set_arith_mode(mode):
     """0 = canonical arithmetic (every weighted sum an exact (Q24, #epsilon) pair turned into f64 once: what the HIP path computes),
     1 = the reference's running f64 sums, terms added in the iteration order of its (emulated) hash containers.  Identical for

@@ -710,3 +710,59 @@ def test_binomial_screen_error_bound_on_this_device(gpu_ctx):
     for eps in (0.03125, 0.04, 0.05, 0.0437, 0.01, 0.2):
         err = gpu_ctx.selftest(eps, 1024)
         assert 0.0 < err <= 1.0e-5, (eps, err)
+
+
+def test_s2_assign_only_leaves_the_splits_to_the_host(gpu_ctx, hip_lib, oracle_mod):
+    """which read separate_broken_haplogroups drops depends on the reference's FxHashSet iteration order among reads that share a
+    first_position (measured: every short-read contig changes with it, scripts/a14_sensitivity.py).  With "s2_assign_only" the library stops behind the greedy
+    re-insertion; a host runs the two integer steps on its own sets.  Checked: the re-inserted haplogroups equal the oracle's, and the restated split + sort
+    with ascending ties on them gives exactly what the default call returns."""
+    def split_and_sort(pile, parts, ranges):                      # part_block_manip.rs:27-98 + :276-288, ties in ascending counter_id
+        parts, ranges = [list(p) for p in parts], list(ranges)
+        new_parts, new_ranges, broken = [], [], []
+        for i in range(len(ranges)):
+            latest, breaks = 0, []
+            for r in parts[i]:
+                if latest != 0 and pile.first[r] > latest and ranges[i][0] <= latest < ranges[i][1]:
+                    breaks.append(latest)
+                latest = max(latest, int(pile.last[r]))
+            if not breaks:
+                continue
+            broken.append(i)
+            spot, start, end, cur = 0, ranges[i][0], breaks[0], []
+            for r in parts[i]:
+                if pile.last[r] <= end:
+                    cur.append(r)
+                else:
+                    new_parts.append(cur); new_ranges.append((start, end)); cur = []
+                    start = end + 1; spot += 1
+                    end = breaks[spot] if spot != len(breaks) else 2 ** 32 - 1
+            new_parts.append(cur); new_ranges.append((start, ranges[i][1]))
+        for i in broken:
+            parts[i] = []
+        parts += new_parts; ranges += new_ranges
+        order = sorted(range(len(parts)), key=lambda k: ranges[k])
+        return [parts[k] for k in order], [ranges[k] for k in order]
+
+    n_split = 0
+    for cfg, idx, scale, bl in ((3, 0, 0.2, 500), (3, 1, 0.1, 500), (4, 0, 0.5, 10000)):
+        c = synth.make_config_contig(cfg, idx, scale)
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, bl)
+        r = gpu_ctx.phase_blocks(c.pileup, s, e, hip_lib.make_params(EPS))
+        groups, ranges = groups_from_blocks(r, s, e)
+        full = gpu_ctx.reassign(c.pileup, groups, ranges, EPS)
+        gpu_ctx.set_option("s2_assign_only", 1); oracle_mod.set_a14_tie_mode(-1)
+        try:
+            ga = gpu_ctx.reassign(c.pileup, groups, ranges, EPS)
+            go = oracle_mod.reassign(c.pileup, groups, ranges, EPS)
+        finally:
+            gpu_ctx.set_option("s2_assign_only", 0); oracle_mod.set_a14_tie_mode(0)
+        assert ga.n_groups == go.n_groups == len(groups)
+        assert np.array_equal(ga.range, go.range) and np.array_equal(ga.grp_off, go.grp_off) and np.array_equal(ga.grp_read, go.grp_read)
+        assert np.array_equal(np.asarray(ga.range).reshape(-1, 2), np.asarray(ranges, np.uint32).reshape(-1, 2))
+        parts, rngs = split_and_sort(c.pileup, [list(map(int, ga.group(k))) for k in range(ga.n_groups)], [tuple(map(int, ga.range[k])) for k in range(ga.n_groups)])
+        assert full.n_groups == len(parts)
+        for k in range(full.n_groups):
+            assert tuple(map(int, full.range[k])) == rngs[k] and list(map(int, full.group(k))) == parts[k], (cfg, idx, k)
+        n_split += full.n_groups - len(groups)
+    assert n_split > 0
