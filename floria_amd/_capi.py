@@ -61,7 +61,8 @@ class CTiming(C.Structure):
                 ("beam_launch_bytes", C.c_uint64), ("jobs", C.c_uint64),
                 ("streams", C.c_uint32), ("stage_width", C.c_uint32), ("phase_ms", C.c_double),
                 ("upload_pinned_bytes", C.c_uint64), ("upload_staged_bytes", C.c_uint64),
-                ("upload_chunks", C.c_uint32), ("reserved", C.c_uint32)]
+                ("upload_chunks", C.c_uint32), ("reserved", C.c_uint32),
+                ("beam_union_ms", C.c_double), ("optimize_union_ms", C.c_double)]
 
 
 def ptr(a, ctype):

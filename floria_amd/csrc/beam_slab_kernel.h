@@ -300,7 +300,7 @@ void beam_slab_kernel(BeamArgs g) {
     const unsigned long long t_wall0 = wall_clock64(), t_core0 = t_last;
     uint32_t c_pass = 0, c_push = 0, c_pop = 0;
     unsigned long long c_nlive = 0, c_nin = 0, c_nstates = 0, c_L = 0, c_copy_pos = 0, c_ncopy = 0, c_add_items = 0, c_zero_items = 0, c_nlead = 0, c_trunc = 0;
-    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0, c_boring = 0, c_heapkeep = 0;
+    unsigned long long c_nl = 0, c_id8 = 0, c_id16 = 0, c_id32 = 0, c_w128 = 0, c_w256 = 0, c_w512 = 0, c_wsum = 0, c_it64 = 0, c_it128 = 0, c_it256 = 0, c_lvl2 = 0, c_general = 0, c_exact = 0, c_boring = 0, c_heapkeep = 0, c_code = 0;
 #endif
 
     bool gave_up = false;
@@ -474,7 +474,7 @@ void beam_slab_kernel(BeamArgs g) {
 
             // ---- A: read vs every LIVE slab; Gs lanes per slab stride over the cells -------------------------------
 #ifdef FLORIA_PROF
-            c_nlive += nlive; c_nin += nin; c_nstates += nstates; c_L += L;
+            c_nlive += nlive; c_nin += nin; c_nstates += nstates; c_L += L; c_code += (unsigned long long)nlive * (ARITH ? L : nin);
 #endif
             const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
             const bool trunc = tend >= (int32_t)start_rel;            // some written position leaves the hash window this step
@@ -1323,7 +1323,7 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[10], (unsigned long long)c_pass); atomicAdd(&g.prof[11], (unsigned long long)c_push); atomicAdd(&g.prof[12], (unsigned long long)c_pop);
                      atomicAdd(&g.prof[32], c_copy_pos); atomicAdd(&g.prof[33], c_ncopy); atomicAdd(&g.prof[34], c_add_items); atomicAdd(&g.prof[35], c_zero_items); atomicAdd(&g.prof[36], c_nlead); atomicAdd(&g.prof[37], c_trunc);
                      atomicAdd(&g.prof[38], c_nl); atomicAdd(&g.prof[39], c_id8); atomicAdd(&g.prof[40], c_id16); atomicAdd(&g.prof[41], c_id32); atomicAdd(&g.prof[42], c_w128); atomicAdd(&g.prof[43], c_w256);
-                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact); atomicAdd(&g.prof[60], c_boring); atomicAdd(&g.prof[61], c_heapkeep);
+                     atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact); atomicAdd(&g.prof[60], c_boring); atomicAdd(&g.prof[61], c_heapkeep); atomicAdd(&g.prof[54], c_code);      // [54]: code bytes gathered by the distance phase
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
     n_fallback = wave_sum_u32(n_fallback);

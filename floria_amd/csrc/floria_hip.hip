@@ -329,6 +329,20 @@ struct EventTimer {
         for (size_t i = 0; i < ev.size(); ++i) if (kind[i] == k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[i].first, ev[i].second) == hipSuccess) t += ms; }
         return t;
     }
+    // wall time during which at least one launch of kind k was in flight (the launches of the job groups overlap on separate streams: their durations add up to
+    // more than the wall clock, this does not)
+    double union_ms(int k) {
+        std::vector<std::pair<float, float>> iv;
+        for (size_t i = 0; i < ev.size(); ++i) if (kind[i] == k) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, ev.front().first, ev[i].first) == hipSuccess && hipEventElapsedTime(&b, ev.front().first, ev[i].second) == hipSuccess) iv.push_back({a, b});
+        }
+        std::sort(iv.begin(), iv.end());
+        double t = 0; float lo = 0, hi = -1;
+        for (auto& x : iv) { if (hi < lo || x.first > hi) { if (hi >= lo) t += hi - lo; lo = x.first; hi = x.second; } else if (x.second > hi) hi = x.second; }
+        if (hi >= lo) t += hi - lo;
+        return t;
+    }
     double span() {
         if (ev.empty()) return 0;
         float ms = 0;
@@ -1820,6 +1834,7 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     if (p1_shortcut && !jobs.empty()) margin = std::min(margin, std::fabs(0.0 - std::log(PROB_CUTOFF)));   // the ploidy-1 decisions: p_k - lse == 0
     R->min_prune_margin = margin;
     ctx->timing.beam_ms = T.sum(K_BEAM); ctx->timing.optimize_ms = T.sum(K_OPT); ctx->timing.select_ms = T.sum(K_SEL);
+    ctx->timing.beam_union_ms = T.union_ms(K_BEAM); ctx->timing.optimize_union_ms = T.union_ms(K_OPT);
     ctx->timing.h2d_ms = T.sum(K_H2D); ctx->timing.d2h_ms = T.sum(K_D2H); ctx->timing.total_ms = T.span(); ctx->timing.phase_ms = T.sum(K_PHASE);
     ctx->timing.algorithmic_bytes = algo_bytes; ctx->timing.beam_steps = steps;
     std::vector<uint32_t> stage_first(P + 2, 0);       // first ploidy of the stage that holds ploidy p

@@ -159,6 +159,8 @@ typedef struct {
     uint64_t upload_staged_bytes; /* last upload: bytes staged through the library's pinned ring (pageable sources)  */
     uint32_t upload_chunks;    /* floria_hip_phase_pileups_batch: chunks whose transfer overlapped the kernels (1 = not pipelined) */
     uint32_t reserved;
+    double   beam_union_ms;    /* wall time with at least one beam-search launch in flight (<= phase_ms; beam_ms, a sum over overlapping launches, can exceed it) */
+    double   optimize_union_ms;/* ... with at least one optimise launch in flight */
 } floria_timing;
 
 typedef struct floria_hip_ctx floria_hip_ctx;

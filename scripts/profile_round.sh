@@ -33,6 +33,10 @@ if bk:      # calls-weighted mean over the kernel's ploidy-specialised instances
 # per S1 call (= step): every launch of the two kernel families; the counter passes ran two S1 calls (one warm-up, one timed)
 calls=2.0
 out["hbm_bytes_per_step"]={fam: sum((2*v["fetch_kib"]+v["write_kib"])*1024 for k,v in out["kernels"].items() if key in k)/calls for fam,key in (("beam","beam_"),("optimize","optimize"))}
+import hashlib
+h=hashlib.sha256()
+for fn in sorted(glob.glob("floria_amd/csrc/*.h")+glob.glob("floria_amd/csrc/*.hip")): h.update(open(fn,"rb").read())
+out["kernel_sources_sha16"]=h.hexdigest()[:16]
 json.dump(out, open(O+"/pmc_summary.json","w"), indent=1)
 print(json.dumps(out)[:600])
 PY
