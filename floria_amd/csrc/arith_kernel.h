@@ -216,11 +216,13 @@ struct FxWave {
     }
     // keys of the lanes with `valid`, in the order of their ranks r = 0..cnt-1 (ascending with the lane); grow = may this table grow (false inside a resize).
     // tag: FX_TAGS LDS words, all ones between calls.
-    __device__ void insert_batch(uint32_t key, bool valid, uint32_t r, uint32_t cnt, uint32_t* tag, bool grow, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+    // (GROW is a template parameter so that the re-insertion inside a resize is not a recursive call: the whole thing inlines, no stack frame)
+    template <bool GROW>
+    __device__ __forceinline__ void insert_batch(uint32_t key, bool valid, uint32_t r, uint32_t cnt, uint32_t* tag, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
         uint32_t done = 0;
         const uint64_t h = FxTable::hash_of(key);
         while (done < cnt) {
-            if (grow && growth_left == 0) grow_batched(tag, spare_c, spare_s, lane);
+            if constexpr (GROW) { if (growth_left == 0) grow_batched(tag, spare_c, spare_s, lane); }
             if (buckets < FX_W) {                           // tables smaller than a group (the first seven keys): one by one
                 const uint64_t at = __ballot(valid && r == done);
                 put_small_lds((uint32_t)__shfl((int)key, (int)__builtin_ctzll(at)), lane);
@@ -248,7 +250,7 @@ struct FxWave {
         }
     }
     // reserve(1) on a full table, the old table's keys re-inserted in bucket order, 64 buckets at a time
-    __device__ void grow_batched(uint32_t* tag, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
+    __device__ __forceinline__ void grow_batched(uint32_t* tag, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
         const uint32_t full_cap = fx_cap_of(buckets), want = items + 1 > full_cap + 1 ? items + 1 : full_cap + 1;
         FxWave n;
         n.bind_lds(spare_c, spare_s, fx_buckets_for(want), lane);
@@ -260,7 +262,7 @@ struct FxWave {
             const bool fullb = !(c & 0x80u);
             const uint64_t fm = __ballot(fullb);
             const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-            n.insert_batch(key, fullb, r, (uint32_t)__popcll(fm), tag, false, spare_c, spare_s, lane);
+            n.template insert_batch<false>(key, fullb, r, (uint32_t)__popcll(fm), tag, spare_c, spare_s, lane);
         }
         spare_c = ctrl; spare_s = slot;
         *this = n;

@@ -137,7 +137,7 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 // of its position set (utils_frags.rs:33-72), a partition's `errors` the running sum over its positions in the bucket order of its position
 // map (local_clustering.rs:226-256), which is emulated per partition (arith_kernel.h).
 // (the ploidy 1-3 instances of 512 threads are held to the 80 VGPRs that let three workgroups share a CU: six waves per SIMD)
-constexpr int opt_min_waves(int tp, int threads, bool arith) { return (!arith && threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1; }
+constexpr int opt_min_waves(int tp, int threads, bool arith) { return arith ? (threads == 512 ? 4 : 1) : ((threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1); }      // (ARITH, 512 threads: 128 VGPRs = two workgroups per CU; 149 would leave one)
 template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false>
 __global__ __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(opt_min_waves(TP, OPT_THREADS, ARITH))))
 void optimize_kernel(OptArgs g) {
@@ -309,7 +309,7 @@ void optimize_kernel(OptArgs g) {
         // t0 + 1, .. of nt.  They depend on the histogram only, so the pass for round r + 1 runs on the wavefronts that have no position map to replay while
         // the statistics of round r are computed (a rejected round r makes them useless, and is the last).  inc: only the reads that reach into the interval of
         // positions whose code byte changed in the last batch of moves.
-        auto dist_arith = [&](uint32_t t0, uint32_t nt, bool inc) {
+        auto dist_arith = [&](uint32_t t0, uint32_t nt, bool inc) __attribute__((always_inline)) {
             const uint32_t chg_lo = inc ? s_chg_lo : 0u, chg_hi = inc ? s_chg_hi : 0xffffffffu;
             // (measured: a thread per read folding up to four partitions at once - the cells loaded once for all of them - is slower, 274 against 250 ms per call: half as many
             // threads have work)
@@ -365,12 +365,14 @@ void optimize_kernel(OptArgs g) {
         // in that order (`olist`, two parities): the statistics of the same partition in the other weighting (the final unit-count pass, :187-215) or
         // after a rejected round walk the list again instead of replaying the map.
         // par = which list is written (reuse = false) or walked again (reuse = true).
-        auto mec_stats_arith = [&](bool phred, uint32_t par, bool reuse, bool with_dist, bool dist_inc) {
+        // (always_inline: called from three places, hipcc would otherwise make it a real function whose captures — every local it touches — live in scratch memory:
+        // 1 KB of scratch per lane, 149 VGPRs and one workgroup per CU, measured)
+        auto mec_stats_arith = [&](bool phred, uint32_t par, bool reuse, bool with_dist, bool dist_inc) __attribute__((always_inline)) {
             uint32_t* const olist = g.ol_pool + ((uint64_t)blockIdx.x * 2 + par) * g.span_max * p;          // [partition][span_max]
             const uint64_t one = phred ? ONE_Q24 : 1ull;
             const double scale = phred ? 0x1p-24 : 1.0;
             // the terms of 64 listed positions (lane = entry; `have` = this lane holds one), added in lane order onto ef; returns the lanes' consensus counts
-            auto fold64 = [&](uint32_t k, uint32_t posrel, bool have, double& ef) -> uint64_t {
+            auto fold64 = [&](uint32_t k, uint32_t posrel, bool have, double& ef) __attribute__((always_inline)) -> uint64_t {
                 const uint64_t* cp = hist + (uint64_t)(have ? posrel : 0u) * PA + k * A;
                 uint64_t q[A];
 #pragma unroll
@@ -525,7 +527,7 @@ void optimize_kernel(OptArgs g) {
                 for (uint32_t d0 = 0; d0 < D; d0 += 64) {                    // 64 positions of the sorted first-insertion list at a time
                     const uint32_t mine = d0 + lane < D ? (wave_sort ? row[d0 + lane] : sp[start + d0 + lane] - k * span) + pos0 : 0u;
                     const uint32_t cnt = D - d0 < 64u ? D - d0 : 64u;
-                    if (g.fx_lds_off) t.insert_batch(mine, lane < cnt, lane, cnt, tag, true, spare_c, spare_s, lane);
+                    if (g.fx_lds_off) t.template insert_batch<true>(mine, lane < cnt, lane, cnt, tag, spare_c, spare_s, lane);
                     else for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");           // the keys (HBM scratch) were stored lane by lane; the walk reads them bucket by bucket
@@ -562,7 +564,7 @@ void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
         uint32_t best_par = 0;                                 // ARITH: the list of the accepted partition
-        auto stats = [&](bool phred, uint32_t par, bool reuse, bool with_dist = false, bool dist_inc = false) { if constexpr (ARITH) mec_stats_arith(phred, par, reuse, with_dist, dist_inc); else mec_stats(phred); };
+        auto stats = [&](bool phred, uint32_t par, bool reuse, bool with_dist = false, bool dist_inc = false) __attribute__((always_inline)) { if constexpr (ARITH) mec_stats_arith(phred, par, reuse, with_dist, dist_inc); else mec_stats(phred); };
 
         refresh_codes(false);
         OPT_TICK(0);     // build
