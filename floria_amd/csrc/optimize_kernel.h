@@ -137,7 +137,10 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 // of its position set (utils_frags.rs:33-72), a partition's `errors` the running sum over its positions in the bucket order of its position
 // map (local_clustering.rs:226-256), which is emulated per partition (arith_kernel.h).
 // (the ploidy 1-3 instances of 512 threads are held to the 80 VGPRs that let three workgroups share a CU: six waves per SIMD)
-constexpr int opt_min_waves(int tp, int threads, bool arith) { return arith ? (threads == 512 ? 4 : 1) : ((threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1); }      // (ARITH, 512 threads: 128 VGPRs = two workgroups per CU; 149 would leave one)
+#ifndef FLORIA_ARITH_OPT_WAVES
+#define FLORIA_ARITH_OPT_WAVES 6
+#endif
+constexpr int opt_min_waves(int tp, int threads, bool arith) { return arith ? (threads == 512 ? FLORIA_ARITH_OPT_WAVES : 1) : ((threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1); }      // (ARITH, 512 threads: 80 VGPRs = three workgroups per CU; the 149 hipcc takes when left alone leave one.  Measured on config 4, arith = 1: 4 / 5 / 6 waves 177 / 175 / 171 ms)
 template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false>
 __global__ __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(opt_min_waves(TP, OPT_THREADS, ARITH))))
 void optimize_kernel(OptArgs g) {
