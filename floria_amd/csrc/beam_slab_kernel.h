@@ -288,6 +288,8 @@ void beam_slab_kernel(BeamArgs g) {
     const float rcp_p = __builtin_amdgcn_rcpf((float)p);
     const float eps_f = (float)g.eps, rdiv_f = (float)(1.0 / GCOLD(div_factor)), cutoff_f = (float)g.cutoff;
     const double margin_alone = fabs(0.0 - g.cutoff);      // |(p_k - lse) - ln 0.01| with p_k == lse
+    const bool screen_ok = g.eps >= 1e-3 && g.eps <= 0.2;
+    const uint32_t screen_nmax = GCOLD(binom_nmax);
     const uint32_t my_sl = lane / psl, my_k = lane % psl;
     const bool lane_pair = my_sl < S && my_k < p;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -408,7 +410,9 @@ void beam_slab_kernel(BeamArgs g) {
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
             const uint64_t tw1 = sm_cur.tw1, tw2 = sm_cur.tw2;
             const uint32_t limit = i < (uint32_t)EARLY_READS ? LM : B;
-            const float tol1 = 4.f * BINOM_SCREEN_C * (float)L + 1e-3f;      // level-1 screen of the pruning test (phase B): n <= L in every lane
+            // level-1 screen of the pruning test (phase B): n <= L in every lane.  Its error bound is validated (floria_hip_selftest) for 1e-3 <= eps <= 0.2 and n within the
+            // host-built table: outside of that every decision takes level 2 (an infinite tolerance: no lane is ever "far enough", no winner "alone")
+            const float tol1 = screen_ok && L <= screen_nmax ? 4.f * BINOM_SCREEN_C * (float)L + 1e-3f : 3e38f;
             const uint32_t ntiles = (L + SLAB_TILE - 1) / SLAB_TILE;
             const int32_t new_hi = last_rel > hi_rel ? last_rel : hi_rel;
             uint64_t* st_q = ST_q(cur); uint64_t* st_h1 = ST_h1(cur); uint64_t* st_h2 = ST_h2(cur);

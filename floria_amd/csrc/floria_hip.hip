@@ -778,10 +778,10 @@ const char* floria_hip_last_error(void) { return g_err.c_str(); }
 }  // extern "C"
 
 // HIP reads GPU_MAX_HW_QUEUES once, when the runtime initialises (lazily, at the first API call); the launch plans of s1_core want 12 hardware queues (below).
-// A host that LINKS this library gets the variable set here, when the loader runs the library's constructors — before its main() and therefore before any HIP
-// call of its own; a host that dlopen()s it after having used HIP cannot be helped (probe_hw_queues notices, and the plans degrade with a message).  Never
-// overrides a value the user has set.
-__attribute__((constructor)) static void floria_hip_set_hw_queue_default() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+// The library does NOT touch the environment on its own (rounds 2-4 did, from a constructor: a setenv() in a process that other threads may be reading the
+// environment of): a host either exports GPU_MAX_HW_QUEUES=12 itself or calls floria_hip_init_env() once, from its main thread, before its first HIP
+// call; a host that did neither is noticed (probe_hw_queues) and gets plans that stay within the queues it has, with one message on stderr.
+extern "C" int floria_hip_init_env(void) { return setenv("GPU_MAX_HW_QUEUES", "12", 0) == 0 ? 0 : FLORIA_E_INVALID; }      // (never overrides a value the user has set)
 
 namespace {
 // How many streams of this process really execute side by side?  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment

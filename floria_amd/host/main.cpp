@@ -87,7 +87,7 @@ static void write_debug_graph(const ContigWork& w) {
 }
 
 int main(int argc, char** argv) {
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);      // the job groups' streams and the copy streams must not share hardware queues (read when HIP initialises)
+    floria_hip_init_env();                      // GPU_MAX_HW_QUEUES=12 unless set: the job groups' streams and the copy streams must not share hardware queues (read when HIP initialises)
     Options o;
     bool have_e = false, have_l = false;
     std::string dump_frags;

@@ -19,7 +19,7 @@ _LIB = None
 
 # every symbol include/floria_hip.h declares
 SYMBOLS = [
-    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version", "floria_hip_realign", "floria_hip_selftest",
+    "floria_hip_create", "floria_hip_destroy", "floria_hip_last_error", "floria_hip_version", "floria_hip_init_env", "floria_hip_realign", "floria_hip_selftest",
     "floria_hip_block_ranges", "floria_hip_ranges_free", "floria_hip_contig_upload", "floria_hip_contig_free",
     "floria_hip_phase_blocks_resident", "floria_hip_phase_blocks", "floria_hip_block_result_free",
     "floria_hip_phase_blocks_batch", "floria_hip_reassign", "floria_hip_groups_free", "floria_hip_last_timing",

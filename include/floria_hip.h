@@ -170,6 +170,13 @@ int  floria_hip_create(int device, floria_hip_ctx** out);
 void floria_hip_destroy(floria_hip_ctx* ctx);
 const char* floria_hip_last_error(void);
 const char* floria_hip_version(void);
+/* Step 0 for a host that links this library: call ONCE, from the main thread, BEFORE the process's first HIP call (floria_hip_create included).  It sets
+ * GPU_MAX_HW_QUEUES=12 unless the variable is already set: HIP reads it once, when the runtime initialises, and maps streams onto that many hardware queues
+ * (default 4); the job groups of S1, the upload pipeline and the speculative ploidy stages want their streams on separate queues.  Exporting the variable in the
+ * process environment does the same.  Without it everything still works and returns the same results: floria_hip_create measures how many streams really run
+ * side by side, keeps its launch plans within that and says so once on stderr (about 25 % less throughput from host memory).  The library itself never touches
+ * the environment (setenv is not safe beside threads that read it). */
+int  floria_hip_init_env(void);
 
 /* utils_frags::get_range_with_lengths (utils_frags.rs:405-463), host side, exact restatement.
  * snp_to_genome_pos has n_snps entries (0-based SNP index -> bp).  Fails (FLORIA_E_INVALID) where

@@ -766,3 +766,30 @@ def test_s2_assign_only_leaves_the_splits_to_the_host(gpu_ctx, hip_lib, oracle_m
             assert tuple(map(int, full.range[k])) == rngs[k] and list(map(int, full.group(k))) == parts[k], (cfg, idx, k)
         n_split += full.n_groups - len(groups)
     assert n_split > 0
+
+
+@pytest.mark.parametrize("eps", (5e-4, 0.3, 0.45))
+def test_epsilon_outside_the_screens_validated_range(gpu_ctx, hip_lib, oracle_mod, eps):
+    """the f32 level-1 screen of the pruning test has a measured error bound for 1e-3 <= eps <= 0.2 and n within the host-built table only; outside
+    of that range every decision must take the exact path.  Results AND the pruning margin equal the oracle's."""
+    for seed in range(4):
+        rng = np.random.default_rng(8800 + seed)
+        pile = random_pileup(rng, int(rng.integers(40, 160)), int(rng.integers(20, 70)), int(rng.integers(2, 4)), max_len=int(rng.integers(8, 40)), err=0.05)
+        S = int(pile.last.max())
+        s = np.asarray([1, max(1, S // 2)], np.uint32); e = np.asarray([S, S], np.uint32)
+        ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, 4, 10), threads=4)
+        rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(eps, 4, 10))
+        assert_block_results_equal(ro, rg, f"eps {eps} seed {seed}")
+        assert ro.min_prune_margin == rg.min_prune_margin
+
+
+def test_reads_longer_than_the_binomial_table(gpu_ctx, hip_lib, oracle_mod):
+    """... and a read of more cells than the table's n (1024): the screen is not trusted there either (and the p-value comes from the device formula)."""
+    rng = np.random.default_rng(8900)
+    pile = random_pileup(rng, 50, 2600, 2, max_len=1500, err=0.04, drop=0.05)
+    assert int(np.diff(pile.read_off).max()) > 1100
+    S = int(pile.last.max())
+    s, e = np.asarray([1], np.uint32), np.asarray([S], np.uint32)
+    ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(EPS, 3, 6), threads=1)
+    rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(EPS, 3, 6))
+    assert_block_results_equal(ro, rg, "long reads")
