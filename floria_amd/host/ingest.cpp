@@ -601,25 +601,153 @@ bool BamStream::next(BamFile& seg, size_t min_bytes) {
 
 std::vector<std::string> get_contigs_to_phase(const BamFile& bam) { return bam.target_names; }
 
+// get_vcf_profile + get_genotypes_from_vcf_hts (file_reader.rs:113-175, 239-314).  rust-htslib's bcf::Reader takes text VCF (plain / gzip / bgzip) and binary
+// BCF2 alike; so does this reader: the file is read through zlib (a BGZF file is a multi-member gzip stream) and told apart by its first bytes.
+namespace {
+struct VcfSink {
+    VcfProfile vp;
+    const std::vector<std::string>& ref_chroms;
+    std::string last_chrom;
+    bool have_last = false;
+    SnpPosition snp_counter = 1;
+    explicit VcfSink(const std::vector<std::string>& rc) : ref_chroms(rc) {}
+    static bool is_acgt(char ch) { const char u = (char)(ch & ~0x20); return u == 'A' || u == 'C' || u == 'G' || u == 'T'; }
+    // one record: CHROM, 1-based POS, REF + ALT alleles
+    void add(const std::string& chrom, long pos1, const std::vector<std::string>& alleles) {
+        const bool known = std::find(ref_chroms.begin(), ref_chroms.end(), chrom) != ref_chroms.end();
+        if (known && (!have_last || last_chrom != chrom)) { snp_counter = 1; last_chrom = chrom; have_last = true; }       // :277-280
+        std::vector<Genotype> al_vec;
+        for (const std::string& a : alleles) {
+            if (a.size() != 1 || !is_acgt(a[0])) return;                                                                   // :290-300 (an empty allele cannot occur)
+            al_vec.push_back((Genotype)a[0]);
+        }
+        const GnPosition pos0 = (GnPosition)(pos1 - 1);                          // htslib's 0-based pos()
+        vp.snp_to_genome_pos[chrom].push_back(pos0);                             // get_genotypes_from_vcf_hts: every contig of the VCF
+        if (!known) return;
+        vp.vcf_snp_pos_to_gn_pos_map[chrom][snp_counter] = pos0;
+        vp.vcf_pos_to_snp_counter_map[chrom][pos0] = snp_counter;
+        vp.vcf_pos_allele_map[chrom][pos0] = al_vec;
+        ++snp_counter;
+    }
+};
+
+// BCF2 (VCFv4.x specification, section 6): "BCF\2\2", l_text, the VCF header text, then records {l_shared, l_indiv, CHROM (index into the header's contig
+// dictionary), POS (0-based), rlen, QUAL, n_info | n_allele << 16, n_sample | n_fmt << 24, ID, alleles ..}: typed values with a descriptor byte
+// (length << 4 | type; length 15 = a typed integer with the real length follows; type 7 = characters).  Only CHROM, POS and the alleles are read.
+void read_bcf(gzFile f, const std::string& vcf_file, std::vector<unsigned char> head, VcfSink& sink) {
+    auto fail = [&](const char* what) -> void { throw Error(FLORIA_E_INVALID, "BCF " + vcf_file + ": " + what); };
+    auto need = [&](std::vector<unsigned char>& buf, size_t n) {
+        const size_t have = buf.size();
+        if (have >= n) return true;
+        buf.resize(n);
+        size_t got = have;
+        while (got < n) { const int r = gzread(f, buf.data() + got, (unsigned)std::min<size_t>(n - got, 1u << 30)); if (r <= 0) break; got += (size_t)r; }
+        buf.resize(got);
+        return got >= n;
+    };
+    auto u32 = [](const unsigned char* q) { return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; };
+    if (!need(head, 9) || memcmp(head.data(), "BCF\2", 4) != 0 || head[4] < 1) fail("not a BCF2 file");
+    const uint32_t l_text = u32(head.data() + 5);
+    if (!need(head, 9 + (size_t)l_text)) fail("truncated header");
+    // the contig dictionary: ##contig=<ID=name,..[,IDX=k]> lines in order (IDX overrides the position)
+    std::vector<std::string> contigs;
+    {
+        const std::string text((const char*)head.data() + 9, l_text);
+        size_t at = 0;
+        while (at < text.size()) {
+            size_t e = text.find('\n', at); if (e == std::string::npos) e = text.size();
+            const std::string line = text.substr(at, e - at);
+            at = e + 1;
+            if (line.rfind("##contig=<", 0) != 0) continue;
+            std::string id; long idx = -1;
+            size_t q = 10;
+            while (q < line.size() && line[q] != '>') {
+                size_t eq = line.find('=', q), stop = q;
+                if (eq == std::string::npos) break;
+                const std::string key = line.substr(q, eq - q);
+                size_t v0 = eq + 1, v1;
+                if (v0 < line.size() && line[v0] == '"') { v1 = line.find('"', v0 + 1); if (v1 == std::string::npos) v1 = line.size(); stop = v1 + 1; ++v0; }
+                else { v1 = line.find_first_of(",>", v0); if (v1 == std::string::npos) v1 = line.size(); stop = v1; }
+                const std::string val = line.substr(v0, v1 - v0);
+                if (key == "ID") id = val; else if (key == "IDX") idx = strtol(val.c_str(), nullptr, 10);
+                q = stop; if (q < line.size() && line[q] == ',') ++q;
+            }
+            if (id.empty()) continue;
+            if (idx < 0) idx = (long)contigs.size();
+            if ((size_t)idx >= contigs.size()) contigs.resize((size_t)idx + 1);
+            contigs[(size_t)idx] = id;
+        }
+    }
+    std::vector<unsigned char> rec;
+    for (;;) {
+        rec.clear();
+        if (!need(rec, 8)) { if (rec.empty()) break; fail("truncated record header"); }
+        const uint32_t l_shared = u32(rec.data()), l_indiv = u32(rec.data() + 4);
+        if (l_shared < 24) fail("record shorter than its fixed fields");
+        rec.clear();
+        if (!need(rec, (size_t)l_shared + l_indiv)) fail("truncated record");
+        const unsigned char* q = rec.data();
+        const unsigned char* const end = q + l_shared;
+        const int32_t chrom = (int32_t)u32(q), pos0 = (int32_t)u32(q + 4);
+        const uint32_t n_allele = u32(q + 16) >> 16;
+        q += 24;
+        if (chrom < 0 || (size_t)chrom >= contigs.size() || contigs[(size_t)chrom].empty()) fail("CHROM index outside the header's contig dictionary");
+        // typed value: -> (type, count), cursor behind the descriptor
+        auto typed = [&](uint32_t& type, uint32_t& count) {
+            if (q >= end) fail("typed value beyond the record");
+            const unsigned d = *q++;
+            type = d & 15u; count = d >> 4;
+            if (count == 15) {                                        // the real length is a typed integer
+                if (q >= end) fail("typed length beyond the record");
+                const unsigned t2 = *q++ & 15u;
+                const size_t w = t2 == 1 ? 1 : t2 == 2 ? 2 : t2 == 3 ? 4 : 0;
+                if (!w || q + w > end) fail("bad typed length");
+                count = w == 1 ? q[0] : w == 2 ? (uint32_t)q[0] | (uint32_t)q[1] << 8 : u32(q);
+                q += w;
+            }
+        };
+        auto width = [&](uint32_t type) -> size_t { return type == 1 || type == 7 ? 1 : type == 2 ? 2 : type == 3 || type == 5 ? 4 : 0; };
+        uint32_t ty, cnt;
+        typed(ty, cnt);                                                // ID
+        if (cnt && (!width(ty) || q + (size_t)cnt * width(ty) > end)) fail("bad ID");
+        q += (size_t)cnt * width(ty);
+        std::vector<std::string> alleles;
+        for (uint32_t a = 0; a < n_allele; ++a) {
+            typed(ty, cnt);
+            if (cnt && (ty != 7 || q + cnt > end)) fail("allele is not a string");
+            alleles.emplace_back((const char*)q, cnt);
+            q += cnt;
+        }
+        if (alleles.empty()) continue;
+        sink.add(contigs[(size_t)chrom], (long)pos0 + 1, alleles);
+    }
+}
+}  // namespace
+
 VcfProfile get_vcf_profile(const std::string& vcf_file, const std::vector<std::string>& ref_chroms) {
     gzFile f = gzopen(vcf_file.c_str(), "rb");                                 // plain text, gzip and bgzip alike
     if (!f) throw Error(FLORIA_E_INVALID, "cannot open VCF " + vcf_file);
-    VcfProfile vp;
-    std::string line, last_chrom;
-    bool have_last = false;
-    SnpPosition snp_counter = 1;
+    VcfSink sink(ref_chroms);
     std::vector<char> buf(1 << 16);
-    auto is_acgt = [](char ch) { const char u = (char)(ch & ~0x20); return u == 'A' || u == 'C' || u == 'G' || u == 'T'; };
+    {   // BCF2 or text?
+        std::vector<unsigned char> head(5);
+        const int got = gzread(f, head.data(), 5);
+        head.resize(got > 0 ? (size_t)got : 0);
+        if (head.size() == 5 && memcmp(head.data(), "BCF\2", 4) == 0) {
+            try { read_bcf(f, vcf_file, std::move(head), sink); } catch (...) { gzclose(f); throw; }
+            gzclose(f);
+            return std::move(sink.vp);
+        }
+        if (gzrewind(f) != 0) { gzclose(f); throw Error(FLORIA_E_INVALID, "cannot rewind VCF " + vcf_file); }
+    }
+    std::string line;
     for (;;) {
         line.clear();
         bool got = false;
         while (gzgets(f, buf.data(), (int)buf.size())) { got = true; line += buf.data(); if (!line.empty() && line.back() == '\n') break; }
         if (!got) break;
         while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-        if (line.empty() || line[0] == '#') {
-            if (line.rfind("BCF", 0) == 0) { gzclose(f); throw Error(FLORIA_E_UNSUPPORTED, "binary BCF input is not supported; convert to VCF"); }
-            continue;
-        }
+        if (line.empty() || line[0] == '#') continue;
         // CHROM POS ID REF ALT ...
         size_t t[5], k = 0, from = 0;
         while (k < 5) { const size_t x = line.find('\t', from); if (x == std::string::npos) break; t[k++] = x; from = x + 1; }
@@ -630,25 +758,10 @@ VcfProfile get_vcf_profile(const std::string& vcf_file, const std::vector<std::s
         const std::string alt = line.substr(t[3] + 1, (k == 5 ? t[4] : line.size()) - t[3] - 1);
         std::vector<std::string> alleles{ref};
         if (alt != ".") { size_t a = 0; for (;;) { const size_t x = alt.find(',', a); alleles.push_back(alt.substr(a, x == std::string::npos ? x : x - a)); if (x == std::string::npos) break; a = x + 1; } }
-        const bool known = std::find(ref_chroms.begin(), ref_chroms.end(), chrom) != ref_chroms.end();
-        if (known && (!have_last || last_chrom != chrom)) { snp_counter = 1; last_chrom = chrom; have_last = true; }       // :277-280
-        bool is_snp = true;
-        std::vector<Genotype> al_vec;
-        for (const std::string& a : alleles) {
-            if (a.size() != 1 || !is_acgt(a[0])) { is_snp = false; break; }                                                // :290-300 (an empty allele cannot occur)
-            al_vec.push_back((Genotype)a[0]);
-        }
-        if (!is_snp) continue;
-        const GnPosition pos0 = (GnPosition)(pos1 - 1);                          // htslib's 0-based pos()
-        vp.snp_to_genome_pos[chrom].push_back(pos0);                             // get_genotypes_from_vcf_hts: every contig of the VCF
-        if (!known) continue;
-        vp.vcf_snp_pos_to_gn_pos_map[chrom][snp_counter] = pos0;
-        vp.vcf_pos_to_snp_counter_map[chrom][pos0] = snp_counter;
-        vp.vcf_pos_allele_map[chrom][pos0] = al_vec;
-        ++snp_counter;
+        sink.add(chrom, pos1, alleles);
     }
     gzclose(f);
-    return vp;
+    return std::move(sink.vp);
 }
 
 std::map<std::string, std::string> get_fasta_seqs(const std::string& fasta_file) {

@@ -212,3 +212,16 @@ def test_a_position_map_that_is_full_when_a_position_is_touched_again(arith, hip
     for eps in NON_DYADIC:
         ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, eps, P=3, B=4)
         assert_block_results_equal(ro, rg, f"{full} positions, eps {eps}")
+
+
+def test_blocks_spanning_more_than_1024_positions_in_reference_arithmetic(arith, hip_lib, oracle_mod):
+    """Beyond 1024 positions per block the first-insertion order comes from the workgroup-wide sort instead of the per-wavefront counting sort, the position
+    maps grow to 2048 buckets, and reads span several LDS tiles."""
+    rng = np.random.default_rng(9300)
+    pile = random_pileup(rng, 90, 1500, 3, max_len=1300, err=0.05, drop=0.1)
+    S = int(pile.last.max())
+    s, e = np.asarray([1, 200], np.uint32), np.asarray([S, min(S, 900)], np.uint32)
+    ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, 0.04, P=3, B=5)
+    assert int(pile.last.max() - pile.first.min()) + 1 > 1024
+    assert_block_results_equal(ro, rg, "wide block")
+    assert ro.min_prune_margin == rg.min_prune_margin

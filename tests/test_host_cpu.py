@@ -709,3 +709,47 @@ def test_unmapped_tail_larger_than_the_window_ends_the_stream(floria_hip, tmp_pa
     assert run(pa, ("-e", "0.03", "-l", "10000", "--bam-window-kb", "1")) == base
     assert run(pa, ("-e", "0.03", "-l", "10000")) == base
     assert run(pa, ("--bam-window-kb", "1")) == run(pb, ())          # the estimator loop walks the same stream
+
+
+def test_bcf2_input_assembled_from_the_specification(floria_hip, tmp_path):
+    """rust-htslib's bcf::Reader (file_reader.rs:239-314) reads binary BCF2 as well as text VCF; so does ingest.cpp since round 5.  The file is assembled
+    byte by byte from the VCF specification's BCF2 chapter inside this test (by nothing of floria_amd/): BGZF members cut inside the header text and inside a
+    record, a contig dictionary given out of order with IDX=, typed strings with the 15+ length escape (a long ID, a long insertion allele), records with INFO
+    and genotype blocks that must be skipped by their lengths, a multi-allelic SNP, an indel and a symbolic allele (dropped by the SNP filter), ALT '.'.
+    Expected: exactly what the text VCF with the same records gives."""
+    import struct
+    recs = [("ctgB", 10, "rs1", "A", ["G"]), ("ctgB", 25, "x" * 40, "C", ["T", "G"]), ("ctgB", 31, ".", "AT", ["A"]), ("ctgB", 40, ".", "G", ["<DEL>"]),
+            ("ctgB", 57, ".", "T", []), ("ctgA", 5, ".", "g", ["a"]), ("ctgA", 9, ".", "C", ["C" + "ACGT" * 8]), ("ctgA", 1200, "id2", "T", ["C"])]
+    text = ("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n##contig=<ID=ctgA,length=5000,IDX=1>\n##contig=<ID=ctgB,length=100,IDX=0>\n"
+            "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\n")
+    body = "".join(f"{c}\t{p}\t{i}\t{r}\t{','.join(a) if a else '.'}\t30\tPASS\tDP=7\tGT\t0/1\n" for c, p, i, r, a in recs)
+    vcf = str(tmp_path / "x.vcf"); open(vcf, "w").write(text + body)
+
+    def tstr(b):                                   # typed string: descriptor (len << 4 | 7), lengths >= 15 as 0xF7 + a typed int8 / int16
+        b = b.encode()
+        if len(b) < 15:
+            return bytes([len(b) << 4 | 7]) + b
+        return bytes([0xF7]) + (bytes([0x11, len(b)]) if len(b) < 128 else bytes([0x12]) + struct.pack("<h", len(b))) + b
+    cid = {"ctgB": 0, "ctgA": 1}
+    out = b"BCF\x02\x02" + struct.pack("<I", len(text) + 1) + text.encode() + b"\0"
+    for c, p, i, r, a in recs:
+        shared = struct.pack("<iiifII", cid[c], p - 1, len(r), 30.0, (1 + len(a)) << 16 | 1, 1 << 24 | 1)
+        shared += (tstr(i) if i != "." else bytes([0x07])) + tstr(r) + b"".join(tstr(x) for x in a)
+        shared += bytes([0x11, 0x00])                                   # FILTER: one int8, PASS = 0
+        shared += bytes([0x11, 0x01, 0x11, 0x07])                       # INFO: key 1 (DP) = int8 7
+        indiv = bytes([0x11, 0x02, 0x21, 0x02, 0x04])                   # FORMAT key 2 (GT): two int8 per sample: 0/1
+        out += struct.pack("<II", len(shared), len(indiv)) + shared + indiv
+    cuts = [0, 3, 200, len(out) - 37, len(out) - 11, len(out)]        # inside the magic, the header text, the last records
+    bcf = str(tmp_path / "x.bcf")
+    open(bcf, "wb").write(b"".join(_bgzf_member(out[a:b]) for a, b in zip(cuts[:-1], cuts[1:])) + _BGZF_EOF)
+    got = {}
+    for name, path in (("vcf", vcf), ("bcf", bcf)):
+        r = subprocess.run([floria_hip, "--vcf-profile", path, "ctgA", "ctgB"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got[name] = r.stdout
+    assert got["bcf"] == got["vcf"]
+    assert got["vcf"].split("\n")[:4] == ["#ctgA\t2", "4\tga", "1199\tTC", "#ctgB\t3"] and "24\tCTG" in got["vcf"] and "56\tT" in got["vcf"]
+    # a truncated file is an error, not a shorter list
+    open(bcf, "wb").write(_bgzf_member(out[:len(out) - 9]) + _BGZF_EOF)
+    r = subprocess.run([floria_hip, "--vcf-profile", bcf, "ctgA", "ctgB"], capture_output=True, text=True)
+    assert r.returncode != 0 and "truncated" in r.stderr
