@@ -118,7 +118,11 @@ int main(int argc, char** argv) {
             else if (a == "-t" || a == "--threads") o.num_threads = (size_t)std::stoul(val());
             else if (a == "-e" || a == "--epsilon") { o.epsilon = std::stod(val()); have_e = true; }
             else if (a == "-n" || a == "--beam-solns") o.max_number_solns = (size_t)std::stoul(val());
-            else if (a == "-p" || a == "--max-ploidy") o.max_ploidy = (size_t)std::stoul(val());
+            else if (a == "-p" || a == "--max-ploidy") {
+                o.max_ploidy = (size_t)std::stoul(val());
+                if (o.max_ploidy < 1 || o.max_ploidy > FLORIA_MAX_PLOIDY)           // (the reference takes any -p; its default is 5.  include/floria_hip.h: the optimise kernel packs partitions into 4 bits)
+                    throw Error(FLORIA_E_UNSUPPORTED, "-p " + std::to_string(o.max_ploidy) + ": this build phases ploidies 1 to " + std::to_string(FLORIA_MAX_PLOIDY));
+            }
             else if (a == "-l" || a == "--block-length") { o.block_length = (size_t)std::stoul(val()); have_l = true; }
             else if (a == "-d" || a == "--snp-density") o.snp_density = std::stod(val());
             else if (a == "-s" || a == "--ploidy-sensitivity") o.ploidy_sensitivity = (uint8_t)std::stoul(val());
