@@ -225,13 +225,13 @@ __host__ __device__ inline SlabLds slab_lds_layout(uint32_t LM, uint32_t p, bool
 //     `same` cells cost nothing but do not perturb the sum); `same` stays an exact integer sum;
 //   * a state carries error_vec (global_clustering.rs:196-202) as p f64 in LDS, a child's score is their sum in partition order with the read's diff added to its
 //     partition first; the survivors' vectors are the parents' with that one element replaced.
-// Slabs, hash, heap, pruning screen, traceback: unchanged.  Biallelic or not, but no q = 0 cells (those pileups keep the generic kernel in this mode).
+// Slabs, hash, heap, pruning screen, traceback: unchanged.  Biallelic or not; pileups with q = 0 cells classify from the sums (their presence bit is part of it) and leave
+// the same terms behind.
 template <int A, bool Q0, int TP = 0, int TB = 0, bool SPEC = false, bool ARITH = false>
 // waves per SIMD: four for the ploidy 2 and 3 instances (126-128 VGPRs, < 10 KB of LDS per wave), SLAB_WAVES = 3 where LDS limits (ploidy >= 4, runtime-parameter
 // instances).  Measured and left alone: five waves spill 17-29 VGPRs and starve the co-running optimise kernels.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ARITH ? 1 : slab_waves(TP), ARITH ? SLAB_WAVES_ARITH : slab_waves(TP))))
 void beam_slab_kernel(BeamArgs g) {
-    static_assert(!ARITH || !Q0, "the reference-arithmetic instances classify from the code bytes");
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
     const uint32_t p = TP ? (uint32_t)TP : g.ploidy, B = TB ? (uint32_t)TB : g.beam, LM = p * B, NS = LM * p;
@@ -424,7 +424,16 @@ void beam_slab_kernel(BeamArgs g) {
             // number of the tile's cells at written positions (<= hi_rel; a prefix, cells ascend) and, for q=0 pileups,
             // the presence-hash words of the cells (LDS) and their sum over the cells beyond hi_rel
             auto scan_tile = [&](uint32_t tl) {
-                if constexpr (ARITH) return;        // (set order: the cells inside the written window are not a prefix; phase A tests every cell)
+                if constexpr (ARITH) {              // (set order: the cells inside the written window are not a prefix; phase A tests every cell)
+                    if constexpr (Q0) {             // q = 0 pileups: the presence-hash words of the tile's cells (LDS), as below
+#pragma unroll
+                        for (int u = 0; u < SLAB_TILE / 64; ++u) {
+                            const uint32_t c = lane + 64 * u;
+                            if (c < tl) { const uint32_t hx = hash_idx(c_snp[c * CST], c_aw[c * CST] >> 28); c_rp1[c] = g.Rp1[hx]; c_rp2[c] = g.Rp2[hx]; }
+                        }
+                    }
+                    return;
+                }
                 uint32_t cnt_in = 0;
                 uint64_t b1 = 0, b2 = 0;
                 uint32_t snps[SLAB_TILE / 64];
@@ -482,7 +491,105 @@ void beam_slab_kernel(BeamArgs g) {
 #endif
             const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
             const bool trunc = tend >= (int32_t)start_rel;            // some written position leaves the hash window this step
-            if constexpr (!CODES) {
+            if constexpr (!CODES && ARITH) {
+                // q = 0 pileups in the reference's arithmetic: classification from the sums (their presence bit is part of it), otherwise as the code-byte form below:
+                // one f64 term per (live slab, cell) in LDS, one fold lane per slab; the exact side sums (same, presence hash of the read's new allele keys) by LDS atomics
+                {   // (1) positions leaving the hash window
+                    uint32_t Gs = 1, lgGs = 0;
+                    while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
+                    const uint32_t per = 64u >> lgGs;
+                    if (trunc)
+                    for (uint32_t l0 = 0; l0 < nlive; l0 += per) {
+                        const uint32_t li = l0 + (lane >> lgGs), sub = lane & (Gs - 1);
+                        const bool act = li < nlive;
+                        const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
+                        uint64_t t1 = 0, t2 = 0;
+                        for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
+                            if (act) {
+                                uint64_t v[A];
+                                const char* vp = pool + (slab_off + (uint32_t)pr * pos_bytes);
+#pragma unroll
+                                for (int h = 0; h < A / 2; ++h) { const ulonglong2 w2 = *(const ulonglong2*)(vp + 16 * h); v[2 * h] = w2.x; v[2 * h + 1] = w2.y; }
+#pragma unroll
+                                for (int al = 0; al < A; ++al) {
+                                    const uint32_t hx = hash_idx(pos0 + (uint32_t)pr, (uint32_t)al);
+                                    const uint64_t qv = Q0 ? (v[al] & QMASK63) : v[al];
+                                    t1 += g.Rq1[hx] * qv; t2 += g.Rq2[hx] * qv;
+                                    if (Q0) { t1 += v[al] ? g.Rp1[hx] : 0ull; t2 += v[al] ? g.Rp2[hx] : 0ull; }
+                                }
+                            }
+                        }
+                        t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs);
+                        if (act && sub == 0) { const uint32_t sidr = live_id[li]; r_t1[sidr] = t1; r_t2[sidr] = t2; }
+                    }
+                }
+                for (uint32_t x = lane; x < nlive; x += 64) { const uint32_t sidr = live_id[x]; r_qs[sidr] = 0; if (Q0) { r_np1[sidr] = 0; r_np2[sidr] = 0; } }
+                for (uint32_t t = 0; t < ntiles; ++t) {
+                    if (ntiles > 1) stage_tile(t); else if (Q0) __syncthreads();          // (the presence-hash words of scan_tile)
+                    const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                    const uint32_t RS = (tl + 7u) & ~7u;
+                    const uint32_t cap_s = div_small((uint32_t)SLAB_TERM_CAP, __builtin_amdgcn_rcpf((float)RS));
+                    const uint32_t spp = min(nlive, min(64u, cap_s));
+                    for (uint32_t l0 = 0; l0 < nlive; l0 += spp) {
+                        const uint32_t ns = min(spp, nlive - l0);
+                        const uint32_t Gl = div_small(64u, __builtin_amdgcn_rcpf((float)ns));
+                        const float rcp_gl = __builtin_amdgcn_rcpf((float)Gl);
+                        const uint32_t lsl = div_small(lane, rcp_gl), sub = lane - lsl * Gl;
+                        const bool act = lsl < ns;
+                        const uint32_t sidr = act ? (uint32_t)live_id[l0 + lsl] : 0u;
+                        const uint32_t slab_off = sidr * slab_bytes;
+                        double* const trow = terms + lsl * RS;
+                        uint64_t qs = 0, np1 = 0, np2 = 0;
+                        if (act) {
+                            constexpr int N = 4;                                 // 16-B slab pieces in flight per lane
+                            const uint32_t U = div_small(RS + Gl - 1u, rcp_gl);
+                            for (uint32_t u0 = 0; u0 < U; u0 += N) {
+                                uint32_t aws[N], cc[N]; bool vs[N], ins[N]; ulonglong2 vv[N][A / 2];
+#pragma unroll
+                                for (int u = 0; u < N; ++u) {
+                                    cc[u] = sub + (u0 + (uint32_t)u) * Gl; vs[u] = cc[u] < tl; const uint32_t cx = vs[u] ? cc[u] : 0u;
+                                    const uint32_t o = c_snp[cx * CST] - pos0; aws[u] = c_aw[cx * CST];
+                                    ins[u] = vs[u] && (int32_t)o <= hi_rel;
+                                    const char* cp = pool + (slab_off + (ins[u] ? o : 0u) * pos_bytes);
+#pragma unroll
+                                    for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
+                                }
+#pragma unroll
+                                for (int u = 0; u < N; ++u) {
+                                    const uint32_t al = aws[u] >> 28, w = aws[u] & 0x0fffffffu;
+                                    uint64_t v[A], mx = 0, va = 0;
+#pragma unroll
+                                    for (int x = 0; x < A; x += 2) { v[x] = ins[u] ? vv[u][x / 2].x : 0ull; v[x + 1] = ins[u] ? vv[u][x / 2].y : 0ull; }
+#pragma unroll
+                                    for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
+                                    const bool nonempty = mx != 0, same = nonempty && (Q0 ? (va & QMASK63) : va) == mx;
+                                    qs += same ? w : 0u;
+                                    if (Q0) { const bool np = vs[u] && !(va >> 63); np1 += np ? c_rp1[vs[u] ? cc[u] : 0u] : 0ull; np2 += np ? c_rp2[vs[u] ? cc[u] : 0u] : 0ull; }
+                                    double tv = nonempty ? (double)w * 0x1p-24 : g.eps;
+                                    tv = same ? 0.0 : tv;
+                                    tv = vs[u] ? tv : 0.0;
+                                    if (cc[u] < RS) trow[cc[u]] = tv;
+                                }
+                            }
+                            atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs);
+                            if (Q0) { atomicAdd((unsigned long long*)&r_np1[sidr], (unsigned long long)np1); atomicAdd((unsigned long long*)&r_np2[sidr], (unsigned long long)np2); }
+                        }
+                        __syncthreads();
+                        if (lane < ns) {
+                            const uint32_t sidf = live_id[l0 + lane];
+                            double d = t == 0 ? 0.0 : r_fd[sidf];
+                            const double2* row = (const double2*)(terms + lane * RS);
+                            for (uint32_t c8 = 0; c8 < RS; c8 += 8u) {
+                                const double2 t0 = row[0], t1 = row[1], t2 = row[2], t3 = row[3];
+                                row += 4;
+                                d += t0.x; d += t0.y; d += t1.x; d += t1.y; d += t2.x; d += t2.y; d += t3.x; d += t3.y;
+                            }
+                            r_fd[sidf] = d;
+                        }
+                        __syncthreads();
+                    }
+                }
+            } else if constexpr (!CODES) {
                 uint32_t Gs = 1, lgGs = 0;
                 while (Gs < 16 && nlive * (Gs * 2) <= 64) { Gs *= 2; ++lgGs; }
                 const uint32_t per = 64u >> lgGs;                   // slabs per pass

@@ -431,7 +431,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.state_bytes = (uint64_t)LM * span_max * p * A * 8;
         // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
         q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + fl::SLAB_DUMMY_WORDS + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + the dummy words of beam_slab_kernel's branch-free tails
-        const bool arith_slab = K.arith && !any_q0 && K.beam_path != 1;      // the reference's running sums on the shared slabs (beam_slab_kernel<.., ARITH = true>)
+        const bool arith_slab = K.arith && K.beam_path != 1;      // the reference's running sums on the shared slabs (beam_slab_kernel<.., ARITH = true>)
         q.SL = fl::slab_lds_layout(LM, p, any_q0, arith_slab);
         q.WL = fl::wide_lds_layout(LM, p, any_q0);
         q.LY = fl::beam_lds_layout(LM);
@@ -608,7 +608,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
             if (K.arith && q.slab) {
                 const bool sp = a.stop_at != nullptr || wait_tried != 0;
                 auto L = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(slots), dim3(64), q.SL.total, st, a); };
-                if (q.beam_spec && p == 2) { if (sp) L(fl::beam_slab_kernel<2, false, 2, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 2, 10, false, true>); }
+                if (any_q0) { if (sp) L(fl::beam_slab_kernel<A, true, 0, 0, true, true>); else L(fl::beam_slab_kernel<A, true, 0, 0, false, true>); }
+                else if (q.beam_spec && p == 2) { if (sp) L(fl::beam_slab_kernel<2, false, 2, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 2, 10, false, true>); }
                 else if (q.beam_spec && p == 3) { if (sp) L(fl::beam_slab_kernel<2, false, 3, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 3, 10, false, true>); }
                 else if (q.beam_spec && p == 4) { if (sp) L(fl::beam_slab_kernel<2, false, 4, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 4, 10, false, true>); }
                 else if (q.beam_spec && p == 5) { if (sp) L(fl::beam_slab_kernel<2, false, 5, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 5, 10, false, true>); }
