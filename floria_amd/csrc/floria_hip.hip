@@ -1654,8 +1654,12 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
     // 58.7 / 68 / 82 ms with two groups — two groups win from there: 2000 contigs 96.4 against 99.4 ms.  End of round 4 (profiles/r04_groups_ab.txt), ms per
     // step with 1 / 2 / 3 / 4 groups: 7 249 blocks 51.6 / 55.2 / 51.4 / -, 10 875 blocks 67.8 / 66.7 / 65.3 / -, 14 503 blocks 81.6 / 78.8 / 75.9 or 79.3 / 78.4-79.1:
     // three groups are 3.7 % faster in five runs of seven and level in the other two (the three chains interleave in one of two patterns); the pipelined call,
-    // which has its own three chunk groups, does not change, and every launch shares the chip three ways, so the default stays at two)
-    uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 48 ? 2 : 1);
+    // which has its own three chunk groups, does not change.  Round 5 (profiles/r05_groups_ab.txt; box A, three interleaved runs): 2 groups 79.5 / 79.6 / 80.2,
+    // 3 groups 77.3 / 76.1 / 77.2, 4 groups with half-size grids 78.9 / 79.3 / 79.2, an equal share of the wave slots per group (3 x 1 366) 81.8-82.2; box B, in the
+    // default bench flow and resident-only: 2 groups 79.9-80.3 (six runs), 3 groups 80.3 / 80.7 / 79.8 / 79.8 / 77.5 / 78.3; 1500 contigs 64.5 against 67.8 (2) and
+    // 68.6 (1).  Three groups land on the level of two or 3 % below it, never above by more than the noise -> three from 40 x CUs blocks on (round 4 kept two for
+    // the per-launch roofline fraction, which is not what a step costs).  Unequal groups (dealing weights 10:8:6 .. 14:8:2) do not pin the good pattern (78.4-80.9).
+    uint32_t G = ctx->knobs.groups ? ctx->knobs.groups : (jobs.size() >= (size_t)ctx->n_cu * 40 ? 3 : 1);
     G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, floria_hip_ctx::MAX_GROUPS), (uint32_t)(jobs.size() / 1024)));
     if (ctx->hw_queues < 5 && !ctx->knobs.groups) G = std::min<uint32_t>(G, 2);
     // chunked: consecutive chunks may share a job group (SC.chunk_groups), which then starts when its LAST chunk has landed
