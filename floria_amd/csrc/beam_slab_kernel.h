@@ -72,13 +72,17 @@ constexpr int SLAB_NS_MAX = 512;
 constexpr int SLAB_PAD_IDX = 64;     // dummy position indices behind a slot's slabs (narrow-sum layout)
 constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
 constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
-// ARITH instances (the reference's running f64 sums, below): the distance terms of a step wait in LDS for the sequential folds — SLAB_TERM_CAP f64 per wave —
-// so LDS allows two waves per SIMD at most and the register budget is that of two
+// ARITH instances (the reference's running f64 sums, below): the distance terms of a step wait in LDS for the sequential folds — SLAB_TERM_CAP f64 per wave.
+// Measured on config 4 at eps 0.04 (scripts/arith_ab.sh, ms per call): 768 terms / two waves per SIMD 172.5-174.6, 512 / three 163.3-163.4, 384 / three 168.1-168.2,
+// 768 / three 167.2-167.4 -> 512 terms (five slabs of a 92-cell read per pass) and the register budget of three waves
 #ifndef FLORIA_TERM_CAP
-#define FLORIA_TERM_CAP 768
+#define FLORIA_TERM_CAP 512
 #endif
 constexpr int SLAB_TERM_CAP = FLORIA_TERM_CAP;
-constexpr int SLAB_WAVES_ARITH = 2;
+#ifndef FLORIA_ARITH_BEAM_WAVES
+#define FLORIA_ARITH_BEAM_WAVES 3
+#endif
+constexpr int SLAB_WAVES_ARITH = FLORIA_ARITH_BEAM_WAVES;
 template <int N> struct IC { static constexpr int value = N; };
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) { if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); } }
 // value of lane (segment base + J) for aligned segments of PS = 2 or 4 lanes: one DPP quad_perm move, no LDS crossbar round trip
