@@ -42,3 +42,8 @@ def test_two_ranks_on_one_gpu_report_the_whole_job():
     assert d2["config"]["contigs_this_rank"] == 32                                      # the LPT queue deals equal-cost contigs evenly
     assert d2["config"]["total_blocks"] == d1["config"]["total_blocks"]                 # the SUM over ranks is the whole job
     assert d2["value"] > 0 and d2["ms_per_step"] > 0 and d2["metric"] == d1["metric"]
+    # every rank's own time and share (round 5: a scaling curve is only readable with them): two entries, the blocks add up, MAX >= mean
+    pr = d2["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and sum(pr["blocks"]) == d2["config"]["total_blocks"] and pr["max_over_mean"] >= 1.0
+    assert abs(max(pr["ms_per_step"]) - d2["ms_per_step"]) < 0.25 * d2["ms_per_step"] and "per_rank" not in d1
+    assert d2["value_is"] == "resident" and d2["value_h2d_inclusive"] > 0
