@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the FLORIA_HIP_GROUP_SKEW knob this script drives was measured and removed (profiles/r05_groups_ab.txt); the script is kept as the record of how it was measured.
 # (GPU) three job groups of unequal size (FLORIA_HIP_GROUP_SKEW): does breaking the symmetry pin one interleaving?  resident ms per step, the FULL default bench flow (H2D pass first)
 REPS=${1:-4}
 for rep in $(seq 1 $REPS); do

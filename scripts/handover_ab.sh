@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the FLORIA_HIP_HANDOVER knob this script drives was measured, rejected and removed (profiles/r05_handover_ab.txt); the script is kept as the record of how it was measured.
 # (GPU) job groups x handover (FLORIA_HIP_HANDOVER: the groups' beam launches of a stage hand the chip over instead of racing for it): resident ms per step, REPS runs each, interleaved
 REPS=${1:-4}
 for rep in $(seq 1 $REPS); do
