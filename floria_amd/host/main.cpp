@@ -39,7 +39,30 @@ namespace {
 
 void usage() {
     fputs("floria-hip - strain phasing for short or long-read shotgun metagenomic sequencing (MI355X build of floria's phasing path).\n\n"
-          "Example usage :\nfloria-hip -b bamfile.bam -v vcffile.vcf -r reference.fa -o results -t 10\n", stderr);
+          "Example usage :\nfloria-hip -b bamfile.bam -v vcffile.vcf -r reference.fa -o results -t 10\n\n"
+          "floria's options, same meaning:\n"
+          "  -b FILE  sorted BAM            -v FILE  VCF (plain / gz / bgz) or BCF with the SNPs     -r FILE  reference fasta\n"
+          "  -o DIR   output directory [floria_out_dir]       --overwrite   reuse an existing one    -t N  host threads [10]\n"
+          "  -e X     allele error rate epsilon [estimated]   -l N  block length in bases [estimated]   -d X  SNP density filter [0.0005]\n"
+          "  -n N     beam solutions [10]    -p N  maximum ploidy [5; this build: 1..16]    -s 1|2|3  ploidy sensitivity [2]    --no-stop-heuristic\n"
+          "  -m N     MAPQ cutoff [15]       -G / --contigs NAME..  only these contigs      --snp-count-filter N [100]\n"
+          "  -X / --no-supp  ignore supplementary alignments      --supp-aln-dist-cutoff N [40000]      --ignore-monomorphic\n"
+          "  --output-reads [--gzip-reads] [--extra-trimming]     --debug / --trace\n"
+          "this build's own:\n"
+          "  --device N | --devices 0-7 | 0,2,5   GPU(s); contigs of a batch are dealt to them, files do not depend on it\n"
+          "  --batch-contigs N [4096]  --batch-cells N [2^28]   contigs taken through the device stages together\n"
+          "  --bam-window-mb N [512]   inflated BAM records held in memory at a time\n"
+          "  --arith auto|reference|canonical   how sums of epsilon terms are rounded when -e is not a multiple of 2^-10: 'reference' = floria's running f64 sums\n"
+          "                 in its hash containers' iteration order (as far as that order can be emulated), 'canonical' = every sum rounded once; auto [default] =\n"
+          "                 reference, except for batches with fragments merged from mates / supplementary alignments or under --ignore-monomorphic\n"
+          "  --epsilon-round   round an ESTIMATED -e to a multiple of 2^-10 (there both arithmetics are the same function)\n"
+          "  --lp-tie first|last, --lp-report   which optimal vertex of the stitching LP is used where the optimum is not unique, and how often that is\n"
+          "  --no-realign      skip the re-alignment of the reads' bases around SNPs\n"
+          "where this build is not floria (DESIGN.md sections 6 and 7):\n"
+          "  * re-alignment around SNPs is the EXACT affine-gap alignment of the 32-base windows; floria's block-aligner is a banded heuristic of it (calls can differ)\n"
+          "  * the stitching LP is solved exactly as a min-cost flow: the same optimal value as floria's simplex, possibly another optimal vertex (short reads: haplosets can differ)\n"
+          "  * hash-set iteration orders decide ties in floria (visiting order of the final reassignment, the read dropped at a haplogroup split): here ascending read order\n"
+          "  * not supported: -H / --hybrid, --reassign-short, --bin-by-cov (hidden or beta in floria)\n", stderr);
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
