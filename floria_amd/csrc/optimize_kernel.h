@@ -157,6 +157,7 @@ void optimize_kernel(OptArgs g) {
     __shared__ double s_errf[MAX_PLOIDY];            // ARITH: running `errors` of every partition
     __shared__ uint32_t s_cntk[MAX_PLOIDY + 1];      // ARITH: positions in every partition's map
     __shared__ uint32_t s_cnt2[2][MAX_PLOIDY];       // ... of the two position lists
+    __shared__ uint32_t s_bpar[MAX_PLOIDY], s_tpar[MAX_PLOIDY], s_keep[MAX_PLOIDY];      // ARITH: which of its two lists holds partition k's ACCEPTED order / the order of the partition being scored; keys unchanged
     uint32_t* s_moved = (uint32_t*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -370,8 +371,11 @@ void optimize_kernel(OptArgs g) {
         // par = which list is written (reuse = false) or walked again (reuse = true).
         // (always_inline: called from three places, hipcc would otherwise make it a real function whose captures — every local it touches — live in scratch memory:
         // 1 KB of scratch per lane, 149 VGPRs and one workgroup per CU, measured)
-        auto mec_stats_arith = [&](bool phred, uint32_t par, bool reuse, bool with_dist, bool dist_inc) __attribute__((always_inline)) {
-            uint32_t* const olist = g.ol_pool + ((uint64_t)blockIdx.x * 2 + par) * g.span_max * p;          // [partition][span_max]
+        // first = the job's first call (nothing to compare with); reuse = walk the accepted lists again, nothing else.
+        auto mec_stats_arith = [&](bool phred, bool first, bool reuse, bool with_dist, bool dist_inc) __attribute__((always_inline)) {
+            auto olist_of = [&](uint32_t par, uint32_t k) { return g.ol_pool + (((uint64_t)blockIdx.x * 2 + par) * p + k) * g.span_max; };          // [slot][parity][partition][span_max]
+            uint32_t* const kprev = (uint32_t*)(g.fk_pool + (uint64_t)blockIdx.x * g.span_max * p);      // [parity][partition][span_max] the first-insertion keys behind every list (the u64 key pool, unused while the keys are 32-bit words in LDS)
+            auto kprev_of = [&](uint32_t par, uint32_t k) { return kprev + ((uint64_t)par * p + k) * g.span_max; };
             const uint64_t one = phred ? ONE_Q24 : 1ull;
             const double scale = phred ? 0x1p-24 : 1.0;
             // the terms of 64 listed positions (lane = entry; `have` = this lane holds one), added in lane order onto ef; returns the lanes' consensus counts
@@ -403,12 +407,13 @@ void optimize_kernel(OptArgs g) {
             };
             if (reuse) {
                 for (uint32_t k = wid; k < p; k += OPT_THREADS / 64) {
-                    const uint32_t D = s_cnt2[par][k];
+                    const uint32_t par = s_bpar[k], D = s_cnt2[par][k];
+                    const uint32_t* const olist = olist_of(par, k);
                     double ef = 0.0;
                     uint64_t good = 0;
                     for (uint32_t d0 = 0; d0 < D; d0 += 64) {
                         const bool have = d0 + lane < D;
-                        const uint32_t posrel = have ? olist[(uint64_t)k * g.span_max + d0 + lane] : 0u;
+                        const uint32_t posrel = have ? olist[d0 + lane] : 0u;
                         good += fold64(k, posrel, have, ef);
                     }
                     good = wave_sum_u64(good);
@@ -476,6 +481,29 @@ void optimize_kernel(OptArgs g) {
             // counting — key e's rank = the number of smaller keys, every key read by all lanes at once — and writes the positions back IN PLACE in that order
             // (a wave's LDS operations execute in order: every read of the row precedes the first write).  No workgroup-wide sort, no barrier.
             const bool wave_sort = k32 && span <= 1024u;
+            // (1b) A batch of moves rarely changes WHO inserts a position first (only where a moved read was, or becomes, the lowest-numbered read of its partition at a
+            // position: the frontier and the gaps), and the map's layout is a function of the first-insertion keys alone: a partition whose keys equal those behind its
+            // accepted list keeps that list - no sort, no replay, only the walk with the new counts.  Compared exactly, key by key, against the copy in HBM scratch.
+            if (tid < p) { s_keep[tid] = (wave_sort && !first) ? 1u : 0u; }
+            __syncthreads();
+            if (wave_sort && !first) {
+                for (uint32_t k = 0; k < p; ++k) {
+                    const uint32_t* const prev = kprev_of(s_bpar[k], k);
+                    bool differs = false;
+                    for (uint32_t pr = tid; pr < span; pr += OPT_THREADS) differs |= fk32[k * span + pr] != prev[pr];
+                    if (differs) s_keep[k] = 0u;
+                }
+                __syncthreads();
+            }
+            if (tid < p) s_tpar[tid] = first ? 0u : (s_keep[tid] ? s_bpar[tid] : s_bpar[tid] ^ 1u);
+            __syncthreads();
+            if (wave_sort)
+                for (uint32_t k = 0; k < p; ++k) {
+                    if (s_keep[k]) continue;
+                    uint32_t* const dst = kprev_of(s_tpar[k], k);
+                    for (uint32_t pr = tid; pr < span; pr += OPT_THREADS) dst[pr] = fk32[k * span + pr];
+                }
+            __syncthreads();          // (the rows are sorted in place below)
             if (!wave_sort) {
             for (uint32_t x = tid; x < M2; x += OPT_THREADS) {
                 uint64_t f = ~0ull;
@@ -491,6 +519,21 @@ void optimize_kernel(OptArgs g) {
             }
             OPT_TICK(11);    // (ARITH) sort
             for (uint32_t k = wid; k < p; k += OPT_THREADS / 64) {            // a wavefront per partition: the table is driven by all 64 lanes (arith_kernel.h: FxWave)
+                const uint32_t par = s_tpar[k];
+                uint32_t* const olist = olist_of(par, k);
+                if (s_keep[k]) {                                             // the accepted order stands: walk its list with the new counts
+                    const uint32_t Dk = s_cnt2[par][k];
+                    double ef = 0.0;
+                    uint64_t good = 0;
+                    for (uint32_t d0 = 0; d0 < Dk; d0 += 64) {
+                        const bool have = d0 + lane < Dk;
+                        const uint32_t posrel = have ? olist[d0 + lane] : 0u;
+                        good += fold64(k, posrel, have, ef);
+                    }
+                    good = wave_sum_u64(good);
+                    if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
+                    continue;
+                }
                 uint32_t start = 0, D = 0;
                 uint32_t* const row = fk32 + k * span;
                 if (wave_sort) {
@@ -547,7 +590,7 @@ void optimize_kernel(OptArgs g) {
                     const uint32_t key = t.slot[in ? i0 + lane : 0];
                     const uint32_t posrel = full ? key - pos0 : 0u;
                     const uint64_t fm = __ballot(full);
-                    if (full) olist[(uint64_t)k * g.span_max + written + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = posrel;
+                    if (full) olist[written + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = posrel;
                     written += (uint32_t)__popcll(fm);
                     good += fold64(k, posrel, full, ef);
                 }
@@ -566,15 +609,17 @@ void optimize_kernel(OptArgs g) {
             }
             __syncthreads();
         };
-        uint32_t best_par = 0;                                 // ARITH: the list of the accepted partition
-        auto stats = [&](bool phred, uint32_t par, bool reuse, bool with_dist = false, bool dist_inc = false) __attribute__((always_inline)) { if constexpr (ARITH) mec_stats_arith(phred, par, reuse, with_dist, dist_inc); else mec_stats(phred); };
+        auto stats = [&](bool phred, bool first, bool reuse, bool with_dist = false, bool dist_inc = false) __attribute__((always_inline)) { if constexpr (ARITH) mec_stats_arith(phred, first, reuse, with_dist, dist_inc); else mec_stats(phred); };
+        // ARITH: the lists of the partition just scored become the accepted ones
+        auto accept_lists = [&]() __attribute__((always_inline)) { if constexpr (ARITH) { __syncthreads(); if ((uint32_t)tid < p) s_bpar[tid] = s_tpar[tid]; __syncthreads(); } };
 
         refresh_codes(false);
         OPT_TICK(0);     // build
         bool not_empty = n > 0;                                 // :76-85 (a job always has reads)
         uint32_t iters_done = 0;
         if (not_empty) {
-            stats(true, 0, false, p > 1, false);
+            stats(true, true, false, p > 1, false);
+            accept_lists();
             OPT_TICK(1);     // first stats
             double prev_score = s_score;
             for (int it = 0; it < NUM_ITER_OPTIMIZE; ++it) {   // :105-127
@@ -717,10 +762,10 @@ void optimize_kernel(OptArgs g) {
                 };
                 apply_moves(false);
                 OPT_TICK(6);     // moves
-                stats(true, best_par ^ 1u, false, true, HL && meta && span <= 65535u);
+                stats(true, false, false, true, HL && meta && span <= 65535u);
                 OPT_TICK(7);     // round stats
                 const double new_score = s_score;
-                if (new_score > prev_score) { prev_score = new_score; best_par ^= 1u; }
+                if (new_score > prev_score) { prev_score = new_score; accept_lists(); }
                 else {                                   // rejected: keep best_part / prev_hap_block
                     apply_moves(true);
                     if (tid == 0) for (uint32_t x = 0; x < nm; ++x) { const uint32_t mvv = moves[x]; s_size[(mvv >> 4) & 15] += 1; s_size[mvv & 15] -= 1; }
@@ -731,7 +776,7 @@ void optimize_kernel(OptArgs g) {
         }
         // ---- get_mec_stats_epsilon_no_phred of the optimised partition (graph_processing.rs:156-162) -----------
         OPT_TICK(8);
-        stats(false, best_par, true);          // (ARITH: the accepted partition's position maps were replayed by the statistics call that accepted it)
+        stats(false, false, true);          // (ARITH: the accepted partition's position maps were replayed by the statistics call that accepted it)
         OPT_TICK(62);    // final stats (slot 62: slots 9-15 also hold the beam kernels' step counters, which made this phase look like 2.7 Gcycles in earlier profiles)
         if (tid == 0) {
             double mecv = 0.0, na = 0.0;
