@@ -150,7 +150,7 @@ void optimize_kernel(OptArgs g) {
     __shared__ uint64_t s_errq[MAX_PLOIDY], s_goodq[MAX_PLOIDY];
     __shared__ uint32_t s_errm[MAX_PLOIDY];
     __shared__ uint32_t s_size[MAX_PLOIDY];
-    __shared__ uint32_t s_ncand, s_nmoves, s_job, s_skip;
+    __shared__ uint32_t s_ncand, s_nmoves, s_job, s_skip, s_dq;
     __shared__ uint32_t s_chg_lo, s_chg_hi;          // positions whose code byte changed in the last batch of moves (HL)
     __shared__ uint32_t s_bkt[OPT_BUCKETS];          // visiting order: reads per bucket of ceil(#cells / 64), then the buckets' write cursors
     __shared__ double s_score;
@@ -313,15 +313,24 @@ void optimize_kernel(OptArgs g) {
         // t0 + 1, .. of nt.  They depend on the histogram only, so the pass for round r + 1 runs on the wavefronts that have no position map to replay while
         // the statistics of round r are computed (a rejected round r makes them useless, and is the last).  inc: only the reads that reach into the interval of
         // positions whose code byte changed in the last batch of moves.
-        auto dist_arith = [&](uint32_t t0, uint32_t nt, bool inc) __attribute__((always_inline)) {
+        // The pairs are handed out 64 at a time from a counter in LDS (s_dq, zeroed behind a barrier before the pass): the wavefronts that replay a position map join
+        // when they are done, so everybody ends together.
+        auto dist_arith = [&](bool inc) __attribute__((always_inline)) {
             const uint32_t chg_lo = inc ? s_chg_lo : 0u, chg_hi = inc ? s_chg_hi : 0xffffffffu;
             // (measured: a thread per read folding up to four partitions at once - the cells loaded once for all of them - is slower, 274 against 250 ms per call: half as many
             // threads have work)
-            for (uint32_t pair = t0; pair < n * p; pair += nt) {
-                const uint32_t i = pair / p, k = pair - i * p;
+            for (;;) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_dq, 64u);
+                base = (uint32_t)__shfl((int)base, 0);
+                if (base >= n * p) break;
+                const uint32_t pair = base + (uint32_t)lane;
+                bool act = pair < n * p;                                 // (no `continue` out of the body: every lane is back at the counter together)
+                const uint32_t i = act ? pair / p : 0u, k = pair - i * p;
                 uint32_t cb = 0, len = 0, kk = 0;
                 read_meta(i, cb, len, kk);
-                if (inc) { const uint32_t fl = m_fl[i]; if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) continue; }      // no code changed at any position of this read: its distances stand
+                if (inc) { const uint32_t fl = m_fl[i]; if ((fl >> 16) < chg_lo || (fl & 0xffffu) > chg_hi) act = false; }      // no code changed at any position of this read: its distances stand
+                if (!act) len = 0;
                 double df = 0.0;
                 constexpr int DU = HL ? 8 : 4;                           // cells per batch: order entries, cells and histogram rows / code bytes requested together
                 for (uint32_t c0 = 0; c0 < len; c0 += DU) {
@@ -357,7 +366,7 @@ void optimize_kernel(OptArgs g) {
                         else if (va != mx) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;
                     }
                 }
-                dist[pair] = df;
+                if (act) dist[pair] = df;
             }
         };
         // ARITH: the same statistics with `errors` as the reference's running sum.  The position map of partition k is filled by its reads in ascending
@@ -435,6 +444,7 @@ void optimize_kernel(OptArgs g) {
             if (k32) for (uint32_t x = tid; x < M; x += OPT_THREADS) fk32[x] = ~0u;
             else for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
             if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; }
+            if (tid == 0) s_dq = 0;
             if (g.fx_lds_off) for (uint32_t x = tid; x < p * FX_TAGS; x += OPT_THREADS) ((uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl))[x] = 0xffffffffu;
             __syncthreads();
             OPT_TICK(14);    // (ARITH) key table cleared
@@ -598,9 +608,8 @@ void optimize_kernel(OptArgs g) {
                 if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = D; }
             }
             // the next round's distances on the wavefronts without a map to replay (dist_arith); with as many partitions as wavefronts, by everybody afterwards
-            if (with_dist && (uint32_t)(OPT_THREADS / 64) > p && wid >= p) dist_arith(tid - 64u * p, OPT_THREADS - 64u * p, dist_inc);
+            if (with_dist) dist_arith(dist_inc);          // (the wavefronts without a map start here at once, the others when their replay and walk are done)
             __syncthreads();
-            if (with_dist && (uint32_t)(OPT_THREADS / 64) <= p) { dist_arith(tid, OPT_THREADS, dist_inc); __syncthreads(); }
             OPT_TICK(12);    // (ARITH) replay + walk, slowest partition
             if (tid == 0 && phred) {
                 double sc = 0.0;
