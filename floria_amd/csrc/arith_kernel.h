@@ -28,7 +28,7 @@ __host__ __device__ inline uint32_t fx_buckets_for(uint32_t cap) {
 // which every probe reads, can sit in LDS while the keys stay in HBM scratch
 // (+16: FxWave::probe16 reads the group at an unaligned position as five aligned words)
 __host__ __device__ inline size_t fx_ctrl_bytes(uint32_t cap) { return (((size_t)fx_buckets_for(cap < 1 ? 1 : cap) + FX_W + 15) & ~(size_t)15) + 16; }
-constexpr uint32_t FX_TAGS = 128;                    // FxWave::insert_batch: words of the conflict-detection table
+constexpr uint32_t FX_TAGS_MIN = 128, FX_TAGS_MAX = 1024;      // FxWave::insert_batch: words of the conflict-detection table (the host takes the largest that costs no workgroup per CU)
 __host__ __device__ inline size_t fx_slot_bytes(uint32_t cap) { return 4ull * fx_buckets_for(cap < 1 ? 1 : cap); }
 
 struct FxTable {
@@ -103,6 +103,7 @@ struct FxWave {
     uint8_t*  ctrl = nullptr;
     uint32_t* slot = nullptr;
     uint32_t  buckets = 0, items = 0, growth_left = 0;
+    uint32_t  tag_mask = FX_TAGS_MIN - 1;      // insert_batch: the claim of bucket b is word b & tag_mask (two buckets on one word are a false conflict: a shorter round, not a wrong one)
     bool      hbm = false;           // the control bytes are in HBM scratch, not LDS: one lane's stores are fenced before other lanes' loads of the next probe
 
     __device__ void bind(uint8_t* c, uint32_t* s, uint32_t nb, uint32_t lane) {
@@ -215,7 +216,7 @@ struct FxWave {
         }
     }
     // keys of the lanes with `valid`, in the order of their ranks r = 0..cnt-1 (ascending with the lane); grow = may this table grow (false inside a resize).
-    // tag: FX_TAGS LDS words, all ones between calls.
+    // tag: tag_mask + 1 LDS words, all ones between calls.
     // (GROW is a template parameter so that the re-insertion inside a resize is not a recursive call: the whole thing inlines, no stack frame)
     template <bool GROW>
     __device__ __forceinline__ void insert_batch(uint32_t key, bool valid, uint32_t r, uint32_t cnt, uint32_t* tag, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
@@ -232,7 +233,7 @@ struct FxWave {
             const uint32_t lim = cnt < done + growth_left ? cnt : done + growth_left;
             const bool act = valid && r >= done && r < lim;
             const uint32_t target = act ? probe16(h) : 0u;
-            const uint32_t tg = target & (FX_TAGS - 1u);
+            const uint32_t tg = target & tag_mask;
             __attribute__((address_space(3))) uint32_t* const tp = (__attribute__((address_space(3))) uint32_t*)tag + tg;
             if (act) (void)__hip_atomic_fetch_min(tp, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t won = act ? __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : r;
@@ -253,8 +254,9 @@ struct FxWave {
     __device__ __forceinline__ void grow_batched(uint32_t* tag, uint8_t*& spare_c, uint32_t*& spare_s, uint32_t lane) {
         const uint32_t full_cap = fx_cap_of(buckets), want = items + 1 > full_cap + 1 ? items + 1 : full_cap + 1;
         FxWave n;
+        n.tag_mask = tag_mask;
         n.bind_lds(spare_c, spare_s, fx_buckets_for(want), lane);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");               // the keys (HBM scratch) were stored by other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");           // the keys (HBM scratch) were stored by other lanes of this wave: same CU, same L1 — waiting for the stores is all it takes (an agent-scope fence writes the XCD's L2 back, for everybody)
         for (uint32_t i0 = 0; i0 < buckets; i0 += 64) {
             const bool in = i0 + lane < buckets;
             const uint32_t c = in ? ((const __attribute__((address_space(3))) uint8_t*)ctrl)[i0 + lane] : 0xffu;

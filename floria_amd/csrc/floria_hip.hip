@@ -167,6 +167,8 @@ struct Knobs {
     uint32_t spec_gate_div = 2;   // speculative stages: grid of the gated (ploidy >= 4) beam launches = slots / this
     uint32_t reassign_path = 0;   // S2 kernel: 0 auto | 1 workgroup-parallel | 2 one-wavefront chain
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
+    uint32_t fx_tags = 0;         // (A/B) reference arithmetic: cap on the words of a position map's claim table (0 = as many as cost no workgroup per CU)
+    uint32_t arith_ow6 = 0;       // (A/B) ... the optimise kernel compiled for six waves per SIMD at every ploidy
     uint32_t arith_hbm = 0;       // (tests) reference arithmetic: position-map tables and first-insertion keys in HBM scratch even where they fit into LDS
     uint32_t opt_block_order = 0; // (A/B, tests) optimise: the build / distance passes visit the reads in block order instead of longest first
     uint32_t s2_assign_only = 0;  // S2 returns the haplogroups as re-inserted (input order): separate_broken_haplogroups and sort_parts are left to a host that iterates its own sets
@@ -391,6 +393,7 @@ struct PloidyPlan {
     bool hl = false, opt_spec = false;
     uint32_t pm_lds_off = 0;      // optimise: where the visiting order of the reads (u16, longest first) sits in the workgroup's LDS (0 = none: the reads in block order)
     uint32_t fk_lds_off = 0;      // ... and the first-insertion keys as 32-bit words
+    uint32_t fx_tags = 0;         // ... and the words of a map's claim table
     uint32_t fx_lds_off = 0;      // reference-arithmetic mode: where the emulated position maps sit in the workgroup's LDS (0 = in HBM scratch)
 };
 
@@ -481,14 +484,29 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.hl = hist_bytes + (size_t)span_max * p + 32 + moved_bytes + meta_bytes <= 60 * 1024 && !K.opt_global;
         const size_t code_bytes = q.hl ? ((size_t)span_max * p + 15) & ~(size_t)15 : 0;       // one byte per (position, partition), see optimize_kernel.h
         q.opt_lds = moved_bytes + meta_bytes + (q.hl ? ((hist_bytes + 15) & ~(size_t)15) + code_bytes : 0);
-        if (K.arith && !K.arith_hbm && q.opt_lds + (size_t)p * (2 * fx_ctrl + 4 * fl::FX_TAGS) + 16 <= 60 * 1024) { q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += (size_t)p * (2 * fx_ctrl + 4 * fl::FX_TAGS); }      // (the control bytes, which every probe reads)
-        if (K.arith && !K.arith_hbm && n_max < (1u << 20) && ctx->cur_len_max < 4096u && q.opt_lds + (size_t)p * span_max * 4 + 16 <= 60 * 1024) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += ((size_t)p * span_max * 4 + 15) & ~(size_t)15; }
-        q.opt_lds += 16;
         // where the ploidy-specialised instances apply (75-92 VGPRs), three 512-thread workgroups per CU beat one of 1024 threads
         if (A == 2 && q.hl && p <= 5 && threads == 1024 && !K.opt_threads && !K.no_specialized) threads = 512;
         q.threads = threads;
         q.opt_spec = A == 2 && q.hl && threads >= 512 && p <= 5 && !K.no_specialized && !K.arith;
         auto wg_per_cu = [&](size_t lds) { return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)((156 * 1024) / (lds + 8 * 1024)), 2048 / threads)); };
+        if (K.arith && !K.arith_hbm) {
+            // the emulated position maps: control bytes (which every probe reads) + the claim words of a batched insertion, and the first-insertion keys as 32-bit words, in
+            // LDS where that still leaves two workgroups per CU; the claim table as large as costs no workgroup (a table of fewer words than buckets makes false conflicts)
+            const size_t cap = 68 * 1024;
+            auto fx_sz = [&](uint32_t tags) { return (size_t)p * (2 * fx_ctrl + 4 * tags); };
+            const size_t fk_sz = ((size_t)p * span_max * 4 + 15) & ~(size_t)15;
+            const bool fk_ok = n_max < (1u << 20) && ctx->cur_len_max < 4096u;
+            uint32_t tags = fl::FX_TAGS_MIN;
+            if (q.opt_lds + fx_sz(tags) + 16 <= cap) {
+                const bool fk = fk_ok && q.opt_lds + fx_sz(tags) + fk_sz + 16 <= cap;
+                const size_t rest = q.opt_lds + (fk ? fk_sz : 0) + 16;
+                const uint32_t tmax = std::min<uint32_t>(fl::FX_TAGS_MAX, K.fx_tags ? K.fx_tags : fl::fx_buckets_for(span_max + 1));
+                while (tags * 2 <= tmax && rest + fx_sz(tags * 2) <= cap && wg_per_cu(rest + fx_sz(tags * 2)) == wg_per_cu(rest + fx_sz(fl::FX_TAGS_MIN))) tags *= 2;
+                q.fx_lds_off = (uint32_t)q.opt_lds; q.opt_lds += fx_sz(tags); q.fx_tags = tags;
+                if (fk) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += fk_sz; }
+            } else if (fk_ok && q.opt_lds + fk_sz + 16 <= cap) { q.fk_lds_off = (uint32_t)q.opt_lds; q.opt_lds += fk_sz; }
+        }
+        q.opt_lds += 16;
         {   // the visiting order of the build / distance passes (optimize_kernel.h: u16 per read), where it costs no workgroup per CU
             const size_t pm_bytes = (((size_t)n_max * 2) + 15) & ~(size_t)15;
             if (!K.arith && !K.opt_block_order && meta_bytes && n_max <= 65535u && q.opt_lds + pm_bytes <= 60 * 1024 && wg_per_cu(q.opt_lds + pm_bytes) == wg_per_cu(q.opt_lds)) {
@@ -706,7 +724,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     if (K.arith) {
                         a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
                         char* base = ctx->arith_pool.as<char>() + sl_arith * lane;
-                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off; a.fk_lds_off = q.fk_lds_off;
+                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off; a.fx_tags = q.fx_tags; a.fk_lds_off = q.fk_lds_off;
                         a.fk_pool = (uint64_t*)base; base += (uint64_t)slots * p * span_max * 8;
                         a.sk_pool = (uint64_t*)base; base += (uint64_t)slots * a.sort_cap * 8;
                         a.sp_pool = (uint32_t*)base; base += ((uint64_t)slots * a.sort_cap * 4 + 15) & ~(uint64_t)15;
@@ -721,7 +739,8 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         return hipGetLastError();
                     };
                     hipError_t le;
-                    if (K.arith && q.hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512, 0, true>) : launch(fl::optimize_kernel<A, true, 128, 0, true>);
+                    if (K.arith && q.hl && threads == 512 && std::min<size_t>((156 * 1024) / (lds + 8 * 1024), 2048 / threads) <= 2 && !K.arith_ow6) le = launch(fl::optimize_kernel<A, true, 512, 0, true, 4>);      // (LDS allows two workgroups per CU: four waves per SIMD, 128 VGPRs)
+                    else if (K.arith && q.hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512, 0, true>) : launch(fl::optimize_kernel<A, true, 128, 0, true>);
                     else if (K.arith) le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512, 0, true>) : launch(fl::optimize_kernel<A, false, 128, 0, true>);
                     else if (q.opt_spec && threads == 1024)
                         le = p == 1 ? launch(fl::optimize_kernel<2, true, 1024, 1>) : p == 2 ? launch(fl::optimize_kernel<2, true, 1024, 2>) : p == 3 ? launch(fl::optimize_kernel<2, true, 1024, 3>)
@@ -938,6 +957,8 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "tail_overlap") { if (value < -1 || value > 1) return fail(FLORIA_E_INVALID, "tail_overlap: 0 | 1"); K.tail_overlap = (int32_t)value; }
     else if (k == "tail_waves") K.tail_waves = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "arith_hbm") K.arith_hbm = value != 0;
+    else if (k == "fx_tags") { if (value != 0 && (value < (int64_t)fl::FX_TAGS_MIN || value > (int64_t)fl::FX_TAGS_MAX || (value & (value - 1)))) return fail(FLORIA_E_INVALID, "fx_tags: 0 | a power of two in 128..1024"); K.fx_tags = (uint32_t)value; }
+    else if (k == "arith_ow6") K.arith_ow6 = value != 0;
     else if (k == "s2_assign_only") K.s2_assign_only = value != 0;
     else if (k == "arith") { if (value < 0 || value > 1) return fail(FLORIA_E_INVALID, "arith: 0 canonical | 1 the reference's running sums"); K.arith = (uint32_t)value; }
     else if (k == "hw_queues") ctx->hw_queues = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));      // (tests: pretend the probe found this many)

@@ -71,7 +71,8 @@ struct OptArgs {
     uint8_t*  fx_pool;           // [slots][ploidy][2][fx_ctrl + fx_slot] the emulated position maps: control bytes, keys
     uint32_t* ol_pool;           // [slots][2][ploidy][span_max] every partition's positions (block-relative) in the bucket order of its map, two parities
     uint64_t  sort_cap, fx_ctrl, fx_slot;
-    uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl], then [ploidy][FX_TAGS] words)
+    uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl], then [ploidy][fx_tags] words)
+    uint32_t  fx_tags;           // words of a map's conflict-detection table (a power of two, FX_TAGS_MIN..FX_TAGS_MAX)
     uint32_t  pm_lds_off;        // != 0: the visiting order of the build and distance passes (u16 read indices, longest reads first) in LDS at this offset ([n_max])
     uint32_t  fk_lds_off;        // != 0: the first-insertion keys as 32-bit words (read << 12 | cell rank: reads < 2^20, cells per read < 2^12) in LDS at this offset ([ploidy*span_max])
 };
@@ -140,9 +141,10 @@ __device__ inline void bitonic_sort(G gain, K key, uint32_t n, int tid, int nthr
 #ifndef FLORIA_ARITH_OPT_WAVES
 #define FLORIA_ARITH_OPT_WAVES 6
 #endif
-constexpr int opt_min_waves(int tp, int threads, bool arith) { return arith ? (threads == 512 ? FLORIA_ARITH_OPT_WAVES : 1) : ((threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1); }      // (ARITH, 512 threads: 80 VGPRs = three workgroups per CU; the 149 hipcc takes when left alone leave one.  Measured on config 4, arith = 1: 4 / 5 / 6 waves 177 / 175 / 171 ms)
-template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false>
-__global__ __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(opt_min_waves(TP, OPT_THREADS, ARITH))))
+constexpr int opt_min_waves(int tp, int threads, bool arith, int ow = 0) { return arith ? (threads == 512 ? (ow ? ow : FLORIA_ARITH_OPT_WAVES) : 1) : ((threads == 512 && tp >= 1 && tp <= 3) ? 6 : 1); }      // (ARITH, 512 threads: 80 VGPRs = three workgroups per CU; the 149 hipcc takes when left alone leave one.  Measured on config 4, arith = 1: 4 / 5 / 6 waves 177 / 175 / 171 ms)
+// OW (ARITH): waves per SIMD to compile for, 0 = the default above (where LDS allows two workgroups per CU anyway — ploidy >= 3 on config 4 — four waves' worth of registers)
+template <int A, bool HL, int OPT_THREADS, int TP = 0, bool ARITH = false, int OW = 0>
+__global__ __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(opt_min_waves(TP, OPT_THREADS, ARITH, OW))))
 void optimize_kernel(OptArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];   // moved bitset [n_max/8 rounded] | histogram (HL)
     __shared__ uint64_t s_gain[OPT_SORT_LDS];
@@ -445,7 +447,7 @@ void optimize_kernel(OptArgs g) {
             else for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
             if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; }
             if (tid == 0) s_dq = 0;
-            if (g.fx_lds_off) for (uint32_t x = tid; x < p * FX_TAGS; x += OPT_THREADS) ((uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl))[x] = 0xffffffffu;
+            if (g.fx_lds_off) for (uint32_t x = tid; x < p * g.fx_tags; x += OPT_THREADS) ((uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl))[x] = 0xffffffffu;
             __syncthreads();
             OPT_TICK(14);    // (ARITH) key table cleared
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
@@ -576,9 +578,9 @@ void optimize_kernel(OptArgs g) {
                 uint8_t* c0 = g.fx_lds_off ? smem + g.fx_lds_off + (uint64_t)k * 2 * g.fx_ctrl : gmem;
                 uint8_t* spare_c = g.fx_lds_off ? c0 + g.fx_ctrl : gmem + fxb;
                 uint32_t* spare_s = (uint32_t*)(gmem + fxb + g.fx_ctrl);
-                uint32_t* const tag = (uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl) + k * FX_TAGS;        // (LDS tables only)
+                uint32_t* const tag = (uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl) + k * g.fx_tags;        // (LDS tables only)
                 FxWave t;
-                t.hbm = g.fx_lds_off == 0;
+                t.hbm = g.fx_lds_off == 0; t.tag_mask = g.fx_tags - 1u;
                 if (D) { if (g.fx_lds_off) t.bind_lds(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane); else t.bind(c0, (uint32_t*)(gmem + g.fx_ctrl), fx_buckets_for(1), lane); }
                 for (uint32_t d0 = 0; d0 < D; d0 += 64) {                    // 64 positions of the sorted first-insertion list at a time
                     const uint32_t mine = d0 + lane < D ? (wave_sort ? row[d0 + lane] : sp[start + d0 + lane] - k * span) + pos0 : 0u;
@@ -586,7 +588,7 @@ void optimize_kernel(OptArgs g) {
                     if (g.fx_lds_off) t.template insert_batch<true>(mine, lane < cnt, lane, cnt, tag, spare_c, spare_s, lane);
                     else for (uint32_t l = 0; l < cnt; ++l) t.insert_new((uint32_t)__shfl((int)mine, (int)l), spare_c, spare_s, lane);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");           // the keys (HBM scratch) were stored lane by lane; the walk reads them bucket by bucket
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // the keys (HBM scratch) were stored lane by lane; the walk reads them bucket by bucket
 #ifdef FLORIA_PROF
                 if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's replay
 #endif

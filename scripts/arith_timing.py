@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """(GPU) where the time of the reference-arithmetic mode goes: kernel-family sums of one resident S1 call, canonical against arith = 1.
-usage: scripts/arith_timing.py [contigs = 250] [epsilon = 0.04] [speculate = -1] [opt_threads = 0]"""
+usage: scripts/arith_timing.py [contigs = 250] [epsilon = 0.04] [speculate = -1] [opt_threads = 0] [knob=value ..]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -22,6 +22,9 @@ if len(sys.argv) > 3:
     ctx.set_option("speculate", int(sys.argv[3]))
 if len(sys.argv) > 4:
     ctx.set_option("opt_threads", int(sys.argv[4]))
+for kv in sys.argv[5:]:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 for mode in (0, 1):
     ctx.set_option("arith", mode)
     ctx.phase_blocks_batch(hs, bc, bs, be, par, copy_out=False)
