@@ -28,6 +28,10 @@ __host__ __device__ inline uint32_t fx_buckets_for(uint32_t cap) {
 // which every probe reads, can sit in LDS while the keys stay in HBM scratch
 // (+16: FxWave::probe16 reads the group at an unaligned position as five aligned words)
 __host__ __device__ inline size_t fx_ctrl_bytes(uint32_t cap) { return (((size_t)fx_buckets_for(cap < 1 ? 1 : cap) + FX_W + 15) & ~(size_t)15) + 16; }
+// K^-1 mod 2^32 for the low word of FxHash's multiplier (Newton: x <- x * (2 - K x) doubles the correct bits): bucket b of a C-bucket table is the home of the keys = b * K^-1 mod C
+constexpr uint32_t fx_inv32(uint32_t k) { uint32_t x = k; for (int i = 0; i < 5; ++i) x *= 2u - k * x; return x; }
+constexpr uint32_t FX_KINV32 = fx_inv32(0x27220a95u);
+static_assert(FX_KINV32 * 0x27220a95u == 1u, "inverse of the hash multiplier");
 constexpr uint32_t FX_TAGS_MIN = 128, FX_TAGS_MAX = 1024;      // FxWave::insert_batch: words of the conflict-detection table (the host takes the largest that costs no workgroup per CU)
 __host__ __device__ inline size_t fx_slot_bytes(uint32_t cap) { return 4ull * fx_buckets_for(cap < 1 ? 1 : cap); }
 

@@ -169,6 +169,7 @@ struct Knobs {
     uint32_t no_bulk = 0;         // (tests) beam_slab_kernel: every step through the general insert path (entry table, duplicate test, evictions)
     uint32_t fx_tags = 0;         // (A/B) reference arithmetic: cap on the words of a position map's claim table (0 = as many as cost no workgroup per CU)
     uint32_t arith_ow6 = 0;       // (A/B) ... the optimise kernel compiled for six waves per SIMD at every ploidy
+    uint32_t arith_replay = 0;    // (tests) reference arithmetic: replay every position map insertion by insertion (the home-bucket rule of optimize_kernel.h off)
     uint32_t arith_hbm = 0;       // (tests) reference arithmetic: position-map tables and first-insertion keys in HBM scratch even where they fit into LDS
     uint32_t opt_block_order = 0; // (A/B, tests) optimise: the build / distance passes visit the reads in block order instead of longest first
     uint32_t s2_assign_only = 0;  // S2 returns the haplogroups as re-inserted (input order): separate_broken_haplogroups and sort_parts are left to a host that iterates its own sets
@@ -724,7 +725,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     if (K.arith) {
                         a.cell_ord = ctx->cur_ord; a.cell_ord_off = ctx->cur_ord_off;
                         char* base = ctx->arith_pool.as<char>() + sl_arith * lane;
-                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off; a.fx_tags = q.fx_tags; a.fk_lds_off = q.fk_lds_off;
+                        a.sort_cap = sort_cap_of(p); a.fx_ctrl = fx_ctrl; a.fx_slot = fx_slot; a.fx_lds_off = q.fx_lds_off; a.fx_tags = q.fx_tags; a.fx_replay = K.arith_replay; a.fk_lds_off = q.fk_lds_off;
                         a.fk_pool = (uint64_t*)base; base += (uint64_t)slots * p * span_max * 8;
                         a.sk_pool = (uint64_t*)base; base += (uint64_t)slots * a.sort_cap * 8;
                         a.sp_pool = (uint32_t*)base; base += ((uint64_t)slots * a.sort_cap * 4 + 15) & ~(uint64_t)15;
@@ -957,6 +958,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "tail_overlap") { if (value < -1 || value > 1) return fail(FLORIA_E_INVALID, "tail_overlap: 0 | 1"); K.tail_overlap = (int32_t)value; }
     else if (k == "tail_waves") K.tail_waves = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "arith_hbm") K.arith_hbm = value != 0;
+    else if (k == "arith_replay") K.arith_replay = value != 0;
     else if (k == "fx_tags") { if (value != 0 && (value < (int64_t)fl::FX_TAGS_MIN || value > (int64_t)fl::FX_TAGS_MAX || (value & (value - 1)))) return fail(FLORIA_E_INVALID, "fx_tags: 0 | a power of two in 128..1024"); K.fx_tags = (uint32_t)value; }
     else if (k == "arith_ow6") K.arith_ow6 = value != 0;
     else if (k == "s2_assign_only") K.s2_assign_only = value != 0;

@@ -72,6 +72,7 @@ struct OptArgs {
     uint32_t* ol_pool;           // [slots][2][ploidy][span_max] every partition's positions (block-relative) in the bucket order of its map, two parities
     uint64_t  sort_cap, fx_ctrl, fx_slot;
     uint32_t  fx_lds_off;        // != 0: the maps' control bytes sit in the workgroup's LDS at this offset instead ([ploidy][2][fx_ctrl], then [ploidy][fx_tags] words)
+    uint32_t  fx_replay;         // (tests) != 0: every map is replayed, the home-bucket rule is off
     uint32_t  fx_tags;           // words of a map's conflict-detection table (a power of two, FX_TAGS_MIN..FX_TAGS_MAX)
     uint32_t  pm_lds_off;        // != 0: the visiting order of the build and distance passes (u16 read indices, longest reads first) in LDS at this offset ([n_max])
     uint32_t  fk_lds_off;        // != 0: the first-insertion keys as 32-bit words (read << 12 | cell rank: reads < 2^20, cells per read < 2^12) in LDS at this offset ([ploidy*span_max])
@@ -159,6 +160,8 @@ void optimize_kernel(OptArgs g) {
     __shared__ double s_errf[MAX_PLOIDY];            // ARITH: running `errors` of every partition
     __shared__ uint32_t s_cntk[MAX_PLOIDY + 1];      // ARITH: positions in every partition's map
     __shared__ uint32_t s_cnt2[2][MAX_PLOIDY];       // ... of the two position lists
+    __shared__ uint32_t s_nk[MAX_PLOIDY], s_kmin[MAX_PLOIDY], s_kmax[MAX_PLOIDY], s_dirC[MAX_PLOIDY];      // ARITH: positions partition k covers, the first and the last (relative); != 0: buckets of its map when every key sits in its home bucket
+    __shared__ uint32_t s_ldir[2][MAX_PLOIDY];       // ... list [parity][k] came from the home-bucket rule (no first-insertion keys stand behind it)
     __shared__ uint32_t s_bpar[MAX_PLOIDY], s_tpar[MAX_PLOIDY], s_keep[MAX_PLOIDY];      // ARITH: which of its two lists holds partition k's ACCEPTED order / the order of the partition being scored; keys unchanged
     uint32_t* s_moved = (uint32_t*)smem;
 
@@ -445,14 +448,39 @@ void optimize_kernel(OptArgs g) {
             const bool k32 = g.fk_lds_off != 0;                                 // (LDS atomics: the HBM ones were a third of this kernel's time)
             if (k32) for (uint32_t x = tid; x < M; x += OPT_THREADS) fk32[x] = ~0u;
             else for (uint32_t x = tid; x < M; x += OPT_THREADS) fk[x] = ~0ull;
-            if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; }
+            if (tid < MAX_PLOIDY) { s_errf[tid] = 0.0; s_goodq[tid] = 0; s_cntk[tid] = 0; s_nk[tid] = 0; s_kmin[tid] = ~0u; s_kmax[tid] = 0; }
             if (tid == 0) s_dq = 0;
             if (g.fx_lds_off) for (uint32_t x = tid; x < p * g.fx_tags; x += OPT_THREADS) ((uint32_t*)(smem + g.fx_lds_off + (uint64_t)p * 2 * g.fx_ctrl))[x] = 0xffffffffu;
             __syncthreads();
-            OPT_TICK(14);    // (ARITH) key table cleared
+            // (0) THE HOME-BUCKET RULE.  A key's first probe is bucket (key * K) mod C (FxHash's low bits, arith_kernel.h), K odd: keys that differ mod C have different
+            // home buckets, an insertion takes another bucket only when its home is full, and a resize re-inserts by the same rule — so if the positions of partition
+            // k span fewer than C of them, C the buckets of a map grown to their number, every key of the final map sits in its home bucket WHATEVER the order of
+            // insertion was, and the iteration order is a function of the set: bucket b holds the position congruent to b * K^-1 mod C, if the partition covers it.
+            // No first-insertion keys, no sort, no replay for such a partition (every one of BASELINE's configs: a block spans ~500 positions, a map of >= 449 keys
+            // has 1024 buckets); the others go the long way below.
+            for (uint32_t k = 0; k < p; ++k)
+                for (uint32_t pr0 = (uint32_t)tid & ~63u; pr0 < span; pr0 += OPT_THREADS) {
+                    const uint32_t pr = pr0 + lane;
+                    bool cov = false;
+                    if (pr < span) {
+#pragma unroll
+                        for (int al = 0; al < A; ++al) cov |= hist[(uint64_t)pr * PA + k * A + al] != 0;
+                    }
+                    const uint64_t cm = __ballot(cov);
+                    if (cm && lane == 0) { atomicAdd(&s_nk[k], (uint32_t)__popcll(cm)); atomicMin(&s_kmin[k], pr0 + (uint32_t)__builtin_ctzll(cm)); atomicMax(&s_kmax[k], pr0 + 63u - (uint32_t)__builtin_clzll(cm)); }
+                }
+            __syncthreads();
+            if ((uint32_t)tid < p) {
+                const uint32_t nk = s_nk[tid];
+                uint32_t C = 4;
+                while (fx_cap_of(C) < nk) C <<= 1;
+                s_dirC[tid] = (!g.fx_replay && (nk == 0 || s_kmax[tid] - s_kmin[tid] < C)) ? C : 0u;
+            }
+            __syncthreads();
+            OPT_TICK(14);    // (ARITH) key table cleared, home-bucket rule decided
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                 uint32_t cb = 0, len = 0, k = 0;
-                if (i < n) { read_meta(i, cb, len, k); if (!meta) k = part[i]; }
+                if (i < n) { read_meta(i, cb, len, k); if (!meta) k = part[i]; if (s_dirC[k]) len = 0; }
                 // A read can only win a position that no earlier read of its partition holds.  The reads are sorted by their first position, so for most of
                 // them every position of their span is already taken when their turn comes: 16 lanes look at the span's keys in LDS first and skip the read's
                 // cells (the global loads this pass waits for) unless some key could still lose.  (Keys only ever decrease: a stale look errs towards loading.)
@@ -496,10 +524,11 @@ void optimize_kernel(OptArgs g) {
             // (1b) A batch of moves rarely changes WHO inserts a position first (only where a moved read was, or becomes, the lowest-numbered read of its partition at a
             // position: the frontier and the gaps), and the map's layout is a function of the first-insertion keys alone: a partition whose keys equal those behind its
             // accepted list keeps that list - no sort, no replay, only the walk with the new counts.  Compared exactly, key by key, against the copy in HBM scratch.
-            if (tid < p) { s_keep[tid] = (wave_sort && !first) ? 1u : 0u; }
+            if (tid < p) { s_keep[tid] = (wave_sort && !first && !s_dirC[tid] && !s_ldir[s_bpar[tid]][tid]) ? 1u : 0u; }
             __syncthreads();
             if (wave_sort && !first) {
                 for (uint32_t k = 0; k < p; ++k) {
+                    if (!s_keep[k]) continue;
                     const uint32_t* const prev = kprev_of(s_bpar[k], k);
                     bool differs = false;
                     for (uint32_t pr = tid; pr < span; pr += OPT_THREADS) differs |= fk32[k * span + pr] != prev[pr];
@@ -511,7 +540,7 @@ void optimize_kernel(OptArgs g) {
             __syncthreads();
             if (wave_sort)
                 for (uint32_t k = 0; k < p; ++k) {
-                    if (s_keep[k]) continue;
+                    if (s_keep[k] || s_dirC[k]) continue;
                     uint32_t* const dst = kprev_of(s_tpar[k], k);
                     for (uint32_t pr = tid; pr < span; pr += OPT_THREADS) dst[pr] = fk32[k * span + pr];
                 }
@@ -544,6 +573,31 @@ void optimize_kernel(OptArgs g) {
                     }
                     good = wave_sum_u64(good);
                     if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
+                    continue;
+                }
+                if (s_dirC[k]) {                                             // every key in its home bucket: the buckets in order, straight from the histogram
+                    const uint32_t C = s_dirC[k], nk = s_nk[k], kmin = pos0 + s_kmin[k], kmax = pos0 + s_kmax[k];
+                    double ef = 0.0;
+                    uint64_t good = 0;
+                    uint32_t written = 0;
+                    for (uint32_t b0 = 0; b0 < (nk ? C : 0u); b0 += 64) {
+                        const uint32_t b = b0 + lane;
+                        const uint32_t key = kmin + ((b * FX_KINV32 - kmin) & (C - 1u));          // the one position of [kmin, kmin + C) whose home is bucket b
+                        bool full = b < C && key <= kmax;
+                        if (full) {
+                            bool cov = false;
+#pragma unroll
+                            for (int al = 0; al < A; ++al) cov |= hist[(uint64_t)(key - pos0) * PA + k * A + al] != 0;
+                            full = cov;
+                        }
+                        const uint32_t posrel = full ? key - pos0 : 0u;
+                        const uint64_t fm = __ballot(full);
+                        if (full) olist[written + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = posrel;
+                        written += (uint32_t)__popcll(fm);
+                        good += fold64(k, posrel, full, ef);
+                    }
+                    good = wave_sum_u64(good);
+                    if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = nk; s_ldir[par][k] = 1u; }
                     continue;
                 }
                 uint32_t start = 0, D = 0;
@@ -607,7 +661,7 @@ void optimize_kernel(OptArgs g) {
                     good += fold64(k, posrel, full, ef);
                 }
                 good = wave_sum_u64(good);
-                if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = D; }
+                if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = D; s_ldir[par][k] = 0u; }
             }
             // the next round's distances on the wavefronts without a map to replay (dist_arith); with as many partitions as wavefronts, by everybody afterwards
             if (with_dist) dist_arith(dist_inc);          // (the wavefronts without a map start here at once, the others when their replay and walk are done)

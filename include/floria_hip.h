@@ -358,7 +358,7 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
  * ploidy below, every job waiting for its block's stop rule; 0 off = default (measured level with it on BASELINE config 4), 1 on), "tail_waves" (waves per CU of that launch,
  * default 2), "beam_path" (0 auto, 1 generic, 2 slab, 3 wide), "no_specialized", "no_p1_shortcut", "opt_threads"
  * (0|128|512|1024), "opt_global", "opt_block_order" (tests / A/B: the optimise kernel's passes visit a block's reads in block order instead of longest first), "slots", "stage_threads" (host threads that fill the pinned staging ring of a pageable upload),
- * "upload_chunks" (chunks of floria_hip_phase_pileups_batch, 0 = auto), "trace" (host-side timestamps of an S1 call on stderr), "reassign_path", "arith_hbm" (tests: the reference-arithmetic mode's tables in HBM scratch even where they fit into LDS), "no_bulk" (tests: every beam step through the general
+ * "upload_chunks" (chunks of floria_hip_phase_pileups_batch, 0 = auto), "trace" (host-side timestamps of an S1 call on stderr), "reassign_path", "arith_hbm" (tests: the reference-arithmetic mode's tables in HBM scratch even where they fit into LDS), "arith_replay" (tests: that mode replays every position map insertion by insertion instead of listing it by the home-bucket rule where that applies), "fx_tags" / "arith_ow6" (A/B: size of the replay's claim table, the six-wave optimise instance at every ploidy), "no_bulk" (tests: every beam step through the general
  * insert path with its duplicate test), "hw_queues" (tests: override the number of
  * concurrently running streams floria_hip_create measured — 6 on an MI355X whose host set GPU_MAX_HW_QUEUES=12 before HIP initialised, 4 or fewer
  * with the runtime's default; below 5 the launch plans stay within two job groups and do not speculate). */

@@ -153,7 +153,7 @@ def test_config4_64_contigs_in_reference_arithmetic(arith, hip_lib, oracle_mod):
         h.free()
 
 
-@pytest.mark.parametrize("knob,value", [("arith_hbm", 1), ("opt_global", 1), ("speculate", 0), ("speculate", 1), ("speculate", 2), ("opt_threads", 512), ("opt_threads", 1024), ("slots", 96), ("groups", 2)])
+@pytest.mark.parametrize("knob,value", [("arith_hbm", 1), ("arith_replay", 1), ("fx_tags", 128), ("opt_global", 1), ("speculate", 0), ("speculate", 1), ("speculate", 2), ("opt_threads", 512), ("opt_threads", 1024), ("slots", 96), ("groups", 2)])
 def test_launch_knobs_do_not_change_reference_arithmetic_results(arith, hip_lib, oracle_mod, knob, value):
     """Histogram in HBM instead of LDS, every stage plan, other workgroup sizes, a small persistent grid: the same bits (the oracle comparison of the
     default plan is test_config_slices_in_reference_arithmetic)."""
@@ -190,6 +190,36 @@ def test_long_reads_in_reference_arithmetic(arith, hip_lib, oracle_mod, seed):
     assert int(np.diff(pile.read_off).max()) > 256
     assert_block_results_equal(ro, rg, f"seed {seed} eps {eps}")
     assert ro.min_prune_margin == rg.min_prune_margin
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sparse_partitions_whose_positions_span_more_than_their_map_has_buckets(arith, hip_lib, oracle_mod, seed):
+    """The optimise kernel lists a position map's iteration order straight from the histogram when the partition's positions span fewer than the map has
+    buckets (every key then sits in its home bucket, optimize_kernel.h) and replays the insertions otherwise.  Linked-read-like fragments - a handful of
+    cells scattered over several hundred positions - make partitions of ~100 keys over ~800 positions (128 or 256 buckets): the replay, with real collisions;
+    the same pileups with the rule switched off must give the same bits, and both the oracle's."""
+    from floria_amd.pileup import Pileup
+    rng = np.random.default_rng(5300 + seed)
+    S = 500 + 100 * seed
+    hap = rng.integers(0, 2, size=(3, S))
+    reads = []
+    for r in range(18 + 4 * seed):
+        snps = np.sort(rng.choice(np.arange(1, S + 1), size=int(rng.integers(4, 14)), replace=False))
+        al = hap[r % 3, snps - 1].copy()
+        flip = rng.random(len(snps)) < 0.06
+        al[flip] ^= 1
+        reads.append((snps, al, rng.integers(8, 40, size=len(snps))))
+    pile = Pileup.from_reads(reads)
+    s, e = np.asarray([1, S // 4], np.uint32), np.asarray([S, S], np.uint32)
+    eps = NON_DYADIC[seed % 3]
+    ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, eps, P=4, B=6)
+    assert_block_results_equal(ro, rg, f"seed {seed} eps {eps}")
+    arith.set_option("arith_replay", 1)
+    try:
+        _, rr = both(arith, hip_lib, oracle_mod, pile, s, e, eps, P=4, B=6)
+    finally:
+        arith.set_option("arith_replay", 0)
+    assert_block_results_equal(ro, rr, f"seed {seed} eps {eps}, every map replayed")
 
 
 @pytest.mark.parametrize("full", (3, 7, 14, 28, 56, 112))
