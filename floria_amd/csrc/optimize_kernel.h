@@ -406,12 +406,18 @@ void optimize_kernel(OptArgs g) {
 #pragma unroll
                 for (int x = 0; x + 1 < A; ++x) term[x] = (double)q[x] * scale;
                 term[A - 1] = q[A - 1] <= one ? g.eps : 0.0;
-                uint64_t hm = __ballot(have);
+                uint64_t nz[A];                                              // (x + 0.0 == x for the non-negative sums here: the zero terms - most of them - stay off the chain)
+#pragma unroll
+                for (int x = 0; x < A; ++x) nz[x] = __ballot(have && term[x] != 0.0);
+                uint64_t hm = 0;
+#pragma unroll
+                for (int x = 0; x < A; ++x) hm |= nz[x];
                 while (hm) {                                                 // (wave-uniform: the sum is the one sequential thing here)
                     const uint32_t l = (uint32_t)__builtin_ctzll(hm);
                     hm &= hm - 1;
 #pragma unroll
                     for (int x = 0; x < A; ++x) {
+                        if (!((nz[x] >> l) & 1ull)) continue;
                         const uint64_t tb = (uint64_t)__double_as_longlong(term[x]);
                         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb, (int)l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb >> 32), (int)l);
                         ef += __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));          // :248-250 all but the last, then :251-253
@@ -478,6 +484,9 @@ void optimize_kernel(OptArgs g) {
             }
             __syncthreads();
             OPT_TICK(14);    // (ARITH) key table cleared, home-bucket rule decided
+            bool any_replay = false;
+            for (uint32_t k = 0; k < p; ++k) any_replay |= s_dirC[k] == 0;
+            if (any_replay)
             for (uint32_t i = grp; i < n16; i += OPT_THREADS / 16) {
                 uint32_t cb = 0, len = 0, k = 0;
                 if (i < n) { read_meta(i, cb, len, k); if (!meta) k = part[i]; if (s_dirC[k]) len = 0; }
@@ -486,7 +495,7 @@ void optimize_kernel(OptArgs g) {
                 // cells (the global loads this pass waits for) unless some key could still lose.  (Keys only ever decrease: a stale look errs towards loading.)
                 if (k32 && meta && span <= 65535u) {
                     bool open = false;
-                    if (i < n) {
+                    if (i < n && len) {
                         const uint32_t fl = m_fl[i], thr = i << 12, lastp = fl >> 16;
                         for (uint32_t pr0 = (fl & 0xffffu) + sub; pr0 <= lastp; pr0 += 128) {          // eight keys per lane and round trip
                             uint32_t v[8];
