@@ -325,7 +325,7 @@ void beam_slab_kernel(BeamArgs g) {
             uint32_t st = 0;            // 1 = decided: go on, 2 = decided: done, 3 = waited in vain (from here on this wave does not wait)
             for (;;) {
                 if (lane == 0) {
-                    const uint32_t tr = __hip_atomic_load(&GCOLD(tried)[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t tr = __hip_atomic_load(&GCOLD(tried)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (blk_done is stored before tried, both written through: optimize_kernel.h)
                     const uint32_t dn = __hip_atomic_load(&GCOLD(blk_done)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     st = dn ? 2u : (tr >= want ? 1u : 0u);
                     if (st == 0 && wall_clock64() - t0 >= tmax) st = 3;

@@ -720,6 +720,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                     a.fuse_select = stage.size() == 1 ? 1 : 0;
                     a.stopping_heuristic = prm->stopping_heuristic; a.mec_threshold = mec_threshold(prm, p);
                     a.blk_done_w = d_done; a.best_ploidy = d_best; a.tried = d_tried;
+                    a.release_tried = tail_p != 0 ? 1u : 0u;
                     a.pm_lds_off = q.pm_lds_off;
                     // (a plan with ANY speculative stage publishes ready bits and stop_at from every stage: a later stage's stop rule compares with these MEC values)
                     if (K.arith) {

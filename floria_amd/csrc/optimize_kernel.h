@@ -52,6 +52,7 @@ struct OptArgs {
     uint32_t  fuse_select;
     int32_t   stopping_heuristic;
     double    mec_threshold;     // threshold for THIS ploidy, computed on the host with libm pow (:204-220)
+    uint32_t  release_tried;     // != 0: a beam launch in flight waits for tried[b] / blk_done[b] (tail_overlap): they are published with agent-scope stores
     uint8_t*  blk_done_w;
     uint32_t* best_ploidy;
     uint32_t* tried;
@@ -859,8 +860,17 @@ void optimize_kernel(OptArgs g) {
                 const double bad = ARITH ? s_errf[k] : (double)s_errq[k] + (double)s_errm[k] * g.eps;
                 mecv += bad; na += good; na += bad;
             }
-            g.mec[(uint64_t)b * g.max_ploidy + p - 1] = mecv;
-            g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] = na;
+            // What OTHER workgroups of launches in flight read (the stop rule of a speculative stage, the waiting jobs of a tail launch) is stored with agent-scope atomics —
+            // written through — and ordered by waiting for the stores: an agent-scope FENCE writes the whole L2 of the XCD back (and an acquire invalidates it), under the
+            // beam kernels that live on its contents.  Everything else is read by later launches only (kernel boundary).
+            const bool publish = g.stop_at != nullptr || g.release_tried;
+            if (publish) {
+                __hip_atomic_store(&g.mec[(uint64_t)b * g.max_ploidy + p - 1], mecv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                g.mec[(uint64_t)b * g.max_ploidy + p - 1] = mecv;
+                g.num_alleles[(uint64_t)b * g.max_ploidy + p - 1] = na;
+            }
             g.iters[(uint64_t)b * g.max_ploidy + p - 1] = iters_done;
             if (g.fuse_select) {                                  // == select_kernel below; only this workgroup touches block b in this launch
                 const double expected = na * g.eps;                                                    // :196
@@ -872,14 +882,20 @@ void optimize_kernel(OptArgs g) {
                     else if (g.stopping_heuristic) { best = p - 1; stop = true; }                     // :233-238
                     if (!stop && mecv < expected) stop = true;                                         // :240-243
                 } else if (mecv < expected) stop = true;                                               // :247-250
-                if (stop || p == g.max_ploidy) { g.blk_done_w[b] = 1; g.best_ploidy[b] = best; }
-                // (release: a beam launch of the next ploidy that runs beside this launch starts block b's job when it sees tried[b] = p, and reads blk_done[b] then)
-                __hip_atomic_store(&g.tried[b], p, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (g.release_tried) {
+                    // a beam launch of the next ploidy runs beside this launch (tail_overlap): it starts block b's job when it sees tried[b] = p, and reads blk_done[b] then
+                    if (stop || p == g.max_ploidy) { __hip_atomic_store(&g.blk_done_w[b], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); g.best_ploidy[b] = best; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                    // (the stores above have completed)
+                    __hip_atomic_store(&g.tried[b], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (stop || p == g.max_ploidy) { g.blk_done_w[b] = 1; g.best_ploidy[b] = best; }
+                    g.tried[b] = p;
+                }
             }
             if (g.stop_at) {
-                __threadfence();                                                              // mec / num_alleles of (b, p) before the ready bit
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                        // mec / num_alleles of (b, p) have completed before the ready bit is set
                 const uint32_t have = atomicOr(&g.ready[b], 1u << p) | (1u << p);
-                __threadfence();                                                              // the other ploidy's mec / num_alleles after its ready bit
+                // (the other ploidy's mec / num_alleles: agent-scope loads in stop_rule_fires, issued after the atomic has returned)
                 for (uint32_t q = p; q <= p + 1 && q <= g.max_ploidy; ++q)
                     if (((have >> q) & 1u) && (q == 1 || ((have >> (q - 1)) & 1u)) && stop_rule_fires(g, b, q)) atomicMin(&g.stop_at[b], q);
             }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(REASSIGN_THREADS) void reassign_kernel(ReassignArgs
         for (uint32_t k = 0; k < n_multi; ++k) {
             const uint32_t m = multi[k];
             bulk_add(prev, m);
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the histogram atomics (performed at L2) have completed; the loads below are agent-scope loads of the same L2.  (An agent-scope fence would write the XCD's whole L2 back and invalidate it, twice per read with a choice.)
             __syncthreads();
             if (wid == 0) {                                             // the read that has a choice: one wavefront, lanes over its cells
                 const uint32_t r = ord ? ord[m] : m;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(REASSIGN_THREADS) void reassign_kernel(ReassignArgs
                 }
                 if (lane == 0) assign[r] = (int32_t)best;
             }
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the histogram atomics (performed at L2) have completed; the loads below are agent-scope loads of the same L2.  (An agent-scope fence would write the XCD's whole L2 back and invalidate it, twice per read with a choice.)
             __syncthreads();
             prev = m + 1;
         }
