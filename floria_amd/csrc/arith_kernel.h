@@ -276,7 +276,12 @@ struct FxWave {
 };
 
 // ---- Frag.positions: for every read its cells, permuted into the set's iteration order --------------------------------------------
-// One thread per read (the emulation is sequential); three tables per thread in global scratch: the growing seq_dict (a pair) and the set.
+// `positions = seq_dict.keys().collect()`: a set with room for all L keys at once (C = fx_buckets_for(L) buckets, never resized), filled in the iteration order of
+// the growing map seq_dict.  THE HOME-BUCKET RULE (optimize_kernel.h, step (0)): a key's first probe is bucket (key * K) mod C, K odd — so when the read's SNP indices
+// span fewer than C positions every key finds its home bucket empty, whatever the order of arrival: the set's iteration order is a function of the keys alone and
+// bucket b holds the position congruent to b * K^-1 mod C.  cell_order_direct_kernel: a WAVEFRONT per read, a position -> cell table of C entries in LDS, the buckets
+// in order 64 at a time; reads that span C positions or more (scattered cells: linked reads) are listed for cell_order_kernel, one thread per read, which emulates
+// the three tables insertion by insertion (the growing seq_dict — a pair — and the set) in global scratch.
 struct CellOrderArgs {
     const ContigDev* contigs;
     const uint64_t*  read_prefix;    // [n_contigs+1] reads before contig c in this launch
@@ -286,12 +291,53 @@ struct CellOrderArgs {
     uint2*    ord;                   // [cells] {SNP, allele << 28 | weight} of the x-th cell of the read in set order (a permuted copy: one load per cell in the kernels)
     uint8_t*  scratch;               // [threads][3 * (ctrl_bytes + slot_bytes)]
     uint64_t  ctrl_bytes, slot_bytes;
+    uint64_t* todo;                  // [1 + n_reads] number of reads left to cell_order_kernel, then their global indices
+    uint32_t  replay_all;            // (tests) != 0: every read goes the long way
 };
+constexpr uint32_t CO_IDX_MAX = 2048;      // largest set (buckets) the direct kernel takes: u16 entries, 4 KB of LDS per wavefront
+__global__ __launch_bounds__(256) void cell_order_direct_kernel(CellOrderArgs g) {
+    __shared__ uint16_t s_idx[4][CO_IDX_MAX];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wid, nw = (uint64_t)gridDim.x * 4;
+    __attribute__((address_space(3))) uint16_t* const idx = (__attribute__((address_space(3))) uint16_t*)s_idx[wid];
+    for (uint64_t gr = gw; gr < g.n_reads; gr += nw) {
+        uint32_t lo = 0, hi = g.n_contigs;                                    // contig of global read gr
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
+        const ContigDev cd = g.contigs[lo];
+        const uint32_t r = (uint32_t)(gr - g.read_prefix[lo]);
+        const uint32_t cb = cd.read_off[r], L = cd.read_off[r + 1] - cb;
+        if (L == 0) continue;
+        const uint32_t first = cd.cell_snp[cb], range = cd.cell_snp[cb + L - 1] - first;
+        const uint32_t C = fx_buckets_for(L);
+        if (range >= C || C > CO_IDX_MAX || L > 65535u || g.replay_all) {       // (wave-uniform)
+            if (lane == 0) g.todo[1 + atomicAdd((unsigned long long*)g.todo, 1ull)] = gr;
+            continue;
+        }
+        // (a wavefront's LDS operations execute in order; the fences keep the compiler from moving them across each other)
+        for (uint32_t x = lane; x <= range; x += 64) idx[x] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t c = lane; c < L; c += 64) idx[cd.cell_snp[cb + c] - first] = (uint16_t)(c + 1);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        uint2* out = g.ord + g.cell_prefix[lo] + cb;
+        uint32_t k = 0;
+        for (uint32_t b0 = 0; b0 < C; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const uint32_t off = (b * FX_KINV32 - first) & (C - 1u);          // the one position of [first, first + C) whose home is bucket b
+            const uint32_t e = (b < C && off <= range) ? idx[off] : 0u;
+            const uint64_t m = __ballot(e != 0u);
+            if (e) out[k + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = make_uint2(first + off, cd.cell_aw[cb + e - 1]);
+            k += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+}
 __global__ void cell_order_kernel(CellOrderArgs g) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t tb = g.ctrl_bytes + g.slot_bytes;
     uint8_t* mine = g.scratch + tid * 3 * tb;
-    for (uint64_t gr = tid; gr < g.n_reads; gr += nth) {
+    const uint64_t n_todo = g.todo[0];
+    for (uint64_t ti = tid; ti < n_todo; ti += nth) {
+        const uint64_t gr = g.todo[1 + ti];
         uint32_t lo = 0, hi = g.n_contigs;                                    // contig of global read gr
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
         const ContigDev cd = g.contigs[lo];

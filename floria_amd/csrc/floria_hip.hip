@@ -959,7 +959,7 @@ int floria_hip_set_option(floria_hip_ctx* ctx, const char* key, int64_t value) {
     else if (k == "tail_overlap") { if (value < -1 || value > 1) return fail(FLORIA_E_INVALID, "tail_overlap: 0 | 1"); K.tail_overlap = (int32_t)value; }
     else if (k == "tail_waves") K.tail_waves = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 16));
     else if (k == "arith_hbm") K.arith_hbm = value != 0;
-    else if (k == "arith_replay") K.arith_replay = value != 0;
+    else if (k == "arith_replay") { K.arith_replay = value != 0; ctx->ord_epoch = ~0ull; }      // (the cell orders are computed again, the long way or the short one)
     else if (k == "fx_tags") { if (value != 0 && (value < (int64_t)fl::FX_TAGS_MIN || value > (int64_t)fl::FX_TAGS_MAX || (value & (value - 1)))) return fail(FLORIA_E_INVALID, "fx_tags: 0 | a power of two in 128..1024"); K.fx_tags = (uint32_t)value; }
     else if (k == "arith_ow6") K.arith_ow6 = value != 0;
     else if (k == "s2_assign_only") K.s2_assign_only = value != 0;
@@ -1525,7 +1525,7 @@ namespace {
 
 // Reference-arithmetic mode: the cells of every read of the given contigs in the iteration order of its position set (cell_order_kernel), for
 // the call in flight: ctx->cur_ord[ctx->cur_ord_off[c] + read_off[r] + x] = {SNP, allele << 28 | weight} of the x-th position of read r's set.
-// Computed by one launch (≈ 130 ms for the 331 M cells of config 4) and kept until the context uploads contigs again: S2 after S1, or the next S1 call over the same resident batch, reuses it.
+// Computed by two launches (round 5: ≈ 130 ms for the 331 M cells of config 4 with the one-thread-per-read table emulation alone) and kept until the context uploads contigs again: S2 after S1, or the next S1 call over the same resident batch, reuses it.
 int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, uint32_t len_max) {
     const uint32_t n_contigs = (uint32_t)cdev.size();
     std::vector<uint64_t> pre(2 * (size_t)n_contigs + 2, 0);                  // reads before contig c [n+1] | cells before contig c [n]
@@ -1547,10 +1547,16 @@ int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::
         const uint64_t tb = fl::fx_ctrl_bytes(std::max(1u, len_max)) + fl::fx_slot_bytes(std::max(1u, len_max));
         uint64_t nth = std::min<uint64_t>((R_all + 255) & ~255ull, 131072);
         nth = std::max<uint64_t>(256, std::min<uint64_t>(nth, ((2ull << 30) / (3 * tb)) & ~255ull));
-        rc = ctx->arith_scr.ensure(3 * tb * nth); if (rc) return rc;
+        const uint64_t todo_bytes = (8 * (R_all + 1) + 255) & ~255ull;          // [count | reads for the table emulation] in front of the emulation's scratch
+        rc = ctx->arith_scr.ensure(todo_bytes + 3 * tb * nth); if (rc) return rc;
+        HIPCHK(hipMemsetAsync(ctx->arith_scr.p, 0, 8, ctx->stream));
         fl::CellOrderArgs oa{};
+        oa.todo = ctx->arith_scr.as<uint64_t>(); oa.replay_all = ctx->knobs.arith_replay;
         oa.contigs = d_contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
-        oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint2>(); oa.scratch = ctx->arith_scr.as<uint8_t>(); oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
+        oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint2>(); oa.scratch = ctx->arith_scr.as<uint8_t>() + todo_bytes; oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
+        // a wavefront per read where the home-bucket rule applies (arith_kernel.h), then one thread per read for the rest (none on BASELINE's configs)
+        hipLaunchKernelGGL(fl::cell_order_direct_kernel, dim3((uint32_t)std::min<uint64_t>((R_all + 3) / 4, (uint64_t)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, oa);
+        HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
         HIPCHK(hipGetLastError());
     }
