@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """(GPU) random pileups through S1 in both arithmetics against the oracle (mode 0 / mode 1), many seeds: a wider net than the test suite's.
+(Round 5: the replay / HBM-table / claim-table options of the reference arithmetic are drawn at random per seed, so the fallback paths behind the home-bucket rule run too.)
 usage: scripts/arith_fuzz.py [first seed = 0] [count = 300]"""
 import sys
 sys.path.insert(0, ".")
@@ -27,6 +28,11 @@ for seed in range(s0, s0 + cnt):
     e = np.minimum(S, s + rng.integers(0, 60, size=nb))
     eps = EPS[int(rng.integers(0, len(EPS)))]
     P, B, sens, stop = int(rng.integers(1, 8)), int(rng.integers(1, 13)), int(rng.integers(1, 4)), int(rng.integers(0, 2))
+    # the reference arithmetic's own launch options, at random: every map / every read's set replayed insertion by insertion, tables in HBM, a small claim table
+    krng = np.random.default_rng(99 + seed)
+    kn = {"arith_replay": int(krng.random() < 0.3), "arith_hbm": int(krng.random() < 0.15), "fx_tags": int(krng.choice([0, 0, 128, 256]))}
+    for k, v in kn.items():
+        ctx.set_option(k, v)
     for mode in (0, 1):
         oracle.set_arith_mode(mode); ctx.set_option("arith", mode)
         ro = oracle.phase_blocks(pile, s, e, oracle.make_params(eps, P, B, sens, stop), threads=4)
@@ -35,7 +41,7 @@ for seed in range(s0, s0 + cnt):
                 and np.array_equal(ro.ploidies_tried, rg.ploidies_tried))
         if not same:
             bad += 1
-            print(f"RESULT MISMATCH seed {seed} mode {mode} eps {eps} P {P} B {B} sens {sens} stop {stop} alleles {alleles}: best {ro.best_ploidy} / {rg.best_ploidy}")
+            print(f"RESULT MISMATCH seed {seed} mode {mode} knobs {kn} eps {eps} P {P} B {B} sens {sens} stop {stop} alleles {alleles}: best {ro.best_ploidy} / {rg.best_ploidy}")
         if ro.min_prune_margin != rg.min_prune_margin:          # a diagnostic built from exp / log: device libm against host libm
             margin_bits += 1
             rel = abs(ro.min_prune_margin - rg.min_prune_margin)
