@@ -339,10 +339,21 @@ void optimize_kernel(OptArgs g) {
                 if (!act) len = 0;
                 double df = 0.0;
                 constexpr int DU = HL ? 8 : 4;                           // cells per batch: order entries, cells and histogram rows / code bytes requested together
+                // (the order entries come from HBM or the Infinity Cache - a block's reads do not stay in L2 between two passes -, a microsecond away: the NEXT batch's are
+                // requested before this batch's are used, so a read of 92 cells waits for six round trips instead of twelve)
+                uint2 nx[DU];
+                if (len) {
+#pragma unroll
+                    for (int u = 0; u < DU; ++u) nx[u] = ord[cb + ((uint32_t)u < len ? (uint32_t)u : len - 1)];
+                }
                 for (uint32_t c0 = 0; c0 < len; c0 += DU) {
                     uint32_t aqs[DU], sn[DU]; uint64_t row[DU][A];
 #pragma unroll
-                    for (int u = 0; u < DU; ++u) { const uint2 ca = ord[cb + (c0 + u < len ? c0 + u : len - 1)]; sn[u] = ca.x; aqs[u] = ca.y; }
+                    for (int u = 0; u < DU; ++u) { sn[u] = nx[u].x; aqs[u] = nx[u].y; }
+                    if (c0 + DU < len) {
+#pragma unroll
+                        for (int u = 0; u < DU; ++u) nx[u] = ord[cb + (c0 + DU + u < len ? c0 + DU + u : len - 1)];
+                    }
                     if constexpr (HL) {                                  // the code byte says it all: 0 = nothing observed, bit a = allele a attains the maximal sum
                         uint32_t cds[DU];
 #pragma unroll
@@ -608,6 +619,9 @@ void optimize_kernel(OptArgs g) {
                     }
                     good = wave_sum_u64(good);
                     if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = nk; s_ldir[par][k] = 1u; }
+#ifdef FLORIA_PROF
+                    if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's walk by the home-bucket rule
+#endif
                     continue;
                 }
                 uint32_t start = 0, D = 0;
