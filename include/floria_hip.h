@@ -340,7 +340,7 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
  *                (csrc/arith_kernel.h).  Applies to floria_hip_phase_* (S1) and floria_hip_reassign* (S2).  Biallelic-or-not pileups without q = 0 cells run the
  *                shared-slab beam kernel with the running sums folded per live slab (beam_slab_kernel<.., ARITH>); the optimise kernel lists a partition's
  *                position map in bucket order straight from the histogram where its keys span fewer positions than the map has buckets (every key then sits
- *                in its home bucket) and replays the insertions otherwise: about 1.6 x the time of mode 0 on BASELINE config 4 (104 against 65 ms at
+ *                in its home bucket) and replays the insertions otherwise: about 1.5 x the time of mode 0 on BASELINE config 4 (98 against 66 ms at
  *                -e 0.04); the host-pileup entry points do not pipeline in this mode.
  * For an epsilon that is a multiple of 2^-10 both modes return the same bits (every sum is exact in f64 in any order); for any other epsilon they are
  * different functions (about 60 % of the blocks of the BASELINE configs come out differently at 0.04) and mode 1 is the one a Rust host's CPU path computes,
