@@ -48,6 +48,30 @@ __device__ __attribute__((noinline)) double log_sum_exp_terms(double dx, int seg
 
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
 template <int CTRL> __device__ __forceinline__ uint64_t dpp_mov64(uint64_t v) { return ((uint64_t)dpp_mov<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_mov<CTRL>((uint32_t)v); }
+// Whole-wave reductions at the end of a job / of the kernel by DPP inside the rows of 16 lanes and four v_readlane across them.  (The __shfl_xor butterflies of common.h
+// need six lane-address registers that hipcc computes before the job loop and keeps - spilled to scratch - until the loop is left.)
+__device__ __forceinline__ double wave_min_f64_dpp(double v) {
+    auto mn = [](double a, uint64_t bb) { const double b = __longlong_as_double((long long)bb); return b < a ? b : a; };
+    v = mn(v, dpp_mov64<0xB1>((uint64_t)__double_as_longlong(v)));
+    v = mn(v, dpp_mov64<0x4E>((uint64_t)__double_as_longlong(v)));
+    v = mn(v, dpp_mov64<0x141>((uint64_t)__double_as_longlong(v)));
+    v = mn(v, dpp_mov64<0x140>((uint64_t)__double_as_longlong(v)));
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    double r = __longlong_as_double((long long)rl64(b, 0));
+    r = mn(r, rl64(b, 16)); r = mn(r, rl64(b, 32)); r = mn(r, rl64(b, 48));
+    return r;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    return rl32(v, 0) + rl32(v, 16) + rl32(v, 32) + rl32(v, 48);
+}
+// 1e300 built where it is used: as a plain constant it is a loop-invariant register pair that hipcc spills for the length of the job loop
+__device__ __forceinline__ double huge_margin() {
+    uint32_t lo, hi;
+    asm volatile("v_mov_b32 %0, 0x8800759c" : "=v"(lo));
+    asm volatile("v_mov_b32 %0, 0x7e37e43c" : "=v"(hi));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 __device__ __forceinline__ uint64_t seg_sum_u64(uint64_t v, uint32_t Gs) {
     if (Gs >= 2) v += dpp_mov64<0xB1>(v);      // quad_perm [1,0,3,2]
     if (Gs >= 4) v += dpp_mov64<0x4E>(v);      // quad_perm [2,3,0,1]
@@ -299,7 +323,7 @@ void beam_slab_kernel(BeamArgs g) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint64_t rk1 = c_rk1[my_k], rk2 = c_rk2[my_k];
     const int seg0 = (int)(my_sl * psl);
-    double min_margin = 1e300;
+    double min_margin = 0.0;
     uint32_t n_fallback = 0;
 #ifdef FLORIA_PROF
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
@@ -339,7 +363,7 @@ void beam_slab_kernel(BeamArgs g) {
         }
         if (SPEC && GCOLD(stop_at) && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) continue;   // nobody will look at this ploidy of the block
         bool dropped = false;
-        min_margin = 1e300;                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
+        min_margin = huge_margin();                                 // per (block, ploidy) job: the host keeps the jobs the stop rule reached
         const ContigDev cd = GCOLD_BS(contigs)[GCOLD_BS(blk_contig)[b]];
         const uint64_t roff = GCOLD_BS(blk_read_off)[b];
         const uint32_t n = (uint32_t)(GCOLD_BS(blk_read_off)[b + 1] - roff);
@@ -1426,7 +1450,7 @@ void beam_slab_kernel(BeamArgs g) {
                 }
             }
             if (lane == 0) atomicAdd(GCOLD(steps_done), (unsigned long long)n);
-            { const double jm = wave_min_f64(min_margin); if (lane == 0) GCOLD(job_margin)[(uint64_t)b * GCOLD(max_ploidy) + p - 1] = jm; }
+            { const double jm = wave_min_f64_dpp(min_margin); if (lane == 0) GCOLD(job_margin)[(uint64_t)b * GCOLD(max_ploidy) + p - 1] = jm; }
         }
         __syncthreads();
         BEAM_TICK(6);
@@ -1441,7 +1465,7 @@ void beam_slab_kernel(BeamArgs g) {
                      atomicAdd(&g.prof[44], c_w512); atomicAdd(&g.prof[45], c_wsum); atomicAdd(&g.prof[48], c_it64); atomicAdd(&g.prof[49], c_it128); atomicAdd(&g.prof[50], c_it256); atomicAdd(&g.prof[51], c_lvl2); atomicAdd(&g.prof[52], c_general); atomicAdd(&g.prof[53], c_exact); atomicAdd(&g.prof[60], c_boring); atomicAdd(&g.prof[61], c_heapkeep); atomicAdd(&g.prof[54], c_code);      // [54]: code bytes gathered by the distance phase
                      atomicAdd(&g.prof[13], c_nlive); atomicAdd(&g.prof[14], c_nin); atomicAdd(&g.prof[15], c_nstates); atomicAdd(&g.prof[9], c_L); }     // [28..31]: wave wall ticks of the ploidy 2..5 launches
 #endif
-    n_fallback = wave_sum_u32(n_fallback);
+    n_fallback = wave_sum_u32_dpp(n_fallback);
     if (lane == 0) {
         if (n_fallback) atomicAdd(&GCOLD(diag)[0], n_fallback);
     }
