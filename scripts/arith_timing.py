@@ -25,7 +25,8 @@ if len(sys.argv) > 4:
 for kv in sys.argv[5:]:
     k, v = kv.split("=")
     ctx.set_option(k, int(v))
-for mode in (0, 1):
+import os
+for mode in [int(x) for x in os.environ.get("ARITH_MODES", "0,1").split(",")]:      # (ARITH_MODES=0: the canonical call only, e.g. under scripts/arith_trace.sh)
     ctx.set_option("arith", mode)
     ctx.phase_blocks_batch(hs, bc, bs, be, par, copy_out=False)
     t = time.perf_counter()

@@ -13,7 +13,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 t0 = None
 # the last S1 call = the last run of beam/optimize kernels; print the last 40 dispatches of those families
 sel = [r for r in rows if 'beam' in r['Kernel_Name'] or 'optimize' in r['Kernel_Name']]
-for r in sel[-24:]:
+for r in sel[-int(__import__("os").environ.get("TRACE_ROWS", "24")):]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     if t0 is None: t0 = s
     name = r['Kernel_Name']
