@@ -315,10 +315,10 @@ void optimize_kernel(OptArgs g) {
             __syncthreads();
         };
 
-        // ARITH, opt_iterate's distances (local_clustering.rs:292-326): one thread per (read, partition) — the running sum cannot be split over lanes —, threads t0,
-        // t0 + 1, .. of nt.  They depend on the histogram only, so the pass for round r + 1 runs on the wavefronts that have no position map to replay while
-        // the statistics of round r are computed (a rejected round r makes them useless, and is the last).  inc: only the reads that reach into the interval of
-        // positions whose code byte changed in the last batch of moves.
+        // ARITH, opt_iterate's distances (local_clustering.rs:292-326): one thread per (read, partition) — the running sum cannot be split over lanes.  They depend on
+        // the histogram only, so the pass for round r + 1 runs beside the statistics of round r (a rejected round r makes it useless, and is the last): on the
+        // wavefronts that have no position map to list at once, on the others when they are done.  inc: only the reads that reach into the interval of positions
+        // whose code byte changed in the last batch of moves.
         // The pairs are handed out 64 at a time from a counter in LDS (s_dq, zeroed behind a barrier before the pass): the wavefronts that replay a position map join
         // when they are done, so everybody ends together.
         auto dist_arith = [&](bool inc) __attribute__((always_inline)) {
