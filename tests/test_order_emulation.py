@@ -146,3 +146,35 @@ def test_entry_or_insert_never_grows_a_full_map_for_a_key_that_is_there():
         assert sorted(grown.tolist()) == sorted(once.tolist())
         one_more, b3 = oracle.fxset_entry_order(np.concatenate([keys, [5]]))              # a NEW key does grow it
         assert b3 == 2 * nb and grown.tolist() == [k for k in one_more.tolist() if k != 5]
+
+
+def test_home_bucket_rule_against_the_emulated_tables():
+    """What the round-5 kernels rely on (optimize_kernel.h step (0), arith_kernel.h cell_order_direct_kernel): hashbrown's first probe for key k in C buckets is
+    (k * K) mod C with K = FxHash's odd multiplier, so keys that span fewer than C values have pairwise different home buckets, nothing is ever displaced — not by
+    later keys, not by a resize — and the iteration order of the final table is the keys sorted by home bucket WHATEVER the order of insertion was.  Checked here
+    against the oracle's insertion-by-insertion emulation of the tables (the thing the kernels would otherwise replay), in many insertion orders; and the converse:
+    keys that span more than the table has buckets do depend on the order."""
+    K = 0x517CC1B727220A95
+    rng = np.random.default_rng(77)
+    for trial in range(300):
+        n = int(rng.integers(1, 700))
+        cap, C = 3, 4                                        # buckets of a map grown to n keys: 4, 8, then 7/8 full at every power of two
+        while cap < n:
+            C *= 2
+            cap = C - 1 if C < 8 else C // 8 * 7
+        lo = int(rng.integers(1, 1 << 20))
+        keys = lo + rng.choice(C, size=n, replace=False).astype(np.uint64)           # n distinct keys of [lo, lo + C)
+        expect = sorted(keys.tolist(), key=lambda k: (k * K) & (C - 1))
+        for order in (np.sort(keys), np.sort(keys)[::-1].copy(), rng.permutation(keys), rng.permutation(keys)):
+            got, nb = oracle.fxset_entry_order(order.astype(np.uint64))
+            assert nb == C, f"trial {trial}: {n} keys -> {nb} buckets, expected {C}"
+            assert got.tolist() == expect, f"trial {trial}: n {n} C {C} lo {lo}"
+    # ... and keys that span MORE than C values collide: two insertion orders, two iteration orders
+    differs = 0
+    for trial in range(50):
+        keys = (1000 + 64 * rng.choice(40, size=20, replace=False)).astype(np.uint64)      # 20 keys -> 32 buckets, all congruent mod 32: one home bucket
+        a, nb = oracle.fxset_entry_order(np.sort(keys))
+        b, _ = oracle.fxset_entry_order(np.sort(keys)[::-1].copy())
+        assert nb == 32 and sorted(a.tolist()) == sorted(b.tolist())
+        differs += a.tolist() != b.tolist()
+    assert differs > 40
