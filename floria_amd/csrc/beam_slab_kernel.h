@@ -349,7 +349,8 @@ void beam_slab_kernel(BeamArgs g) {
             uint32_t st = 0;            // 1 = decided: go on, 2 = decided: done, 3 = waited in vain (from here on this wave does not wait)
             for (;;) {
                 if (lane == 0) {
-                    const uint32_t tr = __hip_atomic_load(&GCOLD(tried)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (blk_done is stored before tried, both written through: optimize_kernel.h)
+                    const uint32_t tr = __hip_atomic_load(&GCOLD(tried)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (blk_done is stored, and acknowledged, before tried: optimize_kernel.h)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // ... and loaded after it: the tried load has returned before the blk_done load is issued
                     const uint32_t dn = __hip_atomic_load(&GCOLD(blk_done)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     st = dn ? 2u : (tr >= want ? 1u : 0u);
                     if (st == 0 && wall_clock64() - t0 >= tmax) st = 3;
@@ -806,7 +807,7 @@ void beam_slab_kernel(BeamArgs g) {
                                     const uint32_t r = U - u0;
                                     if (r >= 7u) batch(IC<8>{}, u0); else if (r >= 5u) batch(IC<6>{}, u0); else if (r >= 3u) batch(IC<4>{}, u0); else batch(IC<2>{}, u0);
                                 }
-                                if (ntiles == 1) atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs);
+                                if (L < (uint32_t)SLAB_TILE) atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs);         // (< 256 cells of weight <= 2^24: the sum stays below 2^32)
                                 else atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs);
                             }
                             __syncthreads();
@@ -871,8 +872,9 @@ void beam_slab_kernel(BeamArgs g) {
                         }
                     }
                     if (act) {
-                        // (a one-tile read's sums stay below 2^32 — at most 256 cells of weight < 2^24 — so the 32-bit atomic on the low word is the whole add)
-                        if (ntiles == 1) { atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs); atomicAdd((uint32_t*)&r_qd[sidr], (uint32_t)qd); }
+                        // (the sums of a read of fewer than 256 cells stay below 2^32 — the weight of a cell is <= 2^24, with equality from q = 73 on — so the 32-bit
+                        // atomic on the low word is the whole add; a read of exactly 256 cells of weight 1.0 would wrap: ADVICE r5)
+                        if (L < (uint32_t)SLAB_TILE) { atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs); atomicAdd((uint32_t*)&r_qd[sidr], (uint32_t)qd); }
                         else { atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs); atomicAdd((unsigned long long*)&r_qd[sidr], (unsigned long long)qd); }
                         atomicAdd(&r_m[sidr], m);
                     }

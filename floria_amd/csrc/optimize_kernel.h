@@ -899,7 +899,9 @@ void optimize_kernel(OptArgs g) {
                 if (g.release_tried) {
                     // a beam launch of the next ploidy runs beside this launch (tail_overlap): it starts block b's job when it sees tried[b] = p, and reads blk_done[b] then
                     if (stop || p == g.max_ploidy) { __hip_atomic_store(&g.blk_done_w[b], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); g.best_ploidy[b] = best; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                    // (the stores above have completed)
+                    // blk_done / best_ploidy must be visible before tried: a workgroup-scope release emits no vmcnt wait on gfx950, so wait for the
+                    // written-through stores explicitly — no L2 write-back, no invalidate
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(&g.tried[b], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     if (stop || p == g.max_ploidy) { g.blk_done_w[b] = 1; g.best_ploidy[b] = best; }
@@ -907,7 +909,9 @@ void optimize_kernel(OptArgs g) {
                 }
             }
             if (g.stop_at) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                        // mec / num_alleles of (b, p) have completed before the ready bit is set
+                // mec / num_alleles of (b, p) must have reached L2 before the ready bit is set: the sc1 stores above and the atomic below go to different addresses
+                // (different channels) and a workgroup-scope release does not wait for them on gfx950 — an explicit wait for the store acknowledgements
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint32_t have = atomicOr(&g.ready[b], 1u << p) | (1u << p);
                 // (the other ploidy's mec / num_alleles: agent-scope loads in stop_rule_fires, issued after the atomic has returned)
                 for (uint32_t q = p; q <= p + 1 && q <= g.max_ploidy; ++q)

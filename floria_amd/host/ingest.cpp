@@ -684,8 +684,19 @@ void read_bcf(gzFile f, const std::string& vcf_file, std::vector<unsigned char> 
         if (!need(rec, 8)) { if (rec.empty()) break; fail("truncated record header"); }
         const uint32_t l_shared = u32(rec.data()), l_indiv = u32(rec.data() + 4);
         if (l_shared < 24) fail("record shorter than its fixed fields");
+        // only the shared part is parsed: it is bounded (a corrupt or hostile length must become a floria Error, not a bad_alloc), the per-sample part is skipped
+        // in bounded reads instead of being buffered
+        if (l_shared > (64u << 20)) fail("record with a shared part of more than 64 MB");
         rec.clear();
-        if (!need(rec, (size_t)l_shared + l_indiv)) fail("truncated record");
+        if (!need(rec, (size_t)l_shared)) fail("truncated record");
+        {
+            unsigned char skip[1 << 16];
+            for (uint64_t left = l_indiv; left != 0;) {
+                const int r = gzread(f, skip, (unsigned)std::min<uint64_t>(left, sizeof skip));
+                if (r <= 0) fail("truncated record");
+                left -= (uint64_t)r;
+            }
+        }
         const unsigned char* q = rec.data();
         const unsigned char* const end = q + l_shared;
         const int32_t chrom = (int32_t)u32(q), pos0 = (int32_t)u32(q + 4);

@@ -318,7 +318,7 @@ int main(int argc, char** argv) {
         // Fragments whose set was EXTENDED by a mate or a supplementary piece (file_reader.rs:541, 639) or thinned by --ignore-monomorphic (utils_frags.rs:745-755: removals
         // from the built set, tombstones included) iterate in another order, which the pileup does not carry.  Under --arith auto a batch that holds such fragments is phased
         // in the canonical form (one note); --arith reference keeps the running sums and says that the orders of those fragments are an approximation.
-        size_t n_batches_fallback = 0, n_frags_merged = 0;
+        size_t n_batches_fallback = 0, n_batches_approx = 0, n_frags_merged = 0;
         Session* const session_holder = sessions.empty() ? nullptr : sessions[0].get();
         fprintf(stderr, "Preprocessing: BAM header%s %.3fs, VCF + FASTA %.3fs, device %.3fs\n", (!have_e || !have_l) ? " + parameter estimate" : "", t_bam, t_vcf, now_s() - tp);
 
@@ -435,7 +435,8 @@ int main(int argc, char** argv) {
                     fprintf(stderr, "floria-hip: note: %s: their position sets do not iterate in the order of one CIGAR walk, which is what the reference-arithmetic mode emulates; "
                                     "such batches are phased in the canonical form (--arith reference forces the running sums with approximate orders for those fragments)\n",
                             o.ignore_monomorphic ? "--ignore-monomorphic removes positions from the fragments" : "this batch holds fragments merged from mates or supplementary alignments");
-                if (other_orders && arith_opt == "reference" && n_batches == 1)
+                if (other_orders && arith_opt == "reference") ++n_batches_approx;
+                if (other_orders && arith_opt == "reference" && n_batches_approx == 1)
                     fprintf(stderr, "floria-hip: warning: --arith reference with %s: the iteration order of those fragments' position sets is emulated as if built by one CIGAR walk\n",
                             o.ignore_monomorphic ? "--ignore-monomorphic" : "fragments merged from mates or supplementary alignments");
                 for (auto& s : sessions) if (floria_hip_set_option(s->ctx(), "arith", fall_back ? 0 : 1) != 0) throw Error(FLORIA_E_INVALID, floria_hip_last_error());
@@ -504,7 +505,8 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
         if (reference_arith && (n_batches_fallback || n_frags_merged))
-            fprintf(stderr, "Arithmetic: %zu of %zu batches phased in the canonical form (%zu fragments merged from several alignments%s)\n", n_batches_fallback, n_batches, n_frags_merged,
+            fprintf(stderr, "Arithmetic: of %zu batches %zu fell back to the canonical form and %zu were forced through the reference's running sums with approximate set orders "
+                            "(%zu fragments merged from several alignments%s)\n", n_batches, n_batches_fallback, n_batches_approx, n_frags_merged,
                     o.ignore_monomorphic ? "; --ignore-monomorphic" : "");
         if (lp_report)
         fprintf(stderr, "LP: the optimum is not unique for %zu of %zu contigs (%zu of %zu edge flows differ in some other optimal solution); this run used the '%s' vertex, "

@@ -28,6 +28,9 @@ for seed in range(s0, s0 + cnt):
     e = np.minimum(S, s + rng.integers(0, 60, size=nb))
     eps = EPS[int(rng.integers(0, len(EPS)))]
     P, B, sens, stop = int(rng.integers(1, 8)), int(rng.integers(1, 13)), int(rng.integers(1, 4)), int(rng.integers(0, 2))
+    if seed % 8 == 7:             # round 6: the wide beams too (-p <= 8, -n <= 40: BASELINE config 5's shape)
+        wr = np.random.default_rng(77 + seed)
+        P, B = int(wr.integers(5, 9)), int(wr.integers(13, 41))
     # the reference arithmetic's own launch options, at random: every map / every read's set replayed insertion by insertion, tables in HBM, a small claim table
     krng = np.random.default_rng(99 + seed)
     kn = {"arith_replay": int(krng.random() < 0.3), "arith_hbm": int(krng.random() < 0.15), "fx_tags": int(krng.choice([0, 0, 128, 256]))}

@@ -255,3 +255,71 @@ def test_blocks_spanning_more_than_1024_positions_in_reference_arithmetic(arith,
     assert int(pile.last.max() - pile.first.min()) + 1 > 1024
     assert_block_results_equal(ro, rg, "wide block")
     assert ro.min_prune_margin == rg.min_prune_margin
+
+
+@pytest.mark.parametrize("eps", (0.04, 0.0437))
+def test_config5_slice_wide_beam_in_reference_arithmetic(arith, hip_lib, oracle_mod, eps):
+    """VERDICT r5 #3a: BASELINE config 5's shape (-p 8 -n 40: up to 320 states per job, the wide-beam path) in the reference's arithmetic against the
+    oracle's mode 1 — a 5 % slice of the contig (8 strains, ~200 x), every block."""
+    C = synth.CONFIGS[5]
+    c = synth.make_config_contig(5, 0, 0.05)
+    s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
+    assert C["max_ploidy"] == 8 and C["beam"] == 40 and len(s) >= 20
+    ro, rg = both(arith, hip_lib, oracle_mod, c.pileup, s, e, eps, P=C["max_ploidy"], B=C["beam"])
+    assert_block_results_equal(ro, rg, f"config 5 slice eps {eps}")
+    assert ro.min_prune_margin == rg.min_prune_margin
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_wide_beams_on_random_pileups_in_reference_arithmetic(arith, hip_lib, oracle_mod, seed):
+    """-p up to 8 and -n up to 40 on random pileups (the fuzz of rounds 4-5 drew -p <= 7, -n <= 12)."""
+    rng = np.random.default_rng(8800 + seed)
+    pile = random_pileup(rng, int(rng.integers(60, 200)), int(rng.integers(20, 80)), int(rng.integers(3, 9)), max_len=int(rng.integers(8, 40)),
+                         alleles=4 if seed == 3 else 2, q0_frac=0.1 if seed == 2 else 0.0, err=0.1)
+    S = int(pile.last.max())
+    s = np.asarray([1, max(1, S // 3)], np.uint32)
+    e = np.asarray([S, min(S, S // 3 + 30)], np.uint32)
+    P, B = ((8, 40), (8, 13), (6, 40), (7, 25))[seed]
+    ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, NON_DYADIC[seed % 3], P=P, B=B)
+    assert_block_results_equal(ro, rg, f"seed {seed} P {P} B {B}")
+    assert ro.min_prune_margin == rg.min_prune_margin
+
+
+def test_config4_full_size_in_reference_arithmetic(arith, hip_lib, oracle_mod):
+    """VERDICT r5 #3b: the headline workload at full size (2000 contigs, ~14.5k blocks) in the mode the CLI runs at its default epsilon, through the call
+    bench.py's second pass times: properties on every block, 128 random blocks against the oracle's mode 1 bit for bit."""
+    from tests import test_gpu_fullsize as F
+    eps = 0.04
+    C = synth.CONFIGS[4]
+    contigs = [synth.make_config_contig(4, i) for i in range(2000)]
+    bc, bs, be = [], [], []
+    for i, c in enumerate(contigs):
+        s, e = hip_lib.get_range_with_lengths(c.snp_pos, C["block_length"])
+        bc += [i] * len(s); bs += list(s); be += list(e)
+    bc, bs, be = np.array(bc), np.array(bs), np.array(be)
+    arena, parr, _ = hip_lib.pack_pileups([c.pileup for c in contigs])
+    r = arith.phase_pileups_batch(parr, bc, bs, be, hip_lib.make_params(eps, C["max_ploidy"], C["beam"]))
+    arena.free()
+    assert 14000 < r.n_blocks < 15000 and r.min_prune_margin > 1e-9
+    ne = np.diff(r.read_off.astype(np.int64)) > 0
+    assert np.all(r.best_ploidy[ne] >= 1) and np.all(r.best_ploidy <= C["max_ploidy"]) and np.all(r.ploidies_tried >= r.best_ploidy)
+    for p in range(C["max_ploidy"]):
+        assert np.all(r.mec[r.ploidies_tried <= p, p] == 0.0)
+    for blk in range(0, r.n_blocks, 97):
+        ids, part = r.block(blk)
+        assert np.array_equal(ids, F.reads_in_interval(contigs[bc[blk]].pileup, bs[blk], be[blk]))
+        if len(ids):
+            assert part.max() < r.best_ploidy[blk]
+    rng = np.random.default_rng(4404)
+    par = oracle_mod.make_params(eps, C["max_ploidy"], C["beam"])
+    by_contig = {}
+    for blk in rng.choice(r.n_blocks, size=128, replace=False):
+        by_contig.setdefault(int(bc[blk]), []).append(int(blk))
+    for ci, blks in by_contig.items():
+        ro = oracle_mod.phase_blocks(contigs[ci].pileup, bs[blks], be[blks], par, threads=16)
+        for k, blk in enumerate(blks):
+            ids, part = r.block(blk)
+            oid, opart = ro.block(k)
+            assert ro.best_ploidy[k] == r.best_ploidy[blk] and ro.ploidies_tried[k] == r.ploidies_tried[blk], f"block {blk}"
+            assert np.array_equal(oid, ids) and np.array_equal(opart, part), f"block {blk}"
+            assert np.array_equal(ro.mec[k].view(np.uint64), r.mec[blk].view(np.uint64)), f"block {blk}"

@@ -798,3 +798,28 @@ def test_reads_longer_than_the_binomial_table(gpu_ctx, hip_lib, oracle_mod):
     ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(EPS, 3, 6), threads=1)
     rg = gpu_ctx.phase_blocks(pile, s, e, hip_lib.make_params(EPS, 3, 6))
     assert_block_results_equal(ro, rg, "long reads")
+
+
+@pytest.mark.parametrize("mode", (0, 1))
+def test_reads_of_exactly_256_cells_of_weight_one(gpu_ctx, hip_lib, oracle_mod, mode):
+    """w(q) is exactly 1.0 = 2^24 Q24 units from q = 73 on, so a read of exactly 256 cells (one LDS tile) that all agree with a slab sums to 2^32:
+    the per-slab `same` must not be accumulated in 32 bits.  Reads of 255 / 256 / 257 cells at q = 93, both arithmetics."""
+    rng = np.random.default_rng(256)
+    hap = rng.integers(0, 2, size=(2, 300))
+    reads = []
+    for r in range(14):
+        L = (256, 256, 255, 257, 256, 200, 256)[r % 7]
+        snps = np.arange(1, L + 1)
+        al = hap[r % 2, :L].copy()
+        if r >= 10:
+            al[rng.integers(0, L, size=3)] ^= 1
+        reads.append((snps, al, np.full(L, 93)))
+    pile = Pileup.from_reads(reads)
+    gpu_ctx.set_option("arith", mode); oracle_mod.set_arith_mode(mode)
+    try:
+        for eps in (EPS, 0.04):
+            ro, rg = both(gpu_ctx, hip_lib, oracle_mod, pile, [1, 100], [257, 256], eps=eps, P=3, B=10)
+            assert_block_results_equal(ro, rg, f"mode {mode} eps {eps}")
+            assert ro.min_prune_margin == rg.min_prune_margin
+    finally:
+        gpu_ctx.set_option("arith", 0); oracle_mod.set_arith_mode(0)
