@@ -205,7 +205,7 @@ def test_merged_fragments_fall_back_to_the_canonical_form_under_arith_auto(flori
     prefix, out = str(tmp_path / "data"), str(tmp_path / "out2")
     r = subprocess.run([floria_hip, "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", "0.04", "-l", "500"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "phased in the canonical form" in r.stderr and "1 of 1 batches phased in the canonical form" in r.stderr
+    assert "phased in the canonical form" in r.stderr and "of 1 batches 1 fell back to the canonical form" in r.stderr
 
 
 @pytest.mark.parametrize("extra", [("--output-reads",), ("--output-reads", "--gzip-reads", "--extra-trimming")])
