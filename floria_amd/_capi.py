@@ -19,12 +19,12 @@ f64p = C.POINTER(C.c_double)
 
 class CPileup(C.Structure):
     _fields_ = [("read_off", u32p), ("snp", u32p), ("allele", u8p), ("qual", u8p),
-                ("first", u32p), ("last", u32p), ("n_reads", C.c_uint32)]
+                ("first", u32p), ("last", u32p), ("n_reads", C.c_uint32), ("set_order", u32p)]
 
 
 class CPileupPacked(C.Structure):
     _fields_ = [("read_off", u32p), ("first", u32p), ("last", u32p), ("bit_off", u32p),
-                ("present", u8p), ("allele2", u8p), ("qual", u8p), ("n_reads", C.c_uint32)]
+                ("present", u8p), ("allele2", u8p), ("qual", u8p), ("n_reads", C.c_uint32), ("set_order", u32p)]
 
 
 class CParams(C.Structure):

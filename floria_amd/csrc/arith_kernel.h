@@ -293,6 +293,7 @@ struct CellOrderArgs {
     uint64_t  ctrl_bytes, slot_bytes;
     uint64_t* todo;                  // [1 + n_reads] number of reads left to cell_order_kernel, then their global indices
     uint32_t  replay_all;            // (tests) != 0: every read goes the long way
+    uint64_t* bad;                   // ~(the smallest global index of a read whose host-given set_order is not a permutation of its cells), 0 = none
 };
 constexpr uint32_t CO_IDX_MAX = 2048;      // largest set (buckets) the direct kernel takes: u16 entries, 4 KB of LDS per wavefront
 __global__ __launch_bounds__(256) void cell_order_direct_kernel(CellOrderArgs g) {
@@ -307,6 +308,27 @@ __global__ __launch_bounds__(256) void cell_order_direct_kernel(CellOrderArgs g)
         const uint32_t r = (uint32_t)(gr - g.read_prefix[lo]);
         const uint32_t cb = cd.read_off[r], L = cd.read_off[r + 1] - cb;
         if (L == 0) continue;
+        if (cd.set_order) {
+            // The host wrote the set's iteration order down (include/floria_hip.h: a Rust host has the FxHashSet itself; floria-hip emulates merges and removals on
+            // the CPU): a gather.  Checked: every entry indexes one of the read's cells (memory safety, any length) and no cell is named twice (a bitmap in
+            // the wavefront's LDS table, reads of up to 16 * CO_IDX_MAX cells; longer reads are bounds-checked only).
+            const uint32_t* so = cd.set_order + cb;
+            uint2* out = g.ord + g.cell_prefix[lo] + cb;
+            const bool bitmap = L <= 16u * CO_IDX_MAX;
+            uint32_t* const bm = (uint32_t*)s_idx[wid];                          // (the wavefront's position table, as 32-bit words: a bit per cell)
+            if (bitmap) { for (uint32_t x = lane; x < (L + 31u) / 32u; x += 64) bm[x] = 0; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+            bool ok = true;
+            for (uint32_t j0 = 0; j0 < L; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                uint32_t e = j < L ? so[j] : 0u;
+                if (e >= L) { ok = false; e = 0; }
+                if (j < L) out[j] = make_uint2(cd.cell_snp[cb + e], cd.cell_aw[cb + e]);
+                if (bitmap && j < L) { const uint32_t bit = 1u << (e & 31u); if (atomicOr(&bm[e >> 5], bit) & bit) ok = false; }
+            }
+            if (__ballot(!ok) && lane == 0) atomicMax((unsigned long long*)g.bad, (unsigned long long)~gr);      // (max of ~index = the smallest index)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            continue;
+        }
         const uint32_t first = cd.cell_snp[cb], range = cd.cell_snp[cb + L - 1] - first;
         const uint32_t C = fx_buckets_for(L);
         if (range >= C || C > CO_IDX_MAX || L > 65535u || g.replay_all) {       // (wave-uniform)

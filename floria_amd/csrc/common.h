@@ -29,6 +29,7 @@ struct ContigDev {
     const uint32_t* meta;       // [8*n_reads] packed per-read record {cell offset, cell count, first, last, tw1 lo/hi, tw2 lo/hi}: one 32-B load per beam step
     uint32_t        n_reads;
     uint32_t        pad;
+    const uint32_t* set_order;  // [n_cells] or null: host-given iteration order of every read's position set (include/floria_hip.h), used by the reference-arithmetic mode
 };
 
 // A ContigDev is loaded from memory, so hipcc cannot tell that its pointers are global: loads through them would be FLAT loads, which

@@ -1088,6 +1088,7 @@ struct UploadPlan {
     std::vector<std::vector<CopyRun>> chunk_runs;       // snp, allele, qual per chunk
     std::vector<uint32_t> chunk_first;                  // [n_chunks+1] contig boundaries
     std::vector<uint32_t> contig_chunk;                 // [n]
+    std::vector<const uint32_t*> so_dev;                // [n] device copy of the contig's set_order (include/floria_hip.h), null where the host gave none
     bool all_pinned = false;
 };
 
@@ -1102,7 +1103,7 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_
         for (uint32_t i = 0; i < n; ++i) {
             const floria_pileup_packed* q = &pk[i];
             if (q->n_reads && (!q->read_off || !q->first || !q->last || !q->bit_off || !q->present || !q->allele2 || !q->qual)) return fail(FLORIA_E_INVALID, "null pileup field");
-            views[i] = floria_pileup{q->read_off, nullptr, nullptr, q->qual, q->first, q->last, q->n_reads};
+            views[i] = floria_pileup{q->read_off, nullptr, nullptr, q->qual, q->first, q->last, q->n_reads, q->set_order};
         }
         pileups = views.data();
     }
@@ -1138,6 +1139,9 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_
     auto seg = [&](size_t bytes) { const size_t o = cursor; cursor += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_ro = seg(4 * (R + n)), o_first = seg(4 * R), o_last = seg(4 * R), o_snp = seg(4 * C + 16), o_aw = seg(4 * C + 16),      // 16-B tails: the
                  o_tw = seg(16 * R), o_meta = seg(32 * R);                                              // beam kernel's LDS-DMA moves cells in 16-B pieces
+    bool any_so = false;
+    for (uint32_t i = 0; i < n; ++i) any_so = any_so || (pileups[i].n_reads && pileups[i].set_order);
+    const size_t o_so = any_so ? seg(4 * C + 16) : 0;                                                   // host-given set orders (optional, the reference-arithmetic mode reads them)
     Arena* A = P.A = arena_get(ctx, cursor + 256);
     if (!A) return FLORIA_E_NOMEM;
     A->n_contigs = n; A->R = R; A->C = C; A->off_ro = o_ro; A->off_first = o_first; A->off_last = o_last; A->read_prefix = P.rp; A->host_meta = false;
@@ -1179,11 +1183,12 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_
     auto a2_off = [&](uint32_t i) { return (size_t)(P.cp[i] / 4 + i); };       // (every contig's 2-bit array starts on its own byte)
     P.chunk_runs.assign(n_chunks, {});
     for (uint32_t g = 0; g < n_chunks; ++g)
-        for (int kind = 0; kind < 3; ++kind)
+        for (int kind = 0; kind < 4; ++kind)
             for (uint32_t i = P.chunk_first[g]; i < P.chunk_first[g + 1]; ++i) {
                 const floria_pileup* p = &pileups[i];
                 if (!p->n_reads) continue;
                 const uint64_t nc = P.cp[i + 1] - P.cp[i];
+                if (kind == 3) { if (p->set_order) add_run(P.chunk_runs[g], p->set_order, D + o_so + 4 * P.cp[i], 4 * nc); continue; }
                 if (pk) {
                     if (kind == 0) add_run(P.chunk_runs[g], pk[i].present, T + t_pr + pb[i], pb[i + 1] - pb[i] - 1);
                     else if (kind == 1) add_run(P.chunk_runs[g], pk[i].allele2, T + t_a2 + a2_off(i), (nc + 3) / 4);
@@ -1202,6 +1207,8 @@ int plan_upload(floria_hip_ctx* ctx, const floria_pileup* pileups, const floria_
         u.n_reads = pileups[i].n_reads; u.n_cells = (uint32_t)(P.cp[i + 1] - P.cp[i]);
         P.ust[i] = fl::UploadStatus{~0ull, 0, 0, 0, 0};
     }
+    P.so_dev.assign(n, nullptr);
+    for (uint32_t i = 0; i < n; ++i) if (pileups[i].n_reads && pileups[i].set_order) P.so_dev[i] = (const uint32_t*)(D + o_so + 4 * P.cp[i]);
     if (pk) {
         P.upk.resize(n);
         for (uint32_t i = 0; i < n; ++i) {
@@ -1262,6 +1269,7 @@ int finish_upload(floria_hip_ctx* ctx, UploadPlan& P, floria_hip_contig** out) {
         c->max_len = P.ust[i].max_len; c->n_alleles = P.ust[i].max_allele >= 2 ? 4 : 2; c->has_q0 = P.ust[i].has_q0 != 0;
         c->dev.read_off = P.ucd[i].read_off; c->dev.first = P.ucd[i].first; c->dev.last = P.ucd[i].last; c->dev.cell_snp = P.ucd[i].snp;
         c->dev.cell_aw = P.ucd[i].cell_aw; c->dev.tw = P.ucd[i].tw; c->dev.meta = P.ucd[i].meta; c->dev.n_reads = P.ucd[i].n_reads;
+        c->dev.set_order = P.so_dev[i];
         out[i] = c;
     }
     P.A->refs = n;
@@ -1377,7 +1385,7 @@ int floria_hip_pack_pileups_batch(const floria_pileup* in, uint32_t n, void* buf
         }
         ro[R] = (uint32_t)C; bo[R] = (uint32_t)bit;
         if (C) memcpy(qu, p->qual, C);
-        out[i] = floria_pileup_packed{ro, fi, la, bo, pr, a2, qu, p->n_reads};
+        out[i] = floria_pileup_packed{ro, fi, la, bo, pr, a2, qu, p->n_reads, p->set_order};      // (the optional set order is not repacked: the packed pileup points at the caller's array)
     }
     return 0;
 }
@@ -1528,13 +1536,13 @@ namespace {
 // Computed by two launches (round 5: ≈ 130 ms for the 331 M cells of config 4 with the one-thread-per-read table emulation alone) and kept until the context uploads contigs again: S2 after S1, or the next S1 call over the same resident batch, reuses it.
 int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, uint32_t len_max) {
     const uint32_t n_contigs = (uint32_t)cdev.size();
-    std::vector<uint64_t> pre(2 * (size_t)n_contigs + 2, 0);                  // reads before contig c [n+1] | cells before contig c [n]
+    std::vector<uint64_t> pre(2 * (size_t)n_contigs + 3, 0);                  // reads before contig c [n+1] | cells before contig c [n] | [1 pad] | status word of the host-given set orders
     uint64_t cells = 0;
     for (uint32_t i = 0; i < n_contigs; ++i) { pre[i + 1] = pre[i] + cdev[i].n_reads; pre[n_contigs + 1 + i] = cells; cells += n_cells[i]; }
     const uint64_t R_all = pre[n_contigs];
     uint64_t sig = 1469598103934665603ull;                                    // FNV-1a over what identifies the contigs: their device arrays and sizes
     auto mix = [&](uint64_t v) { for (int b = 0; b < 8; ++b) { sig ^= (v >> (8 * b)) & 0xff; sig *= 1099511628211ull; } };
-    for (uint32_t i = 0; i < n_contigs; ++i) { mix((uint64_t)(uintptr_t)cdev[i].cell_snp); mix((uint64_t)(uintptr_t)cdev[i].read_off); mix(cdev[i].n_reads); mix(n_cells[i]); }
+    for (uint32_t i = 0; i < n_contigs; ++i) { mix((uint64_t)(uintptr_t)cdev[i].cell_snp); mix((uint64_t)(uintptr_t)cdev[i].read_off); mix(cdev[i].n_reads); mix(n_cells[i]); mix((uint64_t)(uintptr_t)cdev[i].set_order); }
     if (ctx->ord_epoch == ctx->upload_epoch && ctx->ord_sig == sig && ctx->arith_ord.p && ctx->arith_tab.p) {
         ctx->cur_ord = ctx->arith_ord.as<uint2>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
         return 0;
@@ -1552,6 +1560,7 @@ int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::
         HIPCHK(hipMemsetAsync(ctx->arith_scr.p, 0, 8, ctx->stream));
         fl::CellOrderArgs oa{};
         oa.todo = ctx->arith_scr.as<uint64_t>(); oa.replay_all = ctx->knobs.arith_replay;
+        oa.bad = ctx->arith_tab.as<uint64_t>() + 2 * (size_t)n_contigs + 2;              // (zeroed with the prefix tables above)
         oa.contigs = d_contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
         oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint2>(); oa.scratch = ctx->arith_scr.as<uint8_t>() + todo_bytes; oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
         // a wavefront per read where the home-bucket rule applies (arith_kernel.h), then one thread per read for the rest (none on BASELINE's configs)
@@ -1559,6 +1568,20 @@ int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
         HIPCHK(hipGetLastError());
+        bool any_given = false;
+        for (uint32_t i = 0; i < n_contigs; ++i) any_given = any_given || cdev[i].set_order != nullptr;
+        if (any_given) {                                                       // a host-given order that is not a permutation of a read's cells: refuse the call
+            uint64_t bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, oa.bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (bad) {
+                uint32_t ci = 0;
+                const uint64_t gr = ~bad;
+                while (ci + 1 < n_contigs && pre[ci + 1] <= gr) ++ci;
+                return fail(FLORIA_E_INVALID, "set_order of read " + std::to_string((unsigned long long)(gr - pre[ci])) + (n_contigs > 1 ? " (contig " + std::to_string(ci) + " of the batch)" : std::string())
+                                              + " is not a permutation of the indices of its cells");
+            }
+        }
     }
     ctx->cur_ord = ctx->arith_ord.as<uint2>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
     ctx->ord_epoch = ctx->upload_epoch; ctx->ord_sig = sig;
@@ -1982,6 +2005,7 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
             fl::ContigDev& d = SC.cdev[i];
             d.read_off = UP.ucd[i].read_off; d.first = UP.ucd[i].first; d.last = UP.ucd[i].last; d.cell_snp = UP.ucd[i].snp;
             d.cell_aw = UP.ucd[i].cell_aw; d.tw = UP.ucd[i].tw; d.meta = UP.ucd[i].meta; d.n_reads = n_reads_of(i);
+            d.set_order = UP.so_dev[i];
         }
         SC.len_max = BINOM_NMAX_CAP; SC.nall = 2; SC.any_q0 = false;                      // optimistic plan, verified below
         SC.contig_chunk = UP.contig_chunk.data(); SC.n_chunks = UP.n_chunks; SC.chunk_ev = ctx->ev_chunk;

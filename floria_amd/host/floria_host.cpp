@@ -28,7 +28,19 @@ void Session::load_contig(const std::vector<Frag>& all_frags) {
         for (const auto& kv : f.seq_dict) { snp.push_back(kv.first); al.push_back(kv.second); q.push_back(f.qual_dict.at(kv.first)); }
         off.push_back((uint32_t)snp.size()); first.push_back(f.first_position); last.push_back(f.last_position);
     }
-    floria_pileup p{off.data(), snp.data(), al.data(), q.data(), first.data(), last.data(), (uint32_t)all_frags.size()};
+    // fragments whose position set is not that of one CIGAR walk (merged mates / supplementary pieces, --ignore-monomorphic): the contig carries the replayed orders
+    std::vector<uint32_t> set_order;
+    bool other = false;
+    for (const Frag& f : all_frags) other = other || f.other_set_order();
+    if (other)
+        for (const Frag& f : all_frags)
+            for (SnpPosition sp : f.positions_order()) {
+                const auto it = f.seq_dict.find(sp);
+                if (it == f.seq_dict.end()) throw Error(FLORIA_E_INVALID, "Frag whose position provenance does not match its calls");
+                set_order.push_back((uint32_t)(it - f.seq_dict.begin()));
+            }
+    if (other && set_order.size() != snp.size()) throw Error(FLORIA_E_INVALID, "Frag whose position provenance does not match its calls");
+    floria_pileup p{off.data(), snp.data(), al.data(), q.data(), first.data(), last.data(), (uint32_t)all_frags.size(), other ? set_order.data() : nullptr};
     check(floria_hip_contig_upload(ctx_, &p, &contig_));
     frags_ = &all_frags;
 }
@@ -98,6 +110,102 @@ std::vector<std::vector<HapNode>> generate_hap_graph(Session& s, const std::vect
     return cols;
 }
 
+namespace {
+// std's FxHashSet<SnpPosition> as far as Frag.positions uses it: hashbrown's open-addressing table (x86-64 builds: probe groups of 16 control bytes at triangular
+// strides, 7/8 load factor, growth by re-insertion in bucket order) under fxhash 0.2.1 (key * 0x517cc1b727220a95: low bits pick the first group, the top 7 bits
+// tag the control byte).  Written for this one purpose — reserve, insert (which reserves room for one key BEFORE it looks the key up), removal, iteration in bucket
+// order — and checked against the oracle's table and an independent bucket-list model by tests/test_host_cpu.py / tests/test_order_emulation.py.
+class PositionSet {
+public:
+    size_t size() const { return n_; }
+    void reserve(size_t additional) { if (additional > room_) regrow(std::max(n_ + additional, usable(nb_) + 1)); }
+    void insert(SnpPosition k) {
+        reserve(1);
+        if (lookup(k) != SIZE_MAX) return;
+        const size_t at = first_free(k);
+        tag_[at] = (uint8_t)(hash(k) >> 57); key_[at] = k; ++n_; --room_;
+        mirror(at);
+    }
+    void remove(SnpPosition k) {                         // (nothing is inserted after a removal on this path: whether the bucket becomes EMPTY or a tombstone changes nothing that is observed)
+        const size_t at = lookup(k);
+        if (at == SIZE_MAX) return;
+        tag_[at] = GONE; --n_; mirror(at);
+    }
+    template <class F> void each(F f) const { for (size_t i = 0; i < nb_; ++i) if (!(tag_[i] & 0x80)) f(key_[i]); }
+    void extend(const PositionSet& o) {                  // hashbrown's Extend: the whole size hint into an empty table, half of it (rounded up) otherwise
+        reserve(n_ == 0 ? o.n_ : (o.n_ + 1) / 2);
+        o.each([&](SnpPosition k) { insert(k); });
+    }
+private:
+    static constexpr uint8_t FREE = 0xFF, GONE = 0x80;
+    static constexpr size_t G = 16;
+    std::vector<uint8_t> tag_;                           // nb_ + G control bytes: the first G repeated behind the last bucket
+    std::vector<SnpPosition> key_;
+    size_t nb_ = 0, n_ = 0, room_ = 0;
+    static uint64_t hash(SnpPosition k) { return (uint64_t)k * 0x517cc1b727220a95ull; }
+    static size_t usable(size_t nb) { return nb == 0 ? 0 : (nb <= 8 ? nb - 1 : nb / 8 * 7); }
+    static size_t buckets_for(size_t cap) { if (cap < 4) return 4; if (cap < 8) return 8; size_t b = 1; while (b < cap * 8 / 7) b <<= 1; return b; }
+    void mirror(size_t at) { tag_[((at - G) & (nb_ - 1)) + G] = tag_[at]; }
+    size_t first_free(SnpPosition k) const {
+        const size_t mask = nb_ - 1;
+        for (size_t at = (size_t)hash(k) & mask, step = 0;; step += G, at = (at + step) & mask)
+            for (size_t j = 0; j < G; ++j)
+                if (tag_[at + j] & 0x80) {
+                    size_t hit = (at + j) & mask;
+                    if (!(tag_[hit] & 0x80)) { hit = 0; while (!(tag_[hit] & 0x80)) ++hit; }      // a table smaller than a group: the free byte was padding, the real one is in group 0
+                    return hit;
+                }
+    }
+    size_t lookup(SnpPosition k) const {
+        if (nb_ == 0) return SIZE_MAX;
+        const size_t mask = nb_ - 1;
+        const uint8_t t = (uint8_t)(hash(k) >> 57);
+        for (size_t at = (size_t)hash(k) & mask, step = 0;; step += G, at = (at + step) & mask) {
+            bool open = false;
+            for (size_t j = 0; j < G; ++j) {
+                if (tag_[at + j] == t && key_[(at + j) & mask] == k) return (at + j) & mask;
+                open = open || tag_[at + j] == FREE;
+            }
+            if (open) return SIZE_MAX;
+        }
+    }
+    void regrow(size_t capacity) {
+        PositionSet g;
+        g.nb_ = buckets_for(capacity); g.tag_.assign(g.nb_ + G, FREE); g.key_.assign(g.nb_, 0); g.room_ = usable(g.nb_);
+        for (size_t i = 0; i < nb_; ++i) if (!(tag_[i] & 0x80)) {
+            const size_t at = g.first_free(key_[i]);
+            g.tag_[at] = (uint8_t)(hash(key_[i]) >> 57); g.key_[at] = key_[i]; g.mirror(at); ++g.n_; --g.room_;
+        }
+        *this = std::move(g);
+    }
+};
+// frag_from_record (file_reader.rs:661-733): seq_dict grows as the CIGAR walk inserts ascending SNP positions; positions = seq_dict.keys().collect()
+PositionSet collected_positions(const std::vector<SnpPosition>& ascending) {
+    PositionSet seq_dict, positions;
+    for (SnpPosition k : ascending) seq_dict.insert(k);
+    positions.extend(seq_dict);                         // (HashSet::from_iter is `extend` on an empty set)
+    return positions;
+}
+}  // namespace
+
+std::vector<SnpPosition> Frag::positions_order() const {
+    PositionSet acc;
+    if (position_segments.empty()) {
+        std::vector<SnpPosition> keys;
+        for (const auto& kv : seq_dict) keys.push_back(kv.first);
+        acc = collected_positions(keys);
+    } else {
+        for (size_t i = 0; i < position_segments.size(); ++i) {
+            PositionSet s = collected_positions(position_segments[i]);
+            if (i == 0) acc = std::move(s); else acc.extend(s);
+        }
+    }
+    for (SnpPosition k : removed_positions) acc.remove(k);
+    std::vector<SnpPosition> out;
+    acc.each([&](SnpPosition k) { out.push_back(k); });
+    return out;
+}
+
 // utils_frags::remove_monomorphic_allele (utils_frags.rs:713-772).  phred_scale = 1f32 - 10f32^(-q/10) widened to f64 (:702-711); the
 // per-(SNP, allele) sums only add such weights, all multiples of 2^-24: exact in any order, so the hash-map order of the reference does not matter.
 std::vector<Frag> remove_monomorphic_allele(std::vector<Frag> frags, double error) {
@@ -117,8 +225,14 @@ std::vector<Frag> remove_monomorphic_allele(std::vector<Frag> frags, double erro
     }
     std::vector<Frag> out;
     for (Frag& f : frags) {
+        bool cut = false;
+        for (const auto& kv : f.seq_dict) cut = cut || mono.count(kv.first) != 0;
+        if (cut && f.position_segments.empty()) {            // `positions` keeps the layout it had with the removed keys in it (:745-755): remember them
+            f.position_segments.emplace_back();
+            for (const auto& kv : f.seq_dict) f.position_segments[0].push_back(kv.first);
+        }
         for (auto it = f.seq_dict.begin(); it != f.seq_dict.end();) {
-            if (mono.count(it->first)) { f.qual_dict.erase(it->first); f.snp_pos_to_seq_pos.erase(it->first); it = f.seq_dict.erase(it); } else ++it;
+            if (mono.count(it->first)) { f.removed_positions.push_back(it->first); f.qual_dict.erase(it->first); f.snp_pos_to_seq_pos.erase(it->first); it = f.seq_dict.erase(it); } else ++it;
         }
         if (f.seq_dict.empty()) continue;
         f.first_position = f.seq_dict.begin()->first; f.last_position = f.seq_dict.rbegin()->first;
@@ -153,7 +267,7 @@ std::vector<uint32_t> lpt_assign(const std::vector<double>& costs, uint32_t worl
 }
 
 // ---- Batch: every device stage once for MANY contigs ----------------------------------------------------------------------------------
-Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
+Batch::Batch(Session& s, std::vector<ContigWork>& work, bool with_set_orders) : s_(s), work_(work) {
     // The Frags of all contigs go straight into the COMPACT wire form (floria_pileup_packed: a presence bit per SNP of a read's span, a 2-bit allele and a
     // quality byte per call — a fifth of the CSR bytes on the PCIe link), in ONE pinned buffer laid out field by field at the offsets
     // floria_hip_pack_pileups_batch uses, so that every field of a chunk of contigs is one DMA.  Alleles beyond the 2-bit envelope are refused here.
@@ -169,9 +283,19 @@ Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
         rp[i + 1] = rp[i] + work[i].all_frags.size(); cp[i + 1] = cp[i] + C; pb[i + 1] = pb[i] + (bits + 7) / 8 + 1;
     }
     const uint64_t R = rp[n], C = cp[n];
+    // set orders: only for the contigs that hold a fragment whose position set is not that of one CIGAR walk (every other contig's are emulated on the device)
+    std::vector<char> needs_order(n, 0);
+    uint64_t order_cells = 0;
+    if (with_set_orders)
+        for (size_t i = 0; i < n; ++i) {
+            for (const Frag& f : work[i].all_frags) if (f.other_set_order()) { needs_order[i] = 1; break; }
+            if (needs_order[i]) order_cells += cp[i + 1] - cp[i];
+        }
     size_t cur = 0;
     auto seg = [&](uint64_t bytes) { const size_t o = cur; cur += (size_t)((bytes + 63) & ~(uint64_t)63); return o; };
-    const size_t o_ro = seg(4 * (R + n)), o_bo = seg(4 * (R + n)), o_fi = seg(4 * R), o_la = seg(4 * R), o_pr = seg(pb[n] + 16), o_a2 = seg(C / 4 + n + 16), o_qu = seg(C + 16);
+    const size_t o_ro = seg(4 * (R + n)), o_bo = seg(4 * (R + n)), o_fi = seg(4 * R), o_la = seg(4 * R), o_pr = seg(pb[n] + 16), o_a2 = seg(C / 4 + n + 16), o_qu = seg(C + 16),
+                 o_so = seg(4 * order_cells + 16);
+    uint64_t so_at = 0;
     pinned_ = floria_hip_host_alloc(cur + 64);
     if (!pinned_) throw Error(FLORIA_E_NOMEM, floria_hip_last_error());
     char* B = (char*)pinned_;
@@ -200,7 +324,21 @@ Batch::Batch(Session& s, std::vector<ContigWork>& work) : s_(s), work_(work) {
             bit += (uint64_t)f.last_position - f.first_position + 1;
         }
         ro[fr.size()] = c; bo[fr.size()] = (uint32_t)bit;
-        piles_[i] = floria_pileup_packed{ro, fi, la, bo, pr, a2, qu, (uint32_t)fr.size()};
+        uint32_t* so = nullptr;
+        if (needs_order[i]) {
+            so = (uint32_t*)(B + o_so) + so_at; so_at += c;
+            for (size_t k = 0; k < fr.size(); ++k) {
+                const Frag& f = fr[k];
+                const std::vector<SnpPosition> ord = f.positions_order();
+                if (ord.size() != f.seq_dict.size()) throw Error(FLORIA_E_INVALID, "Frag whose position provenance does not match its calls");
+                for (size_t j = 0; j < ord.size(); ++j) {
+                    const auto it = f.seq_dict.find(ord[j]);
+                    if (it == f.seq_dict.end()) throw Error(FLORIA_E_INVALID, "Frag whose position provenance does not match its calls");
+                    so[ro[k] + j] = (uint32_t)(it - f.seq_dict.begin());
+                }
+            }
+        }
+        piles_[i] = floria_pileup_packed{ro, fi, la, bo, pr, a2, qu, (uint32_t)fr.size(), so};
     }
     handles_.assign(n, nullptr);
 }

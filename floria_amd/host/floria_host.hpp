@@ -119,6 +119,14 @@ struct Frag {
     std::string seq_string[2];                                           // only kept with --output-reads: DnaString::from_acgt_bytes of SEQ (anything but ACGT -> A)
     std::vector<uint8_t> qual_string[2];                                 // QUAL + 33
     FlatMap<SnpPosition, std::pair<uint8_t, GnPosition>> snp_pos_to_seq_pos;
+    // What `positions` (types_structs.rs:79, the FxHashSet the reference's distance loop iterates, utils_frags.rs:35) went through, kept only where it is NOT the
+    // set of one CIGAR walk: the SNP positions of every alignment combine_frags merged into this fragment, in merge order (positions.extend(..), file_reader.rs:541
+    // and :639; segment 0 = the receiving alignment, possibly empty), and the positions --ignore-monomorphic removed afterwards (utils_frags.rs:745-755).
+    // positions_order() replays that on an emulated set; a Batch hands the result to the library as floria_pileup_packed::set_order for the reference-arithmetic mode.
+    std::vector<std::vector<SnpPosition>> position_segments;
+    std::vector<SnpPosition> removed_positions;
+    bool other_set_order() const { return !position_segments.empty() || !removed_positions.empty(); }
+    std::vector<SnpPosition> positions_order() const;                    // the positions in the iteration order of the set
     void update(SnpPosition snp_pos, Genotype geno, uint8_t qual) {      // update_frag, types_structs.rs:286-324
         seq_dict[snp_pos] = geno; qual_dict[snp_pos] = qual;
         if (snp_pos < first_position) first_position = snp_pos;
@@ -337,7 +345,9 @@ struct ContigWork {
 };
 class Batch {
 public:
-    Batch(Session& s, std::vector<ContigWork>& work);                  // marshals the Frags into the pinned compact wire form (floria_pileup_packed)
+    // marshals the Frags into the pinned compact wire form (floria_pileup_packed); with_set_orders: contigs that hold merged or cut-down fragments also get
+    // the iteration orders of their fragments' position sets (set_order: what the reference-arithmetic mode needs to add in the reference's order)
+    Batch(Session& s, std::vector<ContigWork>& work, bool with_set_orders = false);
     ~Batch();
     Batch(const Batch&) = delete;
     Batch& operator=(const Batch&) = delete;

@@ -845,7 +845,12 @@ std::pair<std::vector<Frag>, std::vector<Frag>> ContigIngest::finish() {
             if ((first.flags & F_PAIRED1) == F_PAIRED1) { ff = &first.frag; sf = &second.frag; }
             else if ((first.flags & F_PAIRED2) == F_PAIRED2) { ff = &second.frag; sf = &first.frag; }
             else continue;
-            if (!sf->seq_dict.empty()) ff->merged_positions = true;                        // first_frag.positions.extend(sec_frag.positions) (:541)
+            if (!sf->seq_dict.empty()) {                                                   // first_frag.positions.extend(sec_frag.positions) (:541): remember who brought what
+                ff->merged_positions = true;
+                ff->position_segments.emplace_back(); ff->position_segments.emplace_back();
+                for (const auto& kv : ff->seq_dict) ff->position_segments[0].push_back(kv.first);
+                for (const auto& kv : sf->seq_dict) ff->position_segments[1].push_back(kv.first);
+            }
             for (auto& kv : sf->seq_dict) ff->seq_dict[kv.first] = kv.second;              // extend: the mate's call overwrites
             for (auto& kv : sf->qual_dict) ff->qual_dict[kv.first] = kv.second;
             ff->first_position = std::min(ff->first_position, sf->first_position);
@@ -873,7 +878,12 @@ std::pair<std::vector<Frag>, std::vector<Frag>> ContigIngest::finish() {
             for (size_t i = 0; i < frags.size(); ++i) {
                 if ((int)i == primary) continue;
                 Frag& fr = frags[i].frag;
-                if (!fr.seq_dict.empty()) pf.merged_positions = true;                        // :639
+                if (!fr.seq_dict.empty()) {                                                  // :639
+                    pf.merged_positions = true;
+                    if (pf.position_segments.empty()) { pf.position_segments.emplace_back(); for (const auto& kv : pf.seq_dict) pf.position_segments[0].push_back(kv.first); }
+                    pf.position_segments.emplace_back();
+                    for (const auto& kv : fr.seq_dict) pf.position_segments.back().push_back(kv.first);
+                }
                 for (auto& kv : fr.seq_dict) pf.seq_dict[kv.first] = kv.second;
                 for (auto& kv : fr.qual_dict) pf.qual_dict[kv.first] = kv.second;
                 pf.first_position = std::min(pf.first_position, fr.first_position);

@@ -314,11 +314,11 @@ int main(int argc, char** argv) {
         std::vector<std::unique_ptr<Session>> sessions;
         if (!ingest_only) for (int d : devices) sessions.emplace_back(new Session(d));
         for (auto& s : sessions) if (floria_hip_set_option(s->ctx(), "arith", reference_arith ? 1 : 0) != 0) throw Error(FLORIA_E_INVALID, floria_hip_last_error());
-        // What the reference-arithmetic mode emulates is the iteration order of a position set collected from ONE ascending CIGAR walk (arith_kernel.h: cell_order_kernel).
-        // Fragments whose set was EXTENDED by a mate or a supplementary piece (file_reader.rs:541, 639) or thinned by --ignore-monomorphic (utils_frags.rs:745-755: removals
-        // from the built set, tombstones included) iterate in another order, which the pileup does not carry.  Under --arith auto a batch that holds such fragments is phased
-        // in the canonical form (one note); --arith reference keeps the running sums and says that the orders of those fragments are an approximation.
-        size_t n_batches_fallback = 0, n_batches_approx = 0, n_frags_merged = 0;
+        // The reference-arithmetic mode adds a read's terms in the iteration order of its position set.  For a fragment built from ONE alignment the library emulates that
+        // set on the device (arith_kernel.h); fragments whose set was EXTENDED by a mate or a supplementary piece (file_reader.rs:541, 639) or cut down by
+        // --ignore-monomorphic (utils_frags.rs:745-755) carry what their set went through (Frag::position_segments / removed_positions, ingest.cpp) and a Batch hands
+        // the replayed order to the library (floria_pileup_packed::set_order): round 6; until then such batches fell back to the canonical form under --arith auto.
+        size_t n_batches_orders = 0, n_frags_merged = 0, n_frags_cut = 0;
         Session* const session_holder = sessions.empty() ? nullptr : sessions[0].get();
         fprintf(stderr, "Preprocessing: BAM header%s %.3fs, VCF + FASTA %.3fs, device %.3fs\n", (!have_e || !have_l) ? " + parameter estimate" : "", t_bam, t_vcf, now_s() - tp);
 
@@ -419,6 +419,11 @@ int main(int argc, char** argv) {
                         dump << f.id << "\t" << f.first_position << "\t" << f.last_position << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.is_paired ? 1 : 0);
                         for (const auto& kv : f.seq_dict) dump << "\t" << kv.first << ":" << (int)kv.second << ":" << (int)f.qual_dict.at(kv.first);
                         dump << "\n";
+                        if (f.other_set_order()) {          // the iteration order of its position set, replayed (tests compare it with the oracle's emulation)
+                            dump << "#ORDER";
+                            for (SnpPosition sp : f.positions_order()) dump << "\t" << sp;
+                            dump << "\n";
+                        }
                     }
                     for (const Frag& f : w.frags_without_snps) dump << "#SNPLESS\t" << f.id << "\t" << f.first_pos_base << "\t" << f.last_pos_base << "\t" << (f.seq_len[0] + f.seq_len[1]) << "\n";
                 }
@@ -426,26 +431,16 @@ int main(int argc, char** argv) {
             if (ingest_only || work.empty()) continue;
             ++n_batches;
             if (reference_arith) {
-                size_t merged = 0;
-                for (const ContigWork& w : work) for (const Frag& f : w.all_frags) merged += f.merged_positions ? 1 : 0;
-                n_frags_merged += merged;
-                const bool other_orders = merged != 0 || o.ignore_monomorphic;
-                const bool fall_back = other_orders && arith_opt == "auto";
-                if (fall_back && n_batches_fallback++ == 0)
-                    fprintf(stderr, "floria-hip: note: %s: their position sets do not iterate in the order of one CIGAR walk, which is what the reference-arithmetic mode emulates; "
-                                    "such batches are phased in the canonical form (--arith reference forces the running sums with approximate orders for those fragments)\n",
-                            o.ignore_monomorphic ? "--ignore-monomorphic removes positions from the fragments" : "this batch holds fragments merged from mates or supplementary alignments");
-                if (other_orders && arith_opt == "reference") ++n_batches_approx;
-                if (other_orders && arith_opt == "reference" && n_batches_approx == 1)
-                    fprintf(stderr, "floria-hip: warning: --arith reference with %s: the iteration order of those fragments' position sets is emulated as if built by one CIGAR walk\n",
-                            o.ignore_monomorphic ? "--ignore-monomorphic" : "fragments merged from mates or supplementary alignments");
-                for (auto& s : sessions) if (floria_hip_set_option(s->ctx(), "arith", fall_back ? 0 : 1) != 0) throw Error(FLORIA_E_INVALID, floria_hip_last_error());
+                size_t merged = 0, cut = 0;
+                for (const ContigWork& w : work) for (const Frag& f : w.all_frags) { merged += f.merged_positions ? 1 : 0; cut += f.removed_positions.empty() ? 0 : 1; }
+                n_frags_merged += merged; n_frags_cut += cut;
+                if (merged || cut) ++n_batches_orders;
             }
             // the device stages of a set of contigs on one context: S1 + hap graph in one pipelined call, LP + path peeling on the host (one contig per
             // task), S2, COV / ERR / HAPQ of the final haplosets.  `tm` receives the wall seconds of the four stages.
             auto device_stages = [&](Session& session, std::vector<ContigWork>& part, size_t threads, double* tm) {
                 double t1 = now_s();
-                Batch batch(session, part);
+                Batch batch(session, part, reference_arith);
                 batch.generate_hap_graphs(o);
                 tm[0] += now_s() - t1; t1 = now_s();
                 parallel_for(part.size(), threads, [&](size_t i) {
@@ -504,10 +499,9 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Realignment: %zu calls scored on the device in %.3fs (inside the ingest time)\n", n_realign_device, t_realign);
         fprintf(stderr, "Batches %zu; ingest %.3fs, phasing (upload + S1 + graph) %.3fs, LP + paths %.3fs, S2 %.3fs, COV/ERR/HAPQ %.3fs, writers %.3fs\n", n_batches, t_ingest, t_s1,
                 t_stitch, t_s2, t_stats, t_write);
-        if (reference_arith && (n_batches_fallback || n_frags_merged))
-            fprintf(stderr, "Arithmetic: of %zu batches %zu fell back to the canonical form and %zu were forced through the reference's running sums with approximate set orders "
-                            "(%zu fragments merged from several alignments%s)\n", n_batches, n_batches_fallback, n_batches_approx, n_frags_merged,
-                    o.ignore_monomorphic ? "; --ignore-monomorphic" : "");
+        if (reference_arith && n_batches_orders)
+            fprintf(stderr, "Arithmetic: %zu of %zu batches carried the set orders of fragments that are not one alignment's (%zu merged from several alignments, %zu cut down by "
+                            "--ignore-monomorphic): replayed on the host, every batch phased in the reference's running sums\n", n_batches_orders, n_batches, n_frags_merged, n_frags_cut);
         if (lp_report)
         fprintf(stderr, "LP: the optimum is not unique for %zu of %zu contigs (%zu of %zu edge flows differ in some other optimal solution); this run used the '%s' vertex, "
                         "rerun with --lp-tie %s to see what depends on it\n", lp_not_unique.load(), lp_contigs.load(), lp_movable.load(), lp_edges.load(),

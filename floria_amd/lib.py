@@ -145,7 +145,8 @@ def pin_pileups(pileups):
     what a host that marshals `Vec<Frag>` into upload buffers writes directly.  Returns (arena, [Pileup views])."""
     nr = sum(p.n_reads for p in pileups)
     nc = sum(p.n_cells for p in pileups)
-    arena = PinnedArena(4 * (nr + len(pileups)) + 8 * nr + 6 * nc + 256)
+    with_order = any(p.set_order is not None for p in pileups)
+    arena = PinnedArena(4 * (nr + len(pileups)) + 8 * nr + (10 if with_order else 6) * nc + 256)
     fields = {}
     for name, dt in (("read_off", np.uint32), ("first", np.uint32), ("last", np.uint32), ("snp", np.uint32), ("allele", np.uint8), ("qual", np.uint8)):
         views = []
@@ -156,6 +157,12 @@ def pin_pileups(pileups):
             views.append(v)
         fields[name] = views
     out = [Pileup(fields["read_off"][i], fields["snp"][i], fields["allele"][i], fields["qual"][i], fields["first"][i], fields["last"][i]) for i in range(len(pileups))]
+    if with_order:
+        for p, o in zip(pileups, out):
+            if p.set_order is not None:
+                v = arena.take(p.n_cells, np.uint32)
+                v[:] = np.ascontiguousarray(p.set_order, np.uint32)
+                o.set_order = v
     return arena, out
 
 

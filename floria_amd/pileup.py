@@ -19,6 +19,7 @@ class Pileup:
     qual: np.ndarray      # uint8  [n_cells]
     first: np.ndarray     # uint32 [n_reads]
     last: np.ndarray      # uint32 [n_reads]
+    set_order: np.ndarray = None   # optional uint32 [n_cells]: per read, the indices of its cells in the iteration order of Frag.positions (include/floria_hip.h)
 
     @property
     def n_reads(self):
@@ -34,10 +35,14 @@ class Pileup:
                          ("qual", np.uint8), ("first", np.uint32), ("last", np.uint32)):
             a = np.ascontiguousarray(getattr(self, name), dtype=dt)
             setattr(self, name, a)
+        so = None
+        if self.set_order is not None:
+            self.set_order = np.ascontiguousarray(self.set_order, dtype=np.uint32)
+            so = capi.ptr(self.set_order, capi.C.c_uint32)
         return capi.CPileup(capi.ptr(self.read_off, capi.C.c_uint32), capi.ptr(self.snp, capi.C.c_uint32),
                             capi.ptr(self.allele, capi.C.c_uint8), capi.ptr(self.qual, capi.C.c_uint8),
                             capi.ptr(self.first, capi.C.c_uint32), capi.ptr(self.last, capi.C.c_uint32),
-                            self.n_reads)
+                            self.n_reads, so)
 
     def read(self, r):
         lo, hi = int(self.read_off[r]), int(self.read_off[r + 1])

@@ -86,7 +86,7 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
     for i, q in enumerate(snp_pos):
         other[i] = [b for b in BASES if b != ref[q] and b != alt[i]][0]
     paired = lay["kind"] == "short"
-    out_reads, recs, qual_by_name = [], [], {}
+    out_reads, recs, qual_by_name, seg_by_name = [], [], {}, {}
     for r in range(p.n_reads):
         snps, als, quals = p.read(r)
         cell = {int(s) - 1: (int(a), int(q)) for s, a, q in zip(snps, als, quals)}          # SNP index -> (allele, qual)
@@ -96,7 +96,7 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
         segs = [(min(b, clen - 1), e) for b, e in segs]       # (a mate that starts beyond the contig's last base is one base at its end: a record with CIGAR 1M needs one base of SEQ)
         name = f"{contig.name}_r{r}"
         lost = set()
-        recs_r, quals_r = [], []
+        recs_r, quals_r, seg_snps = [], [], []
         for k, (b, e) in enumerate(segs):
             e = max(e, b + 1)
             seq = ref[b:e].copy()
@@ -136,11 +136,13 @@ def contig_dataset(contig, rng, edit_frac=0.1, mapq=60, sub_rate=0.0):
                 flag = 1 | 2 | (64 | 32 if k == 0 else 128 | 16)
             recs_r.append((pos, bam_record(0, pos, name, flag, mapq, cigar, bytes(seq), qual), bytes(seq), cigar))
             quals_r.append(bytes(qual))
+            seg_snps.append([i + 1 for i in range(lo, hi) if i in cell and i not in lost])      # the SNPs THIS alignment calls (its own seq_dict, file_reader.rs:702-727)
         cells = [(i + 1, a, q) for i, (a, q) in sorted(cell.items()) if i not in lost]
         span = (min(b for b, _ in segs), min(max(e, b + 1) for b, e in segs)) if paired else (segs[0][0], max(segs[0][1], segs[0][0] + 1))
         out_reads.append((name, cells, span, recs_r, sum(max(e, b + 1) - b for b, e in segs)))
         qual_by_name[name] = quals_r
-    return dict(quals=qual_by_name, ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
+        seg_by_name[name] = seg_snps
+    return dict(segments=seg_by_name, quals=qual_by_name, ref=bytes(ref), snps=[(int(q), chr(ref[q]), chr(alt[i])) for i, q in enumerate(snp_pos)], reads=out_reads, contig_len=clen)
 
 
 def nw_affine_batch(Q, R, match=1, mismatch=-1, gap_open=-2, gap_extend=-1, band=None):
@@ -226,7 +228,7 @@ def realign_dataset(d, flank=16):
 def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, realign=True, sub_rate=0.0):
     """Write {prefix}.bam / .vcf / .fa for a list of synth Contigs (keep_layout=True).  With realign=False the returned pileups hold the
     calls as sequenced (floria-hip --no-realign).  Returns, per contig name,
-    dict(pileup=Pileup in the order a correct ingest produces, names=[read name], spans=[(first_pos_base, last_pos_base)],
+    dict(pileup=Pileup in the order a correct ingest produces, names=[read name], spans=[(first_pos_base, last_pos_base)], segments=[[SNPs of alignment k]],
          snp_pos0=[0-based genome position of every SNP], contig_len, seq_len=[bases of every read])."""
     rng = np.random.default_rng(seed)
     targets, all_recs, expect = [], [], {}
@@ -278,6 +280,9 @@ def write_dataset(prefix, contigs, seed=0, extra_vcf_lines=True, edit_frac=0.1, 
         by_name = {nm: (recs_r, d["quals"][nm]) for nm, _, _, recs_r, _ in reads}
         expect[c.name] = dict(pileup=pile, names=[names[i] for i in perm], spans=[spans[i] for i in perm], seq_len=[slens[i] for i in perm],
                               paired=c.layout["kind"] == "short",
+                              # per read (pileup order): the SNPs of every alignment in the order combine_frags merges them (first in pair, then its mate,
+                              # file_reader.rs:504-541) - what Frag.positions is built from; a single alignment's list for unpaired reads
+                              segments=[d["segments"][nm] for nm in (names[i] for i in perm)],
                               read_alignments={nm: [(pos, seq, cig, q) for (pos, _rec, seq, cig), q in zip(*by_name[nm])] for nm in by_name},
                               snp_pos0=np.array([q for q, _, _ in d["snps"]], np.uint64), contig_len=d["contig_len"],
                               snpless=[(nm, sp, sl) for nm, cells, sp, _, sl in reads if not cells],

@@ -58,6 +58,14 @@ typedef struct {
     const uint32_t* first;     /* [n_reads]   first_position                    */
     const uint32_t* last;      /* [n_reads]   last_position                     */
     uint32_t        n_reads;
+    /* OPTIONAL (NULL = not given): the iteration order of every read's `positions` set — `for pos in r.positions.iter()`, utils_frags.rs:35 — for the
+     * reference-arithmetic mode (floria_hip_set_option "arith" = 1), which adds a read's terms in that order.  set_order[read_off[r] + j] = index within
+     * read r (0-based, in the ascending-SNP order of its cells) of the cell whose position the set yields j-th: a permutation of 0 .. L_r - 1 per read
+     * (checked on the device; FLORIA_E_INVALID otherwise).  A Rust host writes it down while it marshals a Frag (it HAS the FxHashSet: whatever built it —
+     * one CIGAR walk, `positions.extend(mate.positions)` of combine_frags, file_reader.rs:539-541 and :636-639, the removals of --ignore-monomorphic,
+     * utils_frags.rs:745-755 — is in that order by construction).  With NULL the library emulates the set of ONE CIGAR walk (seq_dict.keys().collect(),
+     * file_reader.rs:729-733; csrc/arith_kernel.h), which is what every fragment built from a single alignment has.  Ignored in arithmetic mode 0. */
+    const uint32_t* set_order; /* [n_cells] or NULL */
 } floria_pileup;
 
 /* The same pileup in the compact wire form SURVEY.md §8(d) counts (per read: first, last; a presence bit per SNP of its span; a 2-bit
@@ -78,6 +86,7 @@ typedef struct {
     const uint8_t*  allele2;   /* [ceil(n_cells / 4)]                                   */
     const uint8_t*  qual;      /* [n_cells]                                             */
     uint32_t        n_reads;
+    const uint32_t* set_order; /* [n_cells] or NULL: as in floria_pileup (travels as it is, 4 B per cell, only when given) */
 } floria_pileup_packed;
 
 /* The fields of `Options` (types_structs.rs:20-51) the hot path reads

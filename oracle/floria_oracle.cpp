@@ -370,12 +370,17 @@ inline double sd_diff(const SD& d, double eps) { return g_arith_mode.load(std::m
 // Frag.positions (file_reader.rs:729-733) = seq_dict.keys().collect::<FxHashSet<_>>(): seq_dict is an FxHashMap filled in ascending
 // order by the CIGAR walk (:661-727, growing as it goes); `collect` reserves room for all keys at once and inserts them in the map's
 // iteration order; iterating the set then walks ITS buckets.  -> for every read the permutation of its cells in that order.
-// (Mates and supplementary alignments merged by combine_frags extend the first alignment's set by the second's, :540-542; the pileup
-// does not say which cell came from which alignment, so such reads are emulated as one alignment.)
+// (Mates and supplementary alignments merged by combine_frags extend the first alignment's set by the second's, :540-542, and --ignore-monomorphic
+// removes positions from the set, utils_frags.rs:745-755: a pileup that carries such fragments says what its sets iterate like in `set_order`
+// (include/floria_hip.h), which is then used as given — positions_order below restates how such a set comes about.)
 inline std::vector<uint32_t> build_cell_order(const floria_pileup* p) {
     std::vector<uint32_t> ord(p->read_off[p->n_reads]);
     if (g_arith_mode.load() == 2) {                            // mode 2: running sums with every container iterated in ASCENDING key order (tests/test_py_restatement.py)
         for (uint32_t c = 0; c < (uint32_t)ord.size(); ++c) ord[c] = c;
+        return ord;
+    }
+    if (p->set_order) {                                        // the host's own iteration order (validated as a permutation per read by validate())
+        for (uint32_t r = 0; r < p->n_reads; ++r) for (uint32_t c = p->read_off[r]; c < p->read_off[r + 1]; ++c) ord[c] = p->read_off[r] + p->set_order[c];
         return ord;
     }
     for (uint32_t r = 0; r < p->n_reads; ++r) {
@@ -978,8 +983,42 @@ int validate(const floria_pileup* p) {
             bool ok = p->first[r - 1] < p->first[r] || (p->first[r - 1] == p->first[r] && p->last[r - 1] >= p->last[r]);
             if (!ok) { g_err = "reads not sorted by Frag::cmp"; return FLORIA_E_INVALID; }
         }
+        if (p->set_order) {
+            std::vector<uint8_t> seen(e - b, 0);
+            for (uint32_t c = b; c < e; ++c) {
+                const uint32_t x = p->set_order[c];
+                if (x >= e - b || seen[x]) { g_err = "set_order of read " + std::to_string(r) + " is not a permutation of the indices of its cells"; return FLORIA_E_INVALID; }
+                seen[x] = 1;
+            }
+        }
     }
     return 0;
+}
+
+// Frag.positions of a fragment that combine_frags merged from several alignments (file_reader.rs:491-659) and / or that --ignore-monomorphic cut down
+// (utils_frags.rs:745-755), as the reference's containers build it:
+//   * every alignment's own set: seq_dict (an FxHashMap growing as the CIGAR walk inserts ascending SNP positions, :702-727) -> keys().collect(), i.e. an
+//     empty set extended by the map's keys in the map's bucket order (`HashSet::from_iter` = extend on an empty set: reserve(size_hint) = all keys at once;
+//     an alignment without SNPs leaves the unallocated empty set);
+//   * `first.positions.extend(other.positions)` (:541, :639) in merge order: hashbrown's Extend reserves the whole hint when the receiving set is EMPTY and
+//     (hint + 1) / 2 otherwise, then `insert`s the other set's keys in ITS bucket order — insert reserves room for one key before it looks the key up
+//     (find_or_find_insert_slot), so a key both mates cover can still grow a full table;
+//   * `positions.remove(pos)` for every removed position: the freed bucket becomes EMPTY or a tombstone, no other key moves.
+// -> the positions in the final set's bucket order.
+std::vector<uint32_t> positions_order(const uint32_t* seg_keys, const uint32_t* seg_off, uint32_t n_seg, const uint32_t* removed, uint32_t n_removed) {
+    FxSet acc;
+    for (uint32_t sgi = 0; sgi < n_seg; ++sgi) {
+        const uint32_t b = seg_off[sgi], e = seg_off[sgi + 1];
+        FxSet seq_dict, positions;
+        for (uint32_t c = b; c < e; ++c) seq_dict.insert(seg_keys[c]);
+        if (e > b) { positions.reserve(e - b); seq_dict.for_each([&](uint64_t pos) { positions.insert(pos); }); }
+        if (sgi == 0) { acc = std::move(positions); continue; }
+        const size_t hint = positions.items;
+        acc.reserve(acc.items == 0 ? hint : (hint + 1) / 2);
+        positions.for_each([&](uint64_t pos) { acc.insert(pos); });
+    }
+    for (uint32_t i = 0; i < n_removed; ++i) acc.remove(removed[i]);
+    return acc.order();
 }
 
 }  // namespace
@@ -1000,6 +1039,13 @@ int floria_oracle_fxset_order(const int64_t* ops, uint32_t n_ops, uint32_t* out,
     FxSet s;
     for (uint32_t i = 0; i < n_ops; ++i) { if (ops[i] > 0) s.insert((uint64_t)(ops[i] - 1)); else if (ops[i] < 0) s.remove((uint64_t)(-ops[i] - 1)); }
     const auto o = s.order();
+    for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+    *n_out = (uint32_t)o.size();
+    return 0;
+}
+// Frag.positions of a merged / cut-down fragment (positions_order above): segment s = the SNP positions of alignment s, ascending, in merge order
+int floria_oracle_positions_order(const uint32_t* seg_keys, const uint32_t* seg_off, uint32_t n_seg, const uint32_t* removed, uint32_t n_removed, uint32_t* out, uint32_t* n_out) {
+    const auto o = positions_order(seg_keys, seg_off, n_seg, removed, n_removed);
     for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
     *n_out = (uint32_t)o.size();
     return 0;

@@ -199,6 +199,29 @@ def fxset_order(ops):
     return out[:n.value].copy()
 
 
+def positions_order(segments, removed=()):
+    """Iteration order (SNP positions) of Frag.positions for a fragment merged from `segments` — the ascending SNP positions of every alignment, in merge
+    order (combine_frags, file_reader.rs:491-659) — after the positions in `removed` were taken out (--ignore-monomorphic, utils_frags.rs:745-755)."""
+    keys = np.ascontiguousarray(np.concatenate([np.asarray(s, np.uint32) for s in segments]) if len(segments) else np.zeros(0, np.uint32), np.uint32)
+    off = np.zeros(len(segments) + 1, np.uint32)
+    off[1:] = np.cumsum([len(s) for s in segments])
+    rem = np.ascontiguousarray(removed, np.uint32)
+    out = np.zeros(max(1, len(keys)), np.uint32)
+    n = C.c_uint32(0)
+    _check(lib().floria_oracle_positions_order(capi.ptr(keys, C.c_uint32), capi.ptr(off, C.c_uint32), C.c_uint32(len(segments)), capi.ptr(rem, C.c_uint32), C.c_uint32(len(rem)),
+                                              capi.ptr(out, C.c_uint32), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def set_order_of(cell_snps, segments, removed=()):
+    """the `set_order` entries of one read (include/floria_hip.h): index of every cell of `cell_snps` (ascending) in the iteration order of its position set"""
+    order = positions_order(segments, removed)
+    cell_snps = np.asarray(cell_snps, np.uint32)
+    idx = np.searchsorted(cell_snps, order)
+    assert len(order) == len(cell_snps) and np.array_equal(cell_snps[idx], order)
+    return idx.astype(np.uint32)
+
+
 def fxset_entry_order(keys):
     """iteration order and bucket count of an FxHashMap filled with `entry(key).or_insert(..)` per key (utils_frags.rs:165)"""
     keys = np.ascontiguousarray(keys, np.uint64)

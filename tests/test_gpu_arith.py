@@ -323,3 +323,43 @@ def test_config4_full_size_in_reference_arithmetic(arith, hip_lib, oracle_mod):
             assert ro.best_ploidy[k] == r.best_ploidy[blk] and ro.ploidies_tried[k] == r.ploidies_tried[blk], f"block {blk}"
             assert np.array_equal(oid, ids) and np.array_equal(opart, part), f"block {blk}"
             assert np.array_equal(ro.mec[k].view(np.uint64), r.mec[blk].view(np.uint64)), f"block {blk}"
+
+
+@pytest.mark.parametrize("eps", (0.04, 0.0437))
+def test_paired_fragments_with_host_given_set_orders(arith, hip_lib, oracle_mod, tmp_path, eps):
+    """BASELINE config 3's shape (paired short reads) at a non-dyadic epsilon with the iteration order of every fragment's position set GIVEN
+    (floria_pileup::set_order): the first mate's set extended by the second's, as combine_frags builds it (file_reader.rs:539-541).  S1 and S2 against the oracle's
+    mode 1 with the same orders, through the resident, the CSR host-pileup and the packed host-pileup entry points; a set_order that is not a permutation is refused."""
+    from floria_amd import synth_bam
+    from tests.test_gpu_parity import groups_from_blocks
+    for idx in (2, 5):
+        c = synth.make_config_contig(3, idx, 0.2, keep_layout=True)
+        ex = synth_bam.write_dataset(str(tmp_path / f"d{idx}"), [c], seed=3)[c.name]
+        pile = ex["pileup"]
+        pile.set_order = np.concatenate([oracle_mod.set_order_of(pile.read(i)[0], [np.asarray(x, np.uint32) for x in ex["segments"][i]]) for i in range(pile.n_reads)])
+        s, e = hip_lib.get_range_with_lengths(ex["snp_pos0"], 500)
+        ro, rg = both(arith, hip_lib, oracle_mod, pile, s, e, eps)
+        assert_block_results_equal(ro, rg, f"contig {idx} eps {eps}")
+        assert ro.min_prune_margin == rg.min_prune_margin
+        bc = np.zeros(len(s), np.uint32)
+        par = hip_lib.make_params(eps)
+        arena, pinned = hip_lib.pin_pileups([pile])
+        rp = arith.phase_pileups_batch(pinned, bc, s, e, par)
+        arena.free()
+        assert_block_results_equal(ro, rp, "CSR host pileups")
+        arena, parr, _ = hip_lib.pack_pileups([pile])
+        rk = arith.phase_pileups_batch(parr, bc, s, e, par)
+        arena.free()
+        assert_block_results_equal(ro, rk, "packed host pileups")
+        groups, ranges = groups_from_blocks(rg, s, e)
+        go = oracle_mod.reassign(pile, groups, ranges, eps)
+        gg = arith.reassign(pile, groups, ranges, eps)
+        assert go.n_groups == gg.n_groups and np.array_equal(go.range, gg.range) and np.array_equal(go.grp_off, gg.grp_off) and np.array_equal(go.grp_read, gg.grp_read)
+    bad = pile.set_order.copy()
+    two = int(np.nonzero(np.diff(pile.read_off) >= 2)[0][0])
+    bad[int(pile.read_off[two])] = bad[int(pile.read_off[two]) + 1]
+    pile.set_order = bad
+    with pytest.raises(hip_lib.FloriaHipError, match="set_order of read"):
+        arith.phase_blocks(pile, s, e, hip_lib.make_params(eps))
+    pile.set_order = None
+    arith.phase_blocks(pile, s, e, hip_lib.make_params(eps))          # (and the context is usable afterwards)

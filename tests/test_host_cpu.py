@@ -348,6 +348,47 @@ def test_ignore_monomorphic(floria_hip, tmp_path):
     assert [g["first"] for g in filt] == [x[4][0][0] for x in want] and [g["last"] for g in filt] == [x[4][-1][0] for x in want]
 
 
+def test_position_sets_of_merged_and_cut_down_fragments_are_replayed(floria_hip, oracle_mod, tmp_path):
+    """a pair's position set is the first mate's extended by the second's (file_reader.rs:539-541) and --ignore-monomorphic removes keys from the built
+    set (utils_frags.rs:745-755): the host keeps what every such set went through and replays it (Frag::positions_order, floria_host.cpp) - compared here, read by
+    read, with the oracle's emulation of the same sequence of container operations (which tests/test_order_emulation.py pins against an independent model)."""
+    c = synth.make_config_contig(3, 2, 0.3, keep_layout=True)
+    prefix = str(tmp_path / "p")
+    ex = synth_bam.write_dataset(prefix, [c], seed=11)[c.name]
+    got, _ = ingest(floria_hip, prefix, tmp_path)
+    reads = got[c.name]["reads"]
+    assert [g["name"] for g in reads] == ex["names"]
+    n_merged = n_not_one_walk = 0
+    for g, segs in zip(reads, ex["segments"]):
+        keys = [x[0] for x in g["cells"]]
+        if len(segs) == 2 and len(segs[1]):                     # the mate brought SNPs: `extend` ran
+            n_merged += 1
+            want = oracle_mod.positions_order([np.asarray(s, np.uint32) for s in segs]).tolist()
+            assert g["order"] == want, g["name"]
+            assert sorted(want) == keys
+            n_not_one_walk += want != oracle_mod.positions_order([np.asarray(keys, np.uint32)]).tolist()
+        else:
+            assert "order" not in g
+    assert n_merged > 500 and n_not_one_walk > 0
+    # long reads under --ignore-monomorphic: the removed positions stay in the replay as removals
+    c1 = synth.make_config_contig(1, 0, keep_layout=True)
+    prefix = str(tmp_path / "m")
+    synth_bam.write_dataset(prefix, [c1], seed=5, realign=False)
+    plain, _ = ingest(floria_hip, prefix, tmp_path, extra=("--no-realign", "-e", "0.03125"))
+    filt, _ = ingest(floria_hip, prefix, tmp_path, extra=("--no-realign", "-e", "0.03125", "--ignore-monomorphic"))
+    before = {g["name"]: [x[0] for x in g["cells"]] for g in plain[c1.name]["reads"]}
+    n_cut = 0
+    for g in filt[c1.name]["reads"]:
+        keys, orig = [x[0] for x in g["cells"]], before[g["name"]]
+        if len(keys) == len(orig):
+            assert "order" not in g
+            continue
+        n_cut += 1
+        removed = sorted(set(orig) - set(keys))
+        assert g["order"] == oracle_mod.positions_order([np.asarray(orig, np.uint32)], np.asarray(removed, np.uint32)).tolist(), g["name"]
+    assert n_cut > 50
+
+
 def test_hand_built_alignments_flags_cigar_ops_and_supplementary_merging(floria_hip, tmp_path):
     """Records the generator never writes, expectations derived by hand from file_reader.rs: alignment_passed_check (:184-235: paired
     or low-MAPQ supplementary, MAPQ, error flags, secondary), the CIGAR walk over = X N D I S H (:661-727), allele index of a multi-allelic
@@ -425,6 +466,9 @@ def test_hand_built_alignments_flags_cigar_ops_and_supplementary_merging(floria_
     assert cells["C_skipN"] == [(11, 1), (12, 1), (17, 1), (18, 1)]
     assert cells["D_supp_near"] == [(41, 1), (42, 1), (43, 1), (49, 1), (50, 1)]
     assert got["D_supp_near"]["span"] == (20900, 22100)                       # first_pos_base = min, last_pos_base = min (:635-636)
+    from oracle import oracle as _orc                                         # the merged set: the primary's positions extended by the supplementary piece's (:639)
+    assert got["D_supp_near"]["order"] == _orc.positions_order([np.asarray([41, 42, 43], np.uint32), np.asarray([49, 50], np.uint32)]).tolist()
+    assert "order" not in got["A_plain"] and "order" not in got["E_supp_far"]
     assert cells["E_supp_far"] == [(61, 1), (62, 1)]
     assert cells["G_supp_lowq"] == [(89, 1), (90, 1)]
     assert cells["J_multi"] == [(21, 2), (22, 1), (23, 0)]

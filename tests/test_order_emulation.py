@@ -178,3 +178,165 @@ def test_home_bucket_rule_against_the_emulated_tables():
         assert nb == 32 and sorted(a.tolist()) == sorted(b.tolist())
         differs += a.tolist() != b.tolist()
     assert differs > 40
+
+
+class ModelTable:
+    """Independent restatement (a Python list of buckets, no control bytes) of what Frag.positions goes through when fragments are merged: `reserve`,
+    `insert` with its reserve-one-before-the-lookup, removal, iteration.  (Nothing is inserted after a removal on this path, so a freed bucket never needs
+    to remember whether it became EMPTY or a tombstone.)"""
+
+    def __init__(self):
+        self.tab, self.items, self.room = [], 0, 0
+
+    @staticmethod
+    def buckets_for(cap):
+        if cap < 8:
+            return 4 if cap < 4 else 8
+        b = 1
+        while b < cap * 8 // 7:
+            b <<= 1
+        return b
+
+    @staticmethod
+    def usable(nb):
+        return 0 if nb == 0 else (nb - 1 if nb - 1 < 8 else nb // 8 * 7)
+
+    @staticmethod
+    def place(tab, k):
+        nb = len(tab)
+        pos, stride = ((k * K) & M64) & (nb - 1), 0
+        while True:
+            free = [tab[i] is None for i in range(nb)]
+            ctrl = free + [True] * (16 - nb) + free if nb < 16 else free + free[:16]
+            hit = next((b for b in range(16) if ctrl[pos + b]), None)
+            if hit is not None:
+                idx = (pos + hit) & (nb - 1)
+                if tab[idx] is not None:
+                    idx = next(i for i in range(16) if ctrl[i])
+                tab[idx] = k
+                return
+            stride += 16
+            pos = (pos + stride) & (nb - 1)
+
+    def grow(self, capacity):
+        new = [None] * self.buckets_for(capacity)
+        for x in self.tab:
+            if x is not None:
+                self.place(new, x)
+        self.tab, self.room = new, self.usable(len(new)) - self.items
+
+    def reserve(self, additional):
+        if additional > self.room:
+            self.grow(max(self.items + additional, self.usable(len(self.tab)) + 1))
+
+    def insert(self, k):
+        self.reserve(1)                       # hashbrown: find_or_find_insert_slot reserves before it looks
+        if k in self.tab:
+            return
+        self.place(self.tab, k); self.items += 1; self.room -= 1
+
+    def extend(self, other):                  # hashbrown's Extend for HashMap: the whole hint into an empty map, half of it (rounded up) otherwise
+        keys = other.order()
+        self.reserve(len(keys) if self.items == 0 else (len(keys) + 1) // 2)
+        for k in keys:
+            self.insert(k)
+
+    def remove(self, k):
+        self.tab[self.tab.index(k)] = None; self.items -= 1
+
+    def order(self):
+        return [x for x in self.tab if x is not None]
+
+    @classmethod
+    def collected(cls, ascending_keys):       # frag_from_record: seq_dict grows key by key, positions = seq_dict.keys().collect()
+        seq = cls()
+        for k in ascending_keys:
+            seq.insert(k)
+        s = cls()
+        s.extend(seq)
+        return s
+
+
+def model_positions_order(segments, removed=()):
+    acc = None
+    for seg in segments:
+        s = ModelTable.collected(seg)
+        if acc is None:
+            acc = s
+        else:
+            acc.extend(s)
+    for k in removed:
+        acc.remove(k)
+    return acc.order()
+
+
+def test_positions_of_merged_fragments_against_the_independent_model():
+    """`first_frag.positions.extend(sec_frag.positions)` (file_reader.rs:539-541, 636-639) and the removals of --ignore-monomorphic
+    (utils_frags.rs:745-755) — the oracle's emulation (control bytes, tombstones) against the list-of-buckets model above: pairs of short mates (disjoint,
+    overlapping, one mate without SNPs), long reads with supplementary pieces, scattered positions with real collisions, exactly-full tables."""
+    rng = np.random.default_rng(2024)
+    n_diff = 0
+    for trial in range(400):
+        kind = trial % 5
+        base = int(rng.integers(1, 50000))
+        if kind == 0:        # a pair: 1-6 SNPs per mate, the second mate behind the first or overlapping it
+            a = np.sort(rng.choice(np.arange(base, base + 12), size=int(rng.integers(1, 7)), replace=False))
+            b = np.sort(rng.choice(np.arange(base + int(rng.integers(0, 14)), base + 30), size=int(rng.integers(1, 7)), replace=False))
+            segs = [a, b]
+        elif kind == 1:      # one mate carries no SNP
+            a = np.sort(rng.choice(np.arange(base, base + 40), size=int(rng.integers(1, 20)), replace=False))
+            segs = [np.zeros(0, np.int64), a] if trial % 2 else [a, np.zeros(0, np.int64)]
+        elif kind == 2:      # a long read with two or three supplementary pieces
+            segs, at = [], base
+            for _ in range(int(rng.integers(2, 5))):
+                n = int(rng.integers(3, 160))
+                segs.append(np.sort(rng.choice(np.arange(at, at + 2 * n), size=n, replace=False)))
+                at += int(rng.integers(n, 4 * n))
+        elif kind == 3:      # scattered positions: more span than buckets, collisions in every table
+            segs = [np.sort(rng.choice(np.arange(base, base + 6000), size=int(rng.integers(2, 120)), replace=False)) for _ in range(int(rng.integers(2, 4)))]
+        else:                # receiving set exactly full (3 / 7 / 14 / 28 / 56 keys) and a mate that repeats one of its keys first
+            full = int(rng.choice([3, 7, 14, 28, 56]))
+            a = np.arange(base, base + full)
+            b = np.sort(np.concatenate([a[:1], np.arange(base + full + 2, base + full + 2 + int(rng.integers(0, 5)))]))
+            segs = [a, b]
+        allk = np.unique(np.concatenate(segs))
+        removed = rng.choice(allk, size=int(rng.integers(0, max(1, len(allk) // 3))), replace=False) if trial % 3 == 0 and len(allk) > 1 else []
+        got = oracle.positions_order([s.astype(np.uint32) for s in segs], np.asarray(removed, np.uint32)).tolist()
+        want = model_positions_order([s.tolist() for s in segs], [int(x) for x in removed])
+        assert got == want, f"trial {trial} kind {kind}"
+        assert sorted(got) == sorted(set(allk.tolist()) - set(int(x) for x in removed))
+        # ... and it is not what ONE CIGAR walk over the union would have built (the case the library emulates without a set_order), often enough to matter
+        one_walk = model_positions_order([sorted(set(allk.tolist()))], [int(x) for x in removed])
+        n_diff += got != one_walk
+    assert n_diff > 40
+
+
+def test_set_order_of_a_pileup_is_used_as_given_and_checked():
+    """The oracle takes a pileup's set_order as the reads' iteration orders (arithmetic mode 1) and refuses one that is not a permutation."""
+    from floria_amd.pileup import Pileup
+    rng = np.random.default_rng(5)
+    reads = []
+    for r in range(40):
+        snps = np.sort(rng.choice(np.arange(1, 60), size=int(rng.integers(2, 12)), replace=False))
+        reads.append((snps, rng.integers(0, 2, size=len(snps)), rng.integers(8, 40, size=len(snps))))
+    pile = Pileup.from_reads(reads)
+    s, e = np.asarray([1], np.uint32), np.asarray([60], np.uint32)
+    par = oracle.make_params(0.04, 3, 6)
+    oracle.set_arith_mode(1)
+    try:
+        base = oracle.phase_blocks(pile, s, e, par, threads=1)
+        # the order of one CIGAR walk, written down explicitly: the same bits
+        pile.set_order = np.concatenate([oracle.set_order_of(pile.read(r)[0], [pile.read(r)[0]]) for r in range(pile.n_reads)])
+        same = oracle.phase_blocks(pile, s, e, par, threads=1)
+        assert np.array_equal(base.part, same.part) and np.array_equal(base.mec.view(np.uint64), same.mec.view(np.uint64))
+        bad = pile.set_order.copy()
+        bad[int(pile.read_off[3])] = bad[int(pile.read_off[3]) + 1]
+        pile.set_order = bad
+        try:
+            oracle.phase_blocks(pile, s, e, par, threads=1)
+            raise AssertionError("a set_order with a repeated index was accepted")
+        except oracle.OracleError:
+            pass
+    finally:
+        oracle.set_arith_mode(0)
+        pile.set_order = None
