@@ -294,6 +294,11 @@ struct CellOrderArgs {
     uint64_t* todo;                  // [1 + n_reads] number of reads left to cell_order_kernel, then their global indices
     uint32_t  replay_all;            // (tests) != 0: every read goes the long way
     uint64_t* bad;                   // ~(the smallest global index of a read whose host-given set_order is not a permutation of its cells), 0 = none
+    uint64_t  read_base;             // this launch covers the reads [read_base, read_base + n_reads) of the batch (a pipelined upload computes the orders chunk by chunk)
+    uint64_t  scratch_bytes;         // bytes behind `scratch`
+    uint32_t  len_max;               // longest read (sizes the emulated tables); 0 = take it from `status` (the flatten kernel's per-contig maximum: known on the device only)
+    const uint32_t* status_max_len;  // [n_contigs] with the stride below
+    uint32_t  status_stride;         // in 32-bit words
 };
 constexpr uint32_t CO_IDX_MAX = 2048;      // largest set (buckets) the direct kernel takes: u16 entries, 4 KB of LDS per wavefront
 __global__ __launch_bounds__(256) void cell_order_direct_kernel(CellOrderArgs g) {
@@ -301,7 +306,8 @@ __global__ __launch_bounds__(256) void cell_order_direct_kernel(CellOrderArgs g)
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wid, nw = (uint64_t)gridDim.x * 4;
     __attribute__((address_space(3))) uint16_t* const idx = (__attribute__((address_space(3))) uint16_t*)s_idx[wid];
-    for (uint64_t gr = gw; gr < g.n_reads; gr += nw) {
+    for (uint64_t gl = gw; gl < g.n_reads; gl += nw) {
+        const uint64_t gr = g.read_base + gl;
         uint32_t lo = 0, hi = g.n_contigs;                                    // contig of global read gr
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.read_prefix[mid] <= gr) lo = mid; else hi = mid; }
         const ContigDev cd = g.contigs[lo];
@@ -354,10 +360,23 @@ __global__ __launch_bounds__(256) void cell_order_direct_kernel(CellOrderArgs g)
     }
 }
 __global__ void cell_order_kernel(CellOrderArgs g) {
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_todo = g.todo[0];
+    if (tid >= n_todo) return;                                                // (nothing left over on BASELINE's configs: every read took the direct kernel)
+    if (g.len_max == 0) {
+        // a pipelined upload: the longest read of the chunk is known on the device only (flatten_kernel's status words); every thread sizes its three tables by it
+        // and as many threads as the scratch holds share the list
+        uint32_t lm = 1;
+        for (uint32_t c = 0; c < g.n_contigs; ++c) { const uint32_t v = g.status_max_len[(uint64_t)c * g.status_stride]; lm = v > lm ? v : lm; }
+        g.ctrl_bytes = fx_ctrl_bytes(lm); g.slot_bytes = fx_slot_bytes(lm);
+        const uint64_t fit = g.scratch_bytes / (3 * (g.ctrl_bytes + g.slot_bytes));
+        if (fit == 0) { atomicMax((unsigned long long*)g.bad, (unsigned long long)~(g.todo[1])); return; }      // (a read of > 10^7 cells: reported as a bad read rather than written out of bounds)
+        nth = nth < fit ? nth : fit;
+        if (tid >= nth) return;
+    }
     const uint64_t tb = g.ctrl_bytes + g.slot_bytes;
     uint8_t* mine = g.scratch + tid * 3 * tb;
-    const uint64_t n_todo = g.todo[0];
     for (uint64_t ti = tid; ti < n_todo; ti += nth) {
         const uint64_t gr = g.todo[1 + ti];
         uint32_t lo = 0, hi = g.n_contigs;                                    // contig of global read gr

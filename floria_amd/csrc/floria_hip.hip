@@ -1534,57 +1534,85 @@ namespace {
 // Reference-arithmetic mode: the cells of every read of the given contigs in the iteration order of its position set (cell_order_kernel), for
 // the call in flight: ctx->cur_ord[ctx->cur_ord_off[c] + read_off[r] + x] = {SNP, allele << 28 | weight} of the x-th position of read r's set.
 // Computed by two launches (round 5: ≈ 130 ms for the 331 M cells of config 4 with the one-thread-per-read table emulation alone) and kept until the context uploads contigs again: S2 after S1, or the next S1 call over the same resident batch, reuses it.
-int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, uint32_t len_max) {
-    const uint32_t n_contigs = (uint32_t)cdev.size();
-    std::vector<uint64_t> pre(2 * (size_t)n_contigs + 3, 0);                  // reads before contig c [n+1] | cells before contig c [n] | [1 pad] | status word of the host-given set orders
+struct OrderPlan {                        // host side of the cell orders of one set of contigs
+    std::vector<uint64_t> pre;            // reads before contig c [n+1] | cells before contig c [n] | [1 pad] | status word of the host-given set orders
+    uint64_t cells = 0, R_all = 0, sig = 0;
+    uint32_t n_contigs = 0;
+};
+void order_plan(const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, OrderPlan& O) {
+    const uint32_t n_contigs = O.n_contigs = (uint32_t)cdev.size();
+    O.pre.assign(2 * (size_t)n_contigs + 3, 0);
     uint64_t cells = 0;
-    for (uint32_t i = 0; i < n_contigs; ++i) { pre[i + 1] = pre[i] + cdev[i].n_reads; pre[n_contigs + 1 + i] = cells; cells += n_cells[i]; }
-    const uint64_t R_all = pre[n_contigs];
+    for (uint32_t i = 0; i < n_contigs; ++i) { O.pre[i + 1] = O.pre[i] + cdev[i].n_reads; O.pre[n_contigs + 1 + i] = cells; cells += n_cells[i]; }
+    O.cells = cells; O.R_all = O.pre[n_contigs];
     uint64_t sig = 1469598103934665603ull;                                    // FNV-1a over what identifies the contigs: their device arrays and sizes
     auto mix = [&](uint64_t v) { for (int b = 0; b < 8; ++b) { sig ^= (v >> (8 * b)) & 0xff; sig *= 1099511628211ull; } };
     for (uint32_t i = 0; i < n_contigs; ++i) { mix((uint64_t)(uintptr_t)cdev[i].cell_snp); mix((uint64_t)(uintptr_t)cdev[i].read_off); mix(cdev[i].n_reads); mix(n_cells[i]); mix((uint64_t)(uintptr_t)cdev[i].set_order); }
-    if (ctx->ord_epoch == ctx->upload_epoch && ctx->ord_sig == sig && ctx->arith_ord.p && ctx->arith_tab.p) {
+    O.sig = sig;
+}
+// the two launches for the reads [r0, r1) of the contigs [c0, c1) on `st` (their cells must have been flattened on that stream, or before it)
+int order_launch(floria_hip_ctx* ctx, const OrderPlan& O, const fl::ContigDev* d_contigs, uint32_t c0, uint32_t c1, uint64_t* todo, uint8_t* scratch, uint64_t scratch_bytes, uint32_t len_max,
+                 const uint32_t* status_max_len, hipStream_t st) {
+    const uint64_t r0 = O.pre[c0], nr = O.pre[c1] - r0;
+    if (!nr) return 0;
+    fl::CellOrderArgs oa{};
+    oa.todo = todo; oa.replay_all = ctx->knobs.arith_replay;
+    oa.bad = ctx->arith_tab.as<uint64_t>() + 2 * (size_t)O.n_contigs + 2;
+    oa.contigs = d_contigs + c0; oa.read_prefix = ctx->arith_tab.as<uint64_t>() + c0; oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + O.n_contigs + 1 + c0;
+    oa.n_contigs = c1 - c0; oa.n_reads = nr; oa.read_base = r0; oa.ord = ctx->arith_ord.as<uint2>(); oa.scratch = scratch; oa.scratch_bytes = scratch_bytes;
+    oa.len_max = len_max; oa.status_max_len = status_max_len; oa.status_stride = (uint32_t)(sizeof(fl::UploadStatus) / 4);
+    uint64_t nth = std::min<uint64_t>((nr + 255) & ~255ull, 131072);
+    if (len_max) {
+        oa.ctrl_bytes = fl::fx_ctrl_bytes(len_max); oa.slot_bytes = fl::fx_slot_bytes(len_max);
+        nth = std::max<uint64_t>(256, std::min<uint64_t>(nth, (scratch_bytes / (3 * (oa.ctrl_bytes + oa.slot_bytes))) & ~255ull));
+    } else nth = std::min<uint64_t>(nth, 16384);
+    // a wavefront per read where the home-bucket rule applies or the host gave the order (arith_kernel.h), then one thread per read for the rest (none on BASELINE's configs)
+    hipLaunchKernelGGL(fl::cell_order_direct_kernel, dim3((uint32_t)std::min<uint64_t>((nr + 3) / 4, (uint64_t)ctx->n_cu * 16)), dim3(256), 0, st, oa);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, st, oa);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int order_bad_read(const OrderPlan& O, uint64_t bad) {
+    if (!bad) return 0;
+    uint32_t ci = 0;
+    const uint64_t gr = ~bad;
+    while (ci + 1 < O.n_contigs && O.pre[ci + 1] <= gr) ++ci;
+    return fail(FLORIA_E_INVALID, "set_order of read " + std::to_string((unsigned long long)(gr - O.pre[ci])) + (O.n_contigs > 1 ? " (contig " + std::to_string(ci) + " of the batch)" : std::string())
+                                  + " is not a permutation of the indices of its cells");
+}
+int cell_orders(floria_hip_ctx* ctx, const fl::ContigDev* d_contigs, const std::vector<fl::ContigDev>& cdev, const std::vector<uint64_t>& n_cells, uint32_t len_max) {
+    const uint32_t n_contigs = (uint32_t)cdev.size();
+    OrderPlan O;
+    order_plan(cdev, n_cells, O);
+    if (ctx->ord_epoch == ctx->upload_epoch && ctx->ord_sig == O.sig && ctx->arith_ord.p && ctx->arith_tab.p) {
         ctx->cur_ord = ctx->arith_ord.as<uint2>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
         return 0;
     }
-    int rc = ctx->arith_tab.ensure(pre.size() * 8); if (rc) return rc;
-    rc = ctx->arith_ord.ensure(8 * cells + 16); if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->arith_tab.p, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = ctx->arith_tab.ensure(O.pre.size() * 8); if (rc) return rc;
+    rc = ctx->arith_ord.ensure(8 * O.cells + 16); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->arith_tab.p, O.pre.data(), O.pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));                                // (`pre` is pageable and local)
-    if (R_all) {
+    if (O.R_all) {
         const uint64_t tb = fl::fx_ctrl_bytes(std::max(1u, len_max)) + fl::fx_slot_bytes(std::max(1u, len_max));
-        uint64_t nth = std::min<uint64_t>((R_all + 255) & ~255ull, 131072);
+        uint64_t nth = std::min<uint64_t>((O.R_all + 255) & ~255ull, 131072);
         nth = std::max<uint64_t>(256, std::min<uint64_t>(nth, ((2ull << 30) / (3 * tb)) & ~255ull));
-        const uint64_t todo_bytes = (8 * (R_all + 1) + 255) & ~255ull;          // [count | reads for the table emulation] in front of the emulation's scratch
+        const uint64_t todo_bytes = (8 * (O.R_all + 1) + 255) & ~255ull;          // [count | reads for the table emulation] in front of the emulation's scratch
         rc = ctx->arith_scr.ensure(todo_bytes + 3 * tb * nth); if (rc) return rc;
         HIPCHK(hipMemsetAsync(ctx->arith_scr.p, 0, 8, ctx->stream));
-        fl::CellOrderArgs oa{};
-        oa.todo = ctx->arith_scr.as<uint64_t>(); oa.replay_all = ctx->knobs.arith_replay;
-        oa.bad = ctx->arith_tab.as<uint64_t>() + 2 * (size_t)n_contigs + 2;              // (zeroed with the prefix tables above)
-        oa.contigs = d_contigs; oa.read_prefix = ctx->arith_tab.as<uint64_t>(); oa.cell_prefix = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
-        oa.n_contigs = n_contigs; oa.n_reads = R_all; oa.ord = ctx->arith_ord.as<uint2>(); oa.scratch = ctx->arith_scr.as<uint8_t>() + todo_bytes; oa.ctrl_bytes = fl::fx_ctrl_bytes(std::max(1u, len_max)); oa.slot_bytes = fl::fx_slot_bytes(std::max(1u, len_max));
-        // a wavefront per read where the home-bucket rule applies (arith_kernel.h), then one thread per read for the rest (none on BASELINE's configs)
-        hipLaunchKernelGGL(fl::cell_order_direct_kernel, dim3((uint32_t)std::min<uint64_t>((R_all + 3) / 4, (uint64_t)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, oa);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(fl::cell_order_kernel, dim3((uint32_t)(nth / 256)), dim3(256), 0, ctx->stream, oa);
-        HIPCHK(hipGetLastError());
+        rc = order_launch(ctx, O, d_contigs, 0, n_contigs, ctx->arith_scr.as<uint64_t>(), ctx->arith_scr.as<uint8_t>() + todo_bytes, 3 * tb * nth, std::max(1u, len_max), nullptr, ctx->stream);
+        if (rc) return rc;
         bool any_given = false;
         for (uint32_t i = 0; i < n_contigs; ++i) any_given = any_given || cdev[i].set_order != nullptr;
         if (any_given) {                                                       // a host-given order that is not a permutation of a read's cells: refuse the call
             uint64_t bad = 0;
-            HIPCHK(hipMemcpyAsync(&bad, oa.bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(&bad, ctx->arith_tab.as<uint64_t>() + 2 * (size_t)n_contigs + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (bad) {
-                uint32_t ci = 0;
-                const uint64_t gr = ~bad;
-                while (ci + 1 < n_contigs && pre[ci + 1] <= gr) ++ci;
-                return fail(FLORIA_E_INVALID, "set_order of read " + std::to_string((unsigned long long)(gr - pre[ci])) + (n_contigs > 1 ? " (contig " + std::to_string(ci) + " of the batch)" : std::string())
-                                              + " is not a permutation of the indices of its cells");
-            }
+            if (int brc = order_bad_read(O, bad)) return brc;
         }
     }
     ctx->cur_ord = ctx->arith_ord.as<uint2>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
-    ctx->ord_epoch = ctx->upload_epoch; ctx->ord_sig = sig;
+    ctx->ord_epoch = ctx->upload_epoch; ctx->ord_sig = O.sig;
     return 0;
 }
 
@@ -1599,6 +1627,7 @@ struct S1Contigs {
     const uint32_t* contig_chunk = nullptr;
     uint32_t n_chunks = 0;
     hipEvent_t* chunk_ev = nullptr;
+    bool orders_in_flight = false; // reference-arithmetic mode, pipelined upload: every chunk's cell orders are computed behind its flatten launch, ahead of its event
     uint32_t chunk_groups = 0;     // job groups the chunks are merged into (0 = one per chunk)
     bool ends_apart = false;       // with three groups: first chunk | middle chunks | last chunk
 };
@@ -1816,7 +1845,9 @@ int s1_core(floria_hip_ctx* ctx, const S1Contigs& SC, const uint32_t* blk_contig
 
     // ---- reference-arithmetic mode: the iteration order of every read's position set (arith_kernel.h) --------------------------------
     ctx->cur_ord = nullptr; ctx->cur_ord_off = nullptr; ctx->cur_len_max = len_max;
-    if (ctx->knobs.arith && n_contigs) {
+    if (ctx->knobs.arith && n_contigs && SC.orders_in_flight) {
+        ctx->cur_ord = ctx->arith_ord.as<uint2>(); ctx->cur_ord_off = ctx->arith_tab.as<uint64_t>() + n_contigs + 1;
+    } else if (ctx->knobs.arith && n_contigs) {
         if (SC.n_cells.size() != n_contigs || chunked) return fail(FLORIA_E_INVALID, "internal: the reference-arithmetic mode needs resident contigs");
         int tk = T.begin(K_SEL);
         rc = cell_orders(ctx, bs.contigs, cdev, SC.n_cells, len_max);
@@ -1959,7 +1990,10 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
     auto n_reads_of = [&](uint32_t i) { return pk ? pk[i].n_reads : pileups[i].n_reads; };
     for (uint32_t i = 0; i < n_contigs; ++i) { const uint32_t* ro = pk ? pk[i].read_off : pileups[i].read_off; if (n_reads_of(i) && ro) cells += ro[n_reads_of(i)]; }
     // auto: ~0.5 GB of host pileup per chunk, at most 5 (measured on BASELINE config 4, 2.65 GB: 5 chunks, the first one half-size, are best)
-    const uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (200ull << 20)));
+    uint32_t want_chunks = ctx->knobs.upload_chunks ? ctx->knobs.upload_chunks : (uint32_t)std::max<uint64_t>(cells * 6 >= (160ull << 20) ? 2 : 1, std::min<uint64_t>(5, cells * 6 / (200ull << 20)));
+    // reference-arithmetic mode: a job group's chain of stages is longer (fewer wave slots, the sequential folds), so a group that starts late ends the call late: two chunks
+    // (measured on config 4 at -e 0.04, ms per call from packed pinned memory, 1 / 2 / 3 / 5 chunks: 122.2 / 117.7 / 120.5 / 123.4; resident 98; profiles/r06_arith_pipe_timing.txt)
+    if (ctx->knobs.arith && !ctx->knobs.upload_chunks) want_chunks = std::min<uint32_t>(want_chunks, 2);
     // (measured, config 4, H2D-inclusive: 500 contigs / 0.66 GB: 2 chunks 60.5 ms, 3-4 chunks 56.5; 1000 contigs / 1.33 GB: 2 chunks 86 ms, 4-5 chunks 77; 2000 contigs: 5 chunks)
     // batches small enough for speculative ploidy stages (s1_core) keep chunk groups x stage width within the hardware queues
     UploadPlan UP;
@@ -1972,7 +2006,12 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
     if (rc) return rc;
     std::vector<floria_hip_contig*> handles(n_contigs, nullptr);
     auto drop = [&](int code) { sync_all(ctx); for (auto* h : handles) if (h) { h->arena = nullptr; delete h; } arena_put(UP.A); return code; };
-    bool pipelined = UP.all_pinned && UP.n_chunks > 1 && !ctx->knobs.arith;       // (the cell orders of the reference-arithmetic mode need every cell on the device)
+    bool pipelined = UP.all_pinned && UP.n_chunks > 1;
+    const bool arith_pipe = pipelined && ctx->knobs.arith != 0;      // reference-arithmetic mode: every chunk's cell orders are computed behind its flatten launch (round 6; until then this mode uploaded the whole batch first)
+    OrderPlan OP;
+    std::vector<fl::ContigDev> pipe_cdev;
+    std::vector<uint64_t> pipe_cells;
+    const uint64_t order_scratch = 64ull << 20;
     uint64_t pinned_b = 0, staged_b = 0;
     floria_block_result* R = nullptr;
     if (pipelined) {
@@ -1988,6 +2027,28 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
         }
         rc = issue_copies(ctx, UP.small_runs, &pinned_b, &staged_b);                       // main stream: read_off / first / last + tables
         hipError_t e = rc ? hipSuccess : issue_tables(ctx, UP, ctx->stream);
+        pipe_cdev.resize(n_contigs); pipe_cells.resize(n_contigs);
+        for (uint32_t i = 0; i < n_contigs; ++i) {
+            fl::ContigDev& d = pipe_cdev[i];
+            d.read_off = UP.ucd[i].read_off; d.first = UP.ucd[i].first; d.last = UP.ucd[i].last; d.cell_snp = UP.ucd[i].snp;
+            d.cell_aw = UP.ucd[i].cell_aw; d.tw = UP.ucd[i].tw; d.meta = UP.ucd[i].meta; d.n_reads = n_reads_of(i);
+            d.set_order = UP.so_dev[i];
+            pipe_cells[i] = UP.cp[i + 1] - UP.cp[i];
+        }
+        size_t ord_cdev_off = 0, ord_todo_words = 0;
+        if (arith_pipe && !rc && e == hipSuccess) {
+            // the order kernels' tables: prefix sums + status word | the contigs' device arrays; the todo lists of the chunks (one count word each) + the emulation's scratch
+            order_plan(pipe_cdev, pipe_cells, OP);
+            ord_cdev_off = (OP.pre.size() * 8 + 255) & ~(size_t)255;
+            ord_todo_words = OP.R_all + UP.n_chunks;
+            rc = ctx->arith_tab.ensure(ord_cdev_off + sizeof(fl::ContigDev) * n_contigs);
+            if (!rc) rc = ctx->arith_ord.ensure(8 * OP.cells + 16);
+            if (!rc) rc = ctx->arith_scr.ensure(((8 * ord_todo_words + 255) & ~(size_t)255) + order_scratch);
+            if (!rc) e = hipMemcpyAsync(ctx->arith_tab.p, OP.pre.data(), OP.pre.size() * 8, hipMemcpyHostToDevice, ctx->stream);       // (OP / pipe_cdev live until this call returns, behind a sync)
+            if (!rc && e == hipSuccess) e = hipMemcpyAsync(ctx->arith_tab.as<char>() + ord_cdev_off, pipe_cdev.data(), sizeof(fl::ContigDev) * n_contigs, hipMemcpyHostToDevice, ctx->stream);
+            for (uint32_t g = 0; g < UP.n_chunks && !rc && e == hipSuccess; ++g) e = hipMemsetAsync(ctx->arith_scr.as<uint64_t>() + OP.pre[UP.chunk_first[g]] + g, 0, 8, ctx->stream);      // the chunks' todo counters
+            ctx->ord_epoch = ~0ull;                                                            // (the cached orders are being overwritten)
+        }
         if (!rc && e == hipSuccess) e = hipEventRecord(ctx->ev_chunk[UP.n_chunks], ctx->stream);
         if (!rc && e == hipSuccess) e = hipStreamWaitEvent(ctx->flat_stream, ctx->ev_chunk[UP.n_chunks], 0);
         for (uint32_t g = 0; g < UP.n_chunks && !rc && e == hipSuccess; ++g) {             // copy stream: the cells of chunk g, back to back with chunk g+1;
@@ -1995,18 +2056,20 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
             if (e == hipSuccess) e = hipEventRecord(ctx->ev_copied[g], ctx->copy_stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(ctx->flat_stream, ctx->ev_copied[g], 0);       // flatten stream: validate + flatten chunk g
             if (e == hipSuccess) e = launch_flatten(ctx, UP, g, ctx->flat_stream);
+            if (e == hipSuccess && arith_pipe) {                                            // ... and the iteration orders of its reads' position sets (arith_kernel.h)
+                const uint32_t c0 = UP.chunk_first[g], c1 = UP.chunk_first[g + 1];
+                const int orc = order_launch(ctx, OP, (const fl::ContigDev*)(ctx->arith_tab.as<char>() + ord_cdev_off), c0, c1, ctx->arith_scr.as<uint64_t>() + OP.pre[c0] + g,
+                                             ctx->arith_scr.as<uint8_t>() + ((8 * ord_todo_words + 255) & ~(size_t)255), order_scratch, 0,
+                                             &((const fl::UploadStatus*)(UP.T + UP.t_st) + c0)->max_len, ctx->flat_stream);
+                if (orc) rc = orc;
+            }
             if (e == hipSuccess) e = hipEventRecord(ctx->ev_chunk[g], ctx->flat_stream);
         }
         if (!rc && e != hipSuccess) rc = fail(FLORIA_E_DEVICE, std::string("pipelined upload: ") + hipGetErrorString(e));
         if (rc) return drop(rc);
         S1Contigs SC;
-        SC.cdev.resize(n_contigs);
-        for (uint32_t i = 0; i < n_contigs; ++i) {
-            fl::ContigDev& d = SC.cdev[i];
-            d.read_off = UP.ucd[i].read_off; d.first = UP.ucd[i].first; d.last = UP.ucd[i].last; d.cell_snp = UP.ucd[i].snp;
-            d.cell_aw = UP.ucd[i].cell_aw; d.tw = UP.ucd[i].tw; d.meta = UP.ucd[i].meta; d.n_reads = n_reads_of(i);
-            d.set_order = UP.so_dev[i];
-        }
+        SC.cdev = pipe_cdev;
+        if (arith_pipe) { SC.n_cells = pipe_cells; SC.orders_in_flight = true; }
         SC.len_max = BINOM_NMAX_CAP; SC.nall = 2; SC.any_q0 = false;                      // optimistic plan, verified below
         SC.contig_chunk = UP.contig_chunk.data(); SC.n_chunks = UP.n_chunks; SC.chunk_ev = ctx->ev_chunk;
         // the compact wire form is on the device in a tenth of the step: what counts then is that the expand / flatten launches of the later chunks are
@@ -2019,6 +2082,14 @@ static int phase_pileups_impl(floria_hip_ctx* ctx, const floria_pileup* pileups,
         hipError_t e2 = hipMemcpy(UP.ust.data(), UP.T + UP.t_st, sizeof(fl::UploadStatus) * n_contigs, hipMemcpyDeviceToHost);
         if (e2 != hipSuccess) { floria_hip_block_result_free(R); return drop(fail(FLORIA_E_DEVICE, std::string("upload status: ") + hipGetErrorString(e2))); }
         rc = finish_upload(ctx, UP, handles.data());
+        if (!rc && arith_pipe) {
+            uint64_t bad = 0;
+            e2 = hipMemcpy(&bad, ctx->arith_tab.as<uint64_t>() + 2 * (size_t)n_contigs + 2, 8, hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) rc = fail(FLORIA_E_DEVICE, std::string("set-order status: ") + hipGetErrorString(e2));
+            else rc = order_bad_read(OP, bad);
+            if (!rc) { ctx->ord_epoch = ctx->upload_epoch; ctx->ord_sig = OP.sig; }          // S2 / the next S1 call over these contigs reuses the orders
+            if (rc) { floria_hip_block_result_free(R); for (auto* h : handles) floria_hip_contig_free(h); return rc; }      // (the handles own the arena by now)
+        }
         if (rc) { floria_hip_block_result_free(R); for (auto*& h : handles) h = nullptr; return drop(rc); }
         bool plan_ok = true;
         for (auto* h : handles) plan_ok = plan_ok && h->n_alleles == 2 && !h->has_q0;

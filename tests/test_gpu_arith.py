@@ -363,3 +363,77 @@ def test_paired_fragments_with_host_given_set_orders(arith, hip_lib, oracle_mod,
         arith.phase_blocks(pile, s, e, hip_lib.make_params(eps))
     pile.set_order = None
     arith.phase_blocks(pile, s, e, hip_lib.make_params(eps))          # (and the context is usable afterwards)
+
+
+@pytest.mark.parametrize("wire", ("packed", "csr"))
+def test_pipelined_upload_in_reference_arithmetic(arith, hip_lib, oracle_mod, wire):
+    """VERDICT r5 #3d: the host-pileup entry points pipeline in this mode too - every chunk's cell orders are computed behind its flatten launch, on the chunk's
+    stream, and the chunk's job group starts behind them.  Twelve config-4 contigs and two paired config-3 contigs (with host-given set orders) from pinned memory
+    in 3 chunks against the oracle's mode 1, and against the same call in one piece."""
+    C = synth.CONFIGS[4]
+    piles, bc, bs, be = [], [], [], []
+    for idx in range(12):
+        c = synth.make_config_contig(4, 100 + idx, 1.0)
+        s, e = oracle_mod.block_ranges(c.snp_pos, C["block_length"])
+        piles.append(c.pileup); bc += [idx] * len(s); bs += list(s); be += list(e)
+    bc, bs, be = np.asarray(bc, np.uint32), np.asarray(bs, np.uint32), np.asarray(be, np.uint32)
+    par = hip_lib.make_params(0.04, C["max_ploidy"], C["beam"])
+    if wire == "packed":
+        arena, src, _ = hip_lib.pack_pileups(piles)
+    else:
+        arena, src = hip_lib.pin_pileups(piles)
+    one = arith.phase_pileups_batch(src, bc, bs, be, par)
+    arith.set_option("upload_chunks", 3)
+    try:
+        rg = arith.phase_pileups_batch(src, bc, bs, be, par)
+        assert arith.timing()["upload_chunks"] == 3
+    finally:
+        arith.set_option("upload_chunks", 0)
+    arena.free()
+    assert_block_results_equal(one, rg, f"{wire}: 3 chunks against one piece")
+    assert one.min_prune_margin == rg.min_prune_margin
+    off = 0
+    for idx in (0, 5, 11):
+        sel = np.nonzero(bc == idx)[0]
+        ro = oracle_mod.phase_blocks(piles[idx], bs[sel], be[sel], oracle_mod.make_params(0.04, C["max_ploidy"], C["beam"]), threads=8)
+        for k, b in enumerate(sel):
+            assert ro.best_ploidy[k] == rg.best_ploidy[b] and np.array_equal(ro.block(k)[1], rg.block(int(b))[1]), f"contig {idx} block {k}"
+            assert np.array_equal(ro.mec[k].view(np.uint64), rg.mec[b].view(np.uint64))
+
+
+def test_pipelined_upload_with_host_given_set_orders(arith, hip_lib, oracle_mod, tmp_path):
+    from floria_amd import synth_bam
+    piles, bc, bs, be, per = [], [], [], [], []
+    for k, idx in enumerate((2, 5, 7)):
+        c = synth.make_config_contig(3, idx, 0.2, keep_layout=True)
+        ex = synth_bam.write_dataset(str(tmp_path / f"q{idx}"), [c], seed=3)[c.name]
+        pile = ex["pileup"]
+        if k != 1:              # (the middle contig carries none: its sets are emulated on the device, the others' are gathered)
+            pile.set_order = np.concatenate([oracle_mod.set_order_of(pile.read(i)[0], [np.asarray(x, np.uint32) for x in ex["segments"][i]]) for i in range(pile.n_reads)])
+        s, e = hip_lib.get_range_with_lengths(ex["snp_pos0"], 500)
+        piles.append(pile); per.append((s, e)); bc += [k] * len(s); bs += list(s); be += list(e)
+    bc, bs, be = np.asarray(bc, np.uint32), np.asarray(bs, np.uint32), np.asarray(be, np.uint32)
+    par = hip_lib.make_params(0.0437)
+    arena, pinned = hip_lib.pin_pileups(piles)
+    arith.set_option("upload_chunks", 3)
+    try:
+        rg = arith.phase_pileups_batch(pinned, bc, bs, be, par)
+        assert arith.timing()["upload_chunks"] == 3
+        # a set order that is not a permutation is refused on this route as well
+        keep = pinned[2].set_order.copy()
+        two = int(np.nonzero(np.diff(pinned[2].read_off) >= 2)[0][0])
+        pinned[2].set_order[int(pinned[2].read_off[two])] = pinned[2].set_order[int(pinned[2].read_off[two]) + 1]
+        with pytest.raises(hip_lib.FloriaHipError, match="set_order of read .*contig 2"):
+            arith.phase_pileups_batch(pinned, bc, bs, be, par)
+        pinned[2].set_order[:] = keep
+        again = arith.phase_pileups_batch(pinned, bc, bs, be, par)
+    finally:
+        arith.set_option("upload_chunks", 0)
+    arena.free()
+    assert_block_results_equal(rg, again, "after a refused call")
+    for k in range(3):
+        sel = np.nonzero(bc == k)[0]
+        ro = oracle_mod.phase_blocks(piles[k], per[k][0], per[k][1], oracle_mod.make_params(0.0437), threads=8)
+        for j, b in enumerate(sel):
+            assert ro.best_ploidy[j] == rg.best_ploidy[b] and np.array_equal(ro.block(j)[1], rg.block(int(b))[1]), f"contig {k} block {j}"
+            assert np.array_equal(ro.mec[j].view(np.uint64), rg.mec[b].view(np.uint64))
