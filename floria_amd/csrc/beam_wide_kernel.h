@@ -38,7 +38,8 @@ __host__ __device__ inline WideLds wide_lds_layout(uint32_t LM, uint32_t p, bool
     return L;
 }
 // u32 words the kernel needs behind a slot's traceback records (per-slab result tables)
-__host__ __device__ inline uint64_t wide_scratch_words(uint32_t LM, uint32_t p, bool q0) { return (uint64_t)LM * p * (q0 ? 22 : 14); }
+// (arith: + the states' error_vec, two parities of LM * p f64, behind the tables)
+__host__ __device__ inline uint64_t wide_scratch_words(uint32_t LM, uint32_t p, bool q0, bool arith = false) { return (uint64_t)LM * p * ((q0 ? 22 : 14) + (arith ? 4 : 0)); }
 
 __device__ inline uint16_t wide_sorted_first(uint16_t* hid, const EntryRec* ent, uint32_t len) {      // into_sorted_vec()[0]
     uint32_t end = len;
@@ -65,7 +66,12 @@ __device__ inline uint16_t wide_sorted_first(uint16_t* hid, const EntryRec* ent,
     return hid[0];
 }
 
-template <int A, bool Q0>
+// ARITH: the reference's own f64 arithmetic (floria_hip_set_option("arith", 1)) for wide beams (round 6; until then such beams took the generic kernel in this
+// mode).  A read's cells are staged in the iteration order of Frag.positions (BeamArgs::cell_ord); phase A gives every live slab ONE lane, which walks the cells in that
+// order and adds `diff += w | epsilon` term by term (utils_frags.rs:32-75) - a wide beam has dozens to hundreds of live slabs, so the lanes are busy anyway and the running
+// sum needs no staging; a state carries error_vec (global_clustering.rs:196-202) as p f64 in the slot's HBM scratch, a child's score is their sum in partition order with
+// the read's diff added to its partition first.  Slabs, hash, heap, traceback: unchanged.
+template <int A, bool Q0, bool ARITH = false>
 __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_heap_len, s_efree_n;
@@ -96,10 +102,12 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
     const uint32_t slab_bytes = g.span_max * pos_bytes;
     char* pool = (char*)(g.state_pool + (uint64_t)blockIdx.x * ((uint64_t)LM * g.span_max * p * A));
     uint32_t* slot_hist = g.hist_pool + (uint64_t)blockIdx.x * g.hist_stride;
-    uint64_t* r_qs = (uint64_t*)(slot_hist + (g.hist_stride - wide_scratch_words(LM, p, Q0)));
+    uint64_t* r_qs = (uint64_t*)(slot_hist + (g.hist_stride - wide_scratch_words(LM, p, Q0, ARITH)));
     uint64_t* r_qd = r_qs + NS; uint64_t* r_t1 = r_qd + NS; uint64_t* r_t2 = r_t1 + NS;
     uint64_t* r_np1 = r_t2 + NS; uint64_t* r_np2 = r_np1 + (Q0 ? NS : 0);
     uint32_t* r_m = (uint32_t*)(r_np2 + (Q0 ? NS : 0));
+    double* const r_fd = (double*)r_qd;                                  // ARITH: the read's running diff against every live slab
+    double* const ev_base = (double*)(r_qs + (uint64_t)NS * (Q0 ? 11 : 7));      // ARITH: error_vec of the current / next states, [2][LM * p]
     const uint64_t lane_lt = (1ull << lane) - 1;
 
     const uint32_t S = 64 / p;
@@ -124,8 +132,10 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
         const uint32_t n = (uint32_t)(g.bs.blk_read_off[b + 1] - roff);
         const uint32_t* reads = g.bs.blk_read + roff;
         const uint32_t pos0 = g.bs.blk_pos0[b];
+        const uint2* const ord = ARITH ? g.cell_ord + g.cell_ord_off[g.bs.blk_contig[b]] : nullptr;     // the contig's cells, every read's in set order
 
         int cur = 0;
+        auto ST_ev = [&](int w) { return ev_base + (w ? NS : 0u); };
         auto ST_q = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_q[1] : LY.off_q[0])); };
         auto ST_h1 = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_h1[1] : LY.off_h1[0])); };
         auto ST_h2 = [&](int w) { return (uint64_t*)(smem + (w ? LY.off_h2[1] : LY.off_h2[0])); };
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
         uint32_t nstates = 1, nlive = 1;
         if (lane == 0) { ST_q(0)[0] = 0; ST_h1(0)[0] = 0; ST_h2(0)[0] = 0; ST_m(0)[0] = 0; live_id[0] = 0; s2l[0] = 0; }
         if (lane < p) ST_sl(0)[lane] = 0;
+        if (ARITH && lane < p) ST_ev(0)[lane] = 0.0;                  // error_vec: vec![(0.0, 0.0); ploidy] (global_clustering.rs:37)
         int32_t hi_rel = -1;
         uint32_t start_rel = 0;
         __syncthreads();
@@ -161,12 +172,13 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                     const uint32_t cc = t * SLAB_TILE + c;
                     bool in = false;
                     if (cc < L) {
-                        const uint32_t snp = G(cd.cell_snp)[cbeg + cc];
-                        const uint32_t aq = G(cd.cell_aw)[cbeg + cc];
+                        uint32_t snp, aq;
+                        if constexpr (ARITH) { const uint64_t ca = G((const uint64_t*)ord)[cbeg + cc]; snp = (uint32_t)ca; aq = (uint32_t)(ca >> 32); }      // (set order: the cells inside the written window are not a prefix)
+                        else { snp = G(cd.cell_snp)[cbeg + cc]; aq = G(cd.cell_aw)[cbeg + cc]; }
                         const uint32_t pr = snp - pos0, al = aq >> 28;
                         c_off[c] = pr * pos_bytes;
-                        c_aw[c] = (al << 28) | (aq & 0x0fffffffu);
                         in = (int32_t)pr <= hi_rel;
+                        c_aw[c] = (al << 28) | (aq & 0x0fffffffu) | ((ARITH && in) ? 0x80000000u : 0u);       // (ARITH: bit 31 = the position lies inside the written window)
                         if (Q0) {
                             const uint64_t r1 = g.Rp1[hash_idx(snp, al)], r2 = g.Rp2[hash_idx(snp, al)];
                             c_rp1[c] = r1; c_rp2[c] = r2;
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
 
             // ---- A: read vs every live slab --------------------------------------------------------------------------
             uint32_t Gs = 1;
-            while (Gs < 16 && nlive * (Gs * 2) <= 64) Gs *= 2;
+            while (!ARITH && Gs < 16 && nlive * (Gs * 2) <= 64) Gs *= 2;          // (ARITH: one lane per slab - the running sum is sequential in the cells)
             const int32_t tend = (int32_t)first_rel - 1 < hi_rel ? (int32_t)first_rel - 1 : hi_rel;
             const bool trunc = tend >= (int32_t)start_rel;
             const uint32_t per = 64 / Gs;
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 const uint32_t slab_off = act ? (uint32_t)live_id[li] * slab_bytes : 0;
                 uint64_t qs = 0, qd = 0, np1 = 0, np2 = 0, t1 = 0, t2 = 0;
                 uint32_t m = 0;
+                double df = 0.0;                                   // ARITH: the running `diff` of utils_frags.rs:32-75 (continued across the tiles of a long read)
                 for (int32_t pr = (int32_t)start_rel + (int32_t)sub; pr <= tend; pr += (int32_t)Gs) {
                     if (act) {
 #pragma unroll
@@ -227,6 +240,36 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 for (uint32_t t = 0; t < ntiles; ++t) {
                     if (ntiles > 1) stage_tile(t);
                     const uint32_t tl = min((uint32_t)SLAB_TILE, L - t * SLAB_TILE);
+                    if constexpr (ARITH) {
+                        if (act)
+                        for (uint32_t c0 = 0; c0 < tl; c0 += 4) {
+                            uint32_t aws[4]; bool vs[4], ins[4];
+                            ulonglong2 vv[4][A / 2];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t c = c0 + u; vs[u] = c < tl; const uint32_t cx = vs[u] ? c : 0;
+                                aws[u] = c_aw[cx]; ins[u] = vs[u] && (aws[u] >> 31);
+                                const char* cp = pool + (slab_off + (ins[u] ? c_off[cx] : 0u));
+#pragma unroll
+                                for (int x = 0; x < A / 2; ++x) vv[u][x] = *(const ulonglong2*)(cp + 16 * x);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (!vs[u]) break;
+                                const uint32_t al = (aws[u] >> 28) & 3u, w = aws[u] & 0x0fffffffu;
+                                uint64_t v[A], mx = 0, va = 0;
+#pragma unroll
+                                for (int x = 0; x < A; x += 2) { v[x] = ins[u] ? vv[u][x / 2].x : 0ull; v[x + 1] = ins[u] ? vv[u][x / 2].y : 0ull; }      // beyond the written window: not in the haplotype (:36-48)
+#pragma unroll
+                                for (int x = 0; x < A; ++x) { const uint64_t qx = Q0 ? (v[x] & QMASK63) : v[x]; mx = qx > mx ? qx : mx; va = (x == (int)al) ? v[x] : va; }
+                                const bool nonempty = mx != 0, same = nonempty && (Q0 ? (va & QMASK63) : va) == mx;
+                                if (!nonempty) df += g.eps;                                   // :45-48 diff += epsilon
+                                else if (same) qs += w;                                       // :54-67 same += w
+                                else df += (double)w * 0x1p-24;                               // :70    diff += w
+                                if (Q0) { const bool np = !(va >> 63); np1 += np ? c_rp1[c0 + u] : 0ull; np2 += np ? c_rp2[c0 + u] : 0ull; }
+                            }
+                        }
+                    } else
                     if (act) {
                         for (uint32_t c0 = sub; c0 < nin; c0 += 4 * Gs) {
                             uint32_t offs[4], aws[4];
@@ -247,11 +290,12 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                         if (sub == 0) { m += tl - nin; if (Q0) { np1 += rpb1; np2 += rpb2; } }
                     }
                 }
+                if constexpr (ARITH) { if (act) r_fd[li] = df; }
                 qs = seg_sum_u64(qs, Gs); qd = seg_sum_u64(qd, Gs); m = seg_sum_u32(m, Gs);
                 if (trunc) { t1 = seg_sum_u64(t1, Gs); t2 = seg_sum_u64(t2, Gs); }
                 if (Q0) { np1 = seg_sum_u64(np1, Gs); np2 = seg_sum_u64(np2, Gs); }
                 if (act && sub == 0) {
-                    r_qs[li] = qs; r_qd[li] = qd; r_m[li] = m;
+                    r_qs[li] = qs; if (!ARITH) { r_qd[li] = qd; r_m[li] = m; }
                     if (trunc) { r_t1[li] = t1; r_t2[li] = t2; }
                     if (Q0) { r_np1[li] = np1; r_np2[li] = np2; }
                 }
@@ -265,14 +309,15 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 const bool act = lane_pair && a < nstates;
                 uint64_t qd = 0, t1 = 0, t2 = 0, np1 = 0, np2 = 0;
                 uint32_t m = 0;
-                double pv = 0.0;
+                double pv = 0.0, df = 0.0, e_own = 0.0;
                 if (act) {
                     const uint32_t li = s2l[st_sl[a * p + my_k]];
                     const uint64_t qs = r_qs[li];
-                    qd = r_qd[li]; m = r_m[li];
+                    if constexpr (ARITH) { df = r_fd[li]; e_own = ST_ev(cur)[a * p + my_k]; }
+                    else { qd = r_qd[li]; m = r_m[li]; }
                     if (trunc) { t1 = r_t1[li] * rk1; t2 = r_t2[li] * rk2; }
                     if (Q0) { np1 = r_np1[li]; np2 = r_np2[li]; }
-                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = qm_to_f64(qd, m, g.eps);
+                    const double same_f = qm_to_f64(qs, 0, g.eps), diff_f = ARITH ? df : qm_to_f64(qd, m, g.eps);
                     const uint64_t nn = (uint64_t)(same_f + diff_f), kk = (uint64_t)diff_f;
                     if (nn <= g.binom_nmax) pv = g.binom_tab[nn * (nn + 1) / 2 + kk];
                     else { pv = binom_device(nn, kk, g.eps, g.div_factor); n_fallback++; }
@@ -288,13 +333,20 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 uint64_t ch1 = 0, ch2 = 0, cq = 0;
                 uint32_t cm = 0;
                 double cscore = 0.0;
+                if constexpr (ARITH) {
+                    // read_to_node_value (global_clustering.rs:196-202): error_vec with the read's diff added to its partition, summed in partition order
+                    const double ed = e_own + df;
+                    double mec = 0.0;
+                    for (uint32_t j = 0; j < p; ++j) { const double ej = shfl_f64(e_own, seg0 + (int)j); mec += (j == my_k) ? ed : ej; }
+                    cscore = mec;
+                }
                 if (act) {
                     const double am = fabs((pv - lse) - g.cutoff);
                     min_margin = am < min_margin ? am : min_margin;
                     pass = (pv - lse) > g.cutoff;
                     cq = st_q[a] + qd;
                     cm = st_m[a] + m;
-                    cscore = qm_to_f64(cq, cm, g.eps);
+                    if (!ARITH) cscore = qm_to_f64(cq, cm, g.eps);
                     ch1 = (st_h1[a] - ts1) + rk1 * (tw1 + (Q0 ? np1 : 0));
                     ch2 = (st_h2[a] - ts2) + rk2 * (tw2 + (Q0 ? np2 : 0));
                 }
@@ -305,6 +357,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                     const double s_score = shfl_f64(cscore, src);
                     const uint64_t s_h1 = shfl_u64(ch1, src), s_h2 = shfl_u64(ch2, src), s_q = shfl_u64(cq, src);
                     const uint32_t s_m = __shfl(cm, src);
+                    const double s_df = ARITH ? shfl_f64(df, src) : 0.0;
                     const uint32_t s_a = a0 + (uint32_t)src / p, s_k = (uint32_t)src % p;
                     const uint32_t hl = s_heap_len;
                     bool dup = false;
@@ -313,7 +366,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                         if (lane == 0) {
                             const uint16_t id = efree[--s_efree_n];
                             EntryRec& E = ent[id];
-                            E.score = s_score; E.h1 = s_h1; E.h2 = s_h2; E.q = s_q; E.m = s_m; E.parent = (uint16_t)s_a; E.k = (uint8_t)s_k;
+                            E.score = s_score; E.h1 = s_h1; E.h2 = s_h2; E.q = s_q; E.m = s_m; E.parent = (uint16_t)s_a; E.k = (uint8_t)s_k; E.df = s_df;
                             uint32_t len = s_heap_len;
                             heap_push(hid, ent, len, id);
                             if (len > limit) efree[s_efree_n++] = heap_pop(hid, ent, len);
@@ -345,6 +398,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 const uint32_t sid = st_sl[(pk & 0xffff) * p + k];
                 nx_sl[x] = (uint16_t)sid;
                 if (k != (pk >> 16)) ref[sid] = 1;
+                if constexpr (ARITH) { const double pe = ST_ev(cur)[(pk & 0xffff) * p + k]; ST_ev(cur ^ 1)[x] = (k == (pk >> 16)) ? pe + ent[hid[j]].df : pe; }      // the survivors' error_vec
             }
             for (uint32_t j = lane; j < nnext; j += 64) {
                 const uint32_t pk = s_pk[j];
@@ -430,7 +484,7 @@ __global__ __launch_bounds__(64) void beam_wide_kernel(BeamArgs g) {
                 for (uint32_t x = lane; x < items; x += 64) {
                     const uint32_t e = x / tl, c = x - e * tl;
                     const uint32_t aw = c_aw[c];
-                    uint64_t* cp = (uint64_t*)(pool + ((uint32_t)lead_list[e] * slab_bytes + c_off[c] + (aw >> 28) * 8));
+                    uint64_t* cp = (uint64_t*)(pool + ((uint32_t)lead_list[e] * slab_bytes + c_off[c] + ((aw >> 28) & 3u) * 8));
                     const uint64_t nv = *cp + (uint64_t)(aw & 0x0fffffffu);
                     *cp = Q0 ? (nv | PRESENT_BIT) : nv;
                 }

@@ -434,7 +434,7 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         q.shortcut = p == 1 && !K.no_p1_shortcut;
         q.state_bytes = (uint64_t)LM * span_max * p * A * 8;
         // traceback records + the slab kernels' per-slab tables that live in HBM (window-exit hash terms; everything for wide beams)
-        q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + fl::SLAB_DUMMY_WORDS + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0));   // + the dummy words of beam_slab_kernel's branch-free tails
+        q.hist_stride = (((uint64_t)fl::beam_hist_off(n_max, LM, B) + LM + 64 + 1) & ~1ull) + fl::SLAB_DUMMY_WORDS + std::max<uint64_t>(4ull * LM * p, fl::wide_scratch_words(LM, p, any_q0, K.arith != 0));   // + the dummy words of beam_slab_kernel's branch-free tails
         const bool arith_slab = K.arith && K.beam_path != 1;      // the reference's running sums on the shared slabs (beam_slab_kernel<.., ARITH = true>)
         q.SL = fl::slab_lds_layout(LM, p, any_q0, arith_slab);
         q.WL = fl::wide_lds_layout(LM, p, any_q0);
@@ -462,7 +462,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
         if (K.arith && q.slab && arith_slab) {               // the reference's running sums on the shared slabs: LDS (the terms of a step) allows two waves per SIMD
             q.wide = false;
             q.beam_slots = std::min<uint32_t>(nj_max, ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(4 * fl::SLAB_WAVES_ARITH, by_lds));
-        } else if (K.arith) {                                // ... or the generic kernel, whose lanes walk a read's cells one by one (q = 0 pileups, beams too wide for the register heap)
+        } else if (K.arith && q.wide && K.beam_path != 1) {  // ... on the shared slabs of a wide beam (beam_wide_kernel<.., ARITH = true>: one lane per live slab walks the cells)
+            q.slab = false; q.beam_spec = false;
+        } else if (K.arith) {                                // ... or the generic kernel, whose lanes walk a read's cells one by one (beams whose slab tables fit neither shared-slab kernel)
             q.slab = false; q.wide = false; q.beam_spec = false;
             q.LY = fl::beam_lds_layout(LM, p);
             q.beam_slots = std::min<uint32_t>(nj_max, ctx->user_slots ? ctx->user_slots : (uint32_t)ctx->n_cu * std::min<uint32_t>(16, std::max<uint32_t>(1, (uint32_t)((158 * 1024) / (q.LY.total + 256)))));
@@ -634,6 +636,9 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                 else if (q.beam_spec && p == 5) { if (sp) L(fl::beam_slab_kernel<2, false, 5, 10, true, true>); else L(fl::beam_slab_kernel<2, false, 5, 10, false, true>); }
                 else if (sp) L(fl::beam_slab_kernel<A, false, 0, 0, true, true>);
                 else L(fl::beam_slab_kernel<A, false, 0, 0, false, true>);
+            } else if (K.arith && q.wide) {
+                if (any_q0) { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, true, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, true, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
+                else { HIPCHK(big_lds((const void*)fl::beam_wide_kernel<A, false, true>, q.WL.total)); hipLaunchKernelGGL((fl::beam_wide_kernel<A, false, true>), dim3(slots), dim3(64), q.WL.total, st, a); }
             } else if (K.arith) {
                 HIPCHK(big_lds((const void*)fl::beam_kernel<A, true>, q.LY.total));
                 hipLaunchKernelGGL((fl::beam_kernel<A, true>), dim3(slots), dim3(64), q.LY.total, st, a);

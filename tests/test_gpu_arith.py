@@ -437,3 +437,27 @@ def test_pipelined_upload_with_host_given_set_orders(arith, hip_lib, oracle_mod,
         for j, b in enumerate(sel):
             assert ro.best_ploidy[j] == rg.best_ploidy[b] and np.array_equal(ro.block(j)[1], rg.block(int(b))[1]), f"contig {k} block {j}"
             assert np.array_equal(ro.mec[j].view(np.uint64), rg.mec[b].view(np.uint64))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_every_beam_path_in_reference_arithmetic(arith, hip_lib, oracle_mod, seed):
+    """The three beam kernels carry the reference's running sums (generic: one lane per (state, partition); slab: terms folded per live slab; wide, round 6: one lane
+    per live slab walks the cells): the same bits from each, and the oracle's - narrow and wide beams, 2 and 4 alleles, q = 0 cells, reads of several LDS tiles."""
+    rng = np.random.default_rng(6600 + seed)
+    long_reads = seed in (1, 4)
+    pile = random_pileup(rng, 50 if long_reads else int(rng.integers(40, 160)), 700 if long_reads else int(rng.integers(20, 90)), int(rng.integers(2, 7)),
+                         max_len=600 if long_reads else int(rng.integers(6, 40)), alleles=4 if seed % 3 == 2 else 2, q0_frac=0.1 if seed % 2 else 0.0, err=0.08, drop=0.05)
+    S = int(pile.last.max())
+    s = np.asarray([1, max(1, S // 4)], np.uint32)
+    e = np.asarray([S, min(S, S // 4 + (400 if long_reads else 30))], np.uint32)
+    P, B = ((4, 8), (3, 30), (8, 12), (6, 5), (5, 20), (7, 9))[seed]
+    eps = NON_DYADIC[seed % 3]
+    ro = oracle_mod.phase_blocks(pile, s, e, oracle_mod.make_params(eps, P, B), threads=8)
+    for path in (1, 2, 3):
+        arith.set_option("beam_path", path)
+        try:
+            rg = arith.phase_blocks(pile, s, e, hip_lib.make_params(eps, P, B))
+        finally:
+            arith.set_option("beam_path", 0)
+        assert_block_results_equal(ro, rg, f"seed {seed} path {path} P {P} B {B}")
+        assert ro.min_prune_margin == rg.min_prune_margin
