@@ -830,7 +830,11 @@ void beam_slab_kernel(BeamArgs g) {
                 // every lane walks ceil(nin / Gl) cells in batches of 2 / 4 / 6 / 8 independent byte loads chosen by the exact count, sums in 32 bits inside a
                 // batch, and the lanes of a slab combine through LDS atomics (3 instructions instead of a 4-stage DPP butterfly on three values)
                 for (uint32_t x = lane; x < nlive; x += 64) { const uint32_t sidr = live_id[x]; r_qs[sidr] = 0; r_qd[sidr] = 0; r_m[sidr] = 0; }
+#ifdef FLORIA_MW_A_SHIFT      // (experiment, profiles/r06_multiwave_ab.txt: phase A with 1 / 2^k of its lanes per slab - if the phase were bound by lanes, more waves per job would pay)
+                const uint32_t Gl = nlive <= 64u ? max(1u, div_small(64u, __builtin_amdgcn_rcpf((float)nlive)) >> FLORIA_MW_A_SHIFT) : 1u;
+#else
                 const uint32_t Gl = nlive <= 64u ? div_small(64u, __builtin_amdgcn_rcpf((float)nlive)) : 1u;
+#endif
                 const float rcp_gl = __builtin_amdgcn_rcpf((float)Gl);
                 for (uint32_t l0 = 0; l0 < nlive; l0 += 64u) {             // (one pass unless more than 64 slabs are live: then Gl == 1)
                     const uint32_t lsl = div_small(lane, rcp_gl), sub = lane - lsl * Gl, li = l0 + lsl;
