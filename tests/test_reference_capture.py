@@ -97,54 +97,93 @@ def test_final_file_parsers_on_the_reference_formats(tmp_path):
     assert len(d) == 2 and "hapq" in d[0] and "reads" in d[1]
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(not os.path.isdir(CAP), reason="no capture of the real floria binary (docs/golden.md): parity stays unpinned")
-def test_against_the_captured_reference(gpu_ctx, hip_lib, oracle_mod, tmp_path):
+DATASETS = {            # scripts/capture_reference.sh: name -> (contigs, -l)
+    "long": (lambda synth: [synth.make_config_contig(1, 0, keep_layout=True), synth.make_config_contig(4, 3, 0.5, keep_layout=True)], 10000),
+    "short": (lambda synth: [synth.make_config_contig(3, 2, 0.3, keep_layout=True)], 500),
+}
+
+
+def _dataset(name, tmp_path, oracle_mod):
+    """the inputs of a captured run, regenerated, with the iteration orders of the merged fragments' position sets (arithmetic mode 1 needs them)"""
     from floria_amd import synth, synth_bam
-    cs = [synth.make_config_contig(1, 0, keep_layout=True), synth.make_config_contig(4, 3, 0.5, keep_layout=True)]
-    prefix = str(tmp_path / "golden_in")
+    make, block_length = DATASETS[name]
+    cs = make(synth)
+    prefix = str(tmp_path / f"golden_{name}")
     expect = synth_bam.write_dataset(prefix, cs, seed=7)
-    subprocess.check_call(["make", "-C", HOST, "floria-hip"], stdout=subprocess.DEVNULL)
-    for run in sorted(glob.glob(os.path.join(CAP, "e*"))):
-        eps = float(os.path.basename(run)[1:])
+    for c in cs:
+        ex = expect[c.name]
+        if ex["paired"]:
+            pile = ex["pileup"]
+            pile.set_order = np.concatenate([oracle_mod.set_order_of(pile.read(i)[0], [np.asarray(x, np.uint32) for x in ex["segments"][i]]) for i in range(pile.n_reads)])
+    return cs, expect, prefix, block_length
+
+
+def _compare_s1(run, c, ex, s, e, res, trace, local, who, n_seen):
+    for b in range(res.n_blocks):
+        if res.best_ploidy[b] == 0:
+            continue
+        ref = trace[(int(s[b]), int(e[b]))]["mec"]; n_seen[0] += 1
+        tried = int(res.ploidies_tried[b])
+        assert np.array_equal(ref[:tried].view(np.uint64), res.mec[b, :tried].view(np.uint64)), (run, c.name, b, f"MEC vector: {who} vs reference")
+        # the partition the reference chose: the first true check of the heap's tie-breaking (SURVEY.md Appendix A) and of opt_iterate
+        assert b in local, (run, c.name, b, "no local_parts file for this block")
+        assert local[b]["best_ploidy"] == int(res.best_ploidy[b]), (run, c.name, b, f"chosen ploidy: {who} vs reference")
+        assert cl.partition_of_block(local[b], ex["names"]) == cl.partition_from_result(res, b), (run, c.name, b, f"partition: {who} vs reference")
+
+
+def _runs():
+    return sorted(glob.glob(os.path.join(CAP, "*", "e*")))
+
+
+@pytest.mark.skipif(not os.path.isdir(CAP), reason="no capture of the real floria binary (docs/golden.md, scripts/capture_reference.sh): parity stays unpinned")
+def test_oracle_against_the_captured_reference(oracle_mod, tmp_path):
+    """The CPU half (no GPU needed): S1 of the oracle against the capture.  A dyadic epsilon in arithmetic mode 0 (every sum exact, S1 independent of the hash orders:
+    any mismatch is a bug of the restatement or of SURVEY's Appendix A); any other epsilon in mode 1 with the emulated containers (order mode 2)."""
+    for run in _runs():
+        name, eps = os.path.basename(os.path.dirname(run)), float(os.path.basename(run)[1:])
+        cs, expect, _, bl = _dataset(name, tmp_path, oracle_mod)
         trace = {(t["snp_start"], t["snp_end"]): t for t in cl.parse_mec_trace(open(os.path.join(run, "trace.log")).read())}
-        # a dyadic epsilon pins the PRODUCT (both arithmetics exact, S1 independent of the hash orders); any other epsilon checks the
-        # oracle's restatement of the reference's running sums in emulated hash order and nothing else
         dyadic = float(eps * 2 ** 20).is_integer()
-        n_seen = 0
+        n_seen = [0]
         for c in cs:
             ex = expect[c.name]
-            s, e = hip_lib.get_range_with_lengths(ex["snp_pos0"], 10000)
-            rg = gpu_ctx.phase_blocks(ex["pileup"], s, e, hip_lib.make_params(eps)) if dyadic else None
+            s, e = oracle_mod.block_ranges(ex["snp_pos0"], bl)
             if not dyadic:
                 oracle_mod.set_arith_mode(1); oracle_mod.set_order_mode(2)
             try:
                 ro = oracle_mod.phase_blocks(ex["pileup"], s, e, oracle_mod.make_params(eps), threads=8 if dyadic else 1)
             finally:
                 oracle_mod.set_arith_mode(0); oracle_mod.set_order_mode(0)
-            local = cl.parse_local_parts(os.path.join(run, c.name, "local_parts"))
-            for b in range(ro.n_blocks):
-                if ro.best_ploidy[b] == 0:
-                    continue
-                ref = trace[(int(s[b]), int(e[b]))]["mec"]; n_seen += 1
-                tried = int(ro.ploidies_tried[b])
-                if dyadic:
-                    assert np.array_equal(ref[:tried].view(np.uint64), rg.mec[b, :tried].view(np.uint64)), (run, c.name, b, "MEC vector: HIP vs reference")
-                assert np.array_equal(ref[:tried].view(np.uint64), ro.mec[b, :tried].view(np.uint64)), (run, c.name, b, "MEC vector: oracle vs reference")
-                # the partition the reference chose: the first true check of the heap's tie-breaking and of opt_iterate
-                assert b in local, (run, c.name, b, "no local_parts file for this block")
-                assert local[b]["best_ploidy"] == int(ro.best_ploidy[b]), (run, c.name, b, "chosen ploidy: oracle vs reference")
-                want = cl.partition_of_block(local[b], ex["names"])
-                assert want == cl.partition_from_result(ro, b), (run, c.name, b, "partition: oracle vs reference")
-                if dyadic:
-                    assert want == cl.partition_from_result(rg, b), (run, c.name, b, "partition: HIP vs reference")
-        assert n_seen == len(trace)
+            _compare_s1(run, c, ex, s, e, ro, trace, cl.parse_local_parts(os.path.join(run, c.name, "local_parts")), "oracle", n_seen)
+        assert n_seen[0] == len(trace)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(CAP), reason="no capture of the real floria binary (docs/golden.md, scripts/capture_reference.sh): parity stays unpinned")
+def test_against_the_captured_reference(gpu_ctx, hip_lib, oracle_mod, tmp_path):
+    """The product against the capture: S1 through the C ABI — canonical arithmetic at a dyadic epsilon, `arith = 1` (the reference's running sums, what floria-hip runs
+    there) at any other — and, end to end, the files floria-hip writes for the same inputs."""
+    subprocess.check_call(["make", "-C", HOST, "floria-hip"], stdout=subprocess.DEVNULL)
+    for run in _runs():
+        name, eps = os.path.basename(os.path.dirname(run)), float(os.path.basename(run)[1:])
+        cs, expect, prefix, bl = _dataset(name, tmp_path, oracle_mod)
+        trace = {(t["snp_start"], t["snp_end"]): t for t in cl.parse_mec_trace(open(os.path.join(run, "trace.log")).read())}
+        dyadic = float(eps * 2 ** 20).is_integer()
+        n_seen = [0]
+        gpu_ctx.set_option("arith", 0 if dyadic else 1)
+        try:
+            for c in cs:
+                ex = expect[c.name]
+                s, e = hip_lib.get_range_with_lengths(ex["snp_pos0"], bl)
+                rg = gpu_ctx.phase_blocks(ex["pileup"], s, e, hip_lib.make_params(eps))
+                _compare_s1(run, c, ex, s, e, rg, trace, cl.parse_local_parts(os.path.join(run, c.name, "local_parts")), "HIP", n_seen)
+        finally:
+            gpu_ctx.set_option("arith", 0)
+        assert n_seen[0] == len(trace)
         # ---- end to end: the files floria-hip writes for the same inputs (differences that S1 does not show localise to the LP vertex, petgraph's
         # tie-breaking or the S2 visiting order: DESIGN.md §7)
-        if not dyadic:
-            continue
-        out = str(tmp_path / f"out_{os.path.basename(run)}")
-        subprocess.check_call([os.path.join(HOST, "floria-hip"), "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", repr(eps), "-l", "10000"],
+        out = str(tmp_path / f"out_{name}_{os.path.basename(run)}")
+        subprocess.check_call([os.path.join(HOST, "floria-hip"), "-b", prefix + ".bam", "-v", prefix + ".vcf", "-r", prefix + ".fa", "-o", out, "-e", repr(eps), "-l", str(bl)],
                               stderr=subprocess.DEVNULL)
         _, ref_rows = cl.parse_ploidy_info(os.path.join(run, "contig_ploidy_info.tsv"))
         _, got_rows = cl.parse_ploidy_info(os.path.join(out, "contig_ploidy_info.tsv"))
@@ -156,3 +195,41 @@ def test_against_the_captured_reference(gpu_ctx, hip_lib, oracle_mod, tmp_path):
             assert not d, (run, c.name, ".haplosets", d[:10])
             d = cl.haploset_diff(cl.parse_vartigs(os.path.join(run, c.name, c.name + ".vartigs")), cl.parse_vartigs(os.path.join(out, c.name, c.name + ".vartigs")))
             assert not d, (run, c.name, ".vartigs", d[:10])
+
+
+def test_capture_comparison_on_a_stand_in_capture(oracle_mod, tmp_path, monkeypatch):
+    """The whole comparison path on a STAND-IN capture: the oracle's own S1 results for the paired short-read data set at -e 0.04 (arithmetic mode 1, emulated containers,
+    merged fragments' set orders), written in the formats the reference leaves behind - `MEC vector` trace lines, local_parts/ files with read names - into the capture
+    layout of scripts/capture_reference.sh, then compared by test_oracle_against_the_captured_reference's code.  Proves nothing about parity (it is the oracle against
+    itself); it proves that a real capture dropped into tests/golden/reference_capture/ is read, matched block by block and compared without further work."""
+    import sys
+    mod = sys.modules[__name__]
+    cap = tmp_path / "reference_capture"
+    run = cap / "short" / "e0.04"
+    cs, expect, _, bl = _dataset("short", tmp_path, oracle_mod)
+    lines = []
+    for c in cs:
+        ex = expect[c.name]
+        s, e = oracle_mod.block_ranges(ex["snp_pos0"], bl)
+        oracle_mod.set_arith_mode(1); oracle_mod.set_order_mode(2)
+        try:
+            ro = oracle_mod.phase_blocks(ex["pileup"], s, e, oracle_mod.make_params(0.04), threads=1)
+        finally:
+            oracle_mod.set_arith_mode(0); oracle_mod.set_order_mode(0)
+        pile = ex["pileup"]
+        for b in range(ro.n_blocks):
+            if ro.best_ploidy[b] == 0:
+                continue
+            lines.append("TRACE [floria::graph_processing] MEC vector [" + ", ".join(repr(float(v)) for v in ro.mec[b]) + f"], error_thresh 0.5, SNPs interval  {int(s[b])} {int(e[b])}\n")
+            write_local_part(str(run / c.name / "local_parts"), b, int(s[b]), int(ro.best_ploidy[b]),
+                             [[(ex["names"][r], int(pile.first[r]), int(pile.last[r])) for r in part] for part in cl.partition_from_result(ro, b)])
+    os.makedirs(run, exist_ok=True)
+    (run / "trace.log").write_text("".join(lines))
+    monkeypatch.setattr(mod, "CAP", str(cap))
+    assert _runs() == [str(run)]
+    test_oracle_against_the_captured_reference.__wrapped__(oracle_mod, tmp_path) if hasattr(test_oracle_against_the_captured_reference, "__wrapped__") else test_oracle_against_the_captured_reference(oracle_mod, tmp_path)
+    # ... and a capture that disagrees is reported with the block it disagrees at
+    bad = (run / "trace.log").read_text().replace("MEC vector [", "MEC vector [1e-9, ", 1)
+    (run / "trace.log").write_text(bad)
+    with pytest.raises(AssertionError, match="MEC vector: oracle vs reference"):
+        test_oracle_against_the_captured_reference(oracle_mod, tmp_path)
