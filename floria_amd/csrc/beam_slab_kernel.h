@@ -803,10 +803,14 @@ void beam_slab_kernel(BeamArgs g) {
                             };
                             if (act) {
                                 const uint32_t U = div_small(RS + Gl - 1u, rcp_gl);             // rounds of Gl cells
+#if defined(FLORIA_ARITH_BATCH) && FLORIA_ARITH_BATCH == 4
+                                for (uint32_t u0 = 0; u0 < U; u0 += 4u) { if (U - u0 >= 3u) batch(IC<4>{}, u0); else batch(IC<2>{}, u0); }
+#else
                                 for (uint32_t u0 = 0; u0 < U; u0 += 8u) {
                                     const uint32_t r = U - u0;
                                     if (r >= 7u) batch(IC<8>{}, u0); else if (r >= 5u) batch(IC<6>{}, u0); else if (r >= 3u) batch(IC<4>{}, u0); else batch(IC<2>{}, u0);
                                 }
+#endif
                                 if (L < (uint32_t)SLAB_TILE) atomicAdd((uint32_t*)&r_qs[sidr], (uint32_t)qs);         // (< 256 cells of weight <= 2^24: the sum stays below 2^32)
                                 else atomicAdd((unsigned long long*)&r_qs[sidr], (unsigned long long)qs);
                             }

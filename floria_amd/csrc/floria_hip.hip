@@ -746,7 +746,16 @@ int run_phase(floria_hip_ctx* ctx, bool any_q0, const fl::BlockSet& bs, const st
                         return hipGetLastError();
                     };
                     hipError_t le;
-                    if (K.arith && q.hl && threads == 512 && std::min<size_t>((156 * 1024) / (lds + 8 * 1024), 2048 / threads) <= 2 && !K.arith_ow6) le = launch(fl::optimize_kernel<A, true, 512, 0, true, 4>);      // (LDS allows two workgroups per CU: four waves per SIMD, 128 VGPRs)
+                    // reference arithmetic, 512 threads, histogram in LDS, biallelic, ploidy <= 5 (every BASELINE config at the CLI's defaults): ploidy-specialised instances
+                    // (round 6: the per-partition loops unroll, `pair / p` is a multiplication); four waves per SIMD (128 VGPRs) where LDS allows two workgroups per CU anyway
+                    const bool arith_two_wg = K.arith && q.hl && threads == 512 && std::min<size_t>((156 * 1024) / (lds + 8 * 1024), 2048 / threads) <= 2 && !K.arith_ow6;
+                    if (K.arith && q.hl && threads == 512 && A == 2 && p <= 5 && !K.no_specialized) {
+                        if (arith_two_wg) le = p == 1 ? launch(fl::optimize_kernel<2, true, 512, 1, true, 4>) : p == 2 ? launch(fl::optimize_kernel<2, true, 512, 2, true, 4>) : p == 3 ? launch(fl::optimize_kernel<2, true, 512, 3, true, 4>)
+                                             : p == 4 ? launch(fl::optimize_kernel<2, true, 512, 4, true, 4>) : launch(fl::optimize_kernel<2, true, 512, 5, true, 4>);
+                        else le = p == 1 ? launch(fl::optimize_kernel<2, true, 512, 1, true>) : p == 2 ? launch(fl::optimize_kernel<2, true, 512, 2, true>) : p == 3 ? launch(fl::optimize_kernel<2, true, 512, 3, true>)
+                                : p == 4 ? launch(fl::optimize_kernel<2, true, 512, 4, true>) : launch(fl::optimize_kernel<2, true, 512, 5, true>);
+                    }
+                    else if (arith_two_wg) le = launch(fl::optimize_kernel<A, true, 512, 0, true, 4>);      // (LDS allows two workgroups per CU: four waves per SIMD, 128 VGPRs)
                     else if (K.arith && q.hl) le = threads == 1024 ? launch(fl::optimize_kernel<A, true, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, true, 512, 0, true>) : launch(fl::optimize_kernel<A, true, 128, 0, true>);
                     else if (K.arith) le = threads == 1024 ? launch(fl::optimize_kernel<A, false, 1024, 0, true>) : threads == 512 ? launch(fl::optimize_kernel<A, false, 512, 0, true>) : launch(fl::optimize_kernel<A, false, 128, 0, true>);
                     else if (q.opt_spec && threads == 1024)

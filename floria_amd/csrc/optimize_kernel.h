@@ -108,6 +108,15 @@ __device__ __forceinline__ uint64_t row16_sum_u64(uint64_t v) {
     return v;
 }
 
+// whole-wave sums by DPP inside the rows of 16 lanes and four v_readlane across them.  (The __shfl_xor butterflies of common.h need six lane-address registers that
+// hipcc computes before the job loop and keeps - spilled to scratch in the register-capped instances - until the loop is left: round 5 found the same in the beam kernel.)
+__device__ __forceinline__ uint64_t opt_wave_sum_u64(uint64_t v) {
+    v = row16_sum_u64(v);
+    auto rl = [](uint64_t x, int l) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l); };
+    return rl(v, 0) + rl(v, 16) + rl(v, 32) + rl(v, 48);
+}
+__device__ __forceinline__ uint32_t opt_wave_sum_u32(uint32_t v) { return (uint32_t)opt_wave_sum_u64((uint64_t)v); }
+
 __device__ __forceinline__ bool cand_before(uint64_t ga, uint32_t ka, uint64_t gb, uint32_t kb) {
     return ga > gb || (ga == gb && ka < kb);
 }
@@ -303,7 +312,7 @@ void optimize_kernel(OptArgs g) {
                         if (mx <= (phred ? ONE_Q24 : 1ull)) em += 1;           // cons_bases <= 1. -> errors += epsilon
                     }
                 }
-                eq = wave_sum_u64(eq); gq = wave_sum_u64(gq); em = wave_sum_u32(em);
+                eq = opt_wave_sum_u64(eq); gq = opt_wave_sum_u64(gq); em = opt_wave_sum_u32(em);
                 if (lane == 0) { atomicAdd((unsigned long long*)&s_errq[k], (unsigned long long)eq); atomicAdd((unsigned long long*)&s_goodq[k], (unsigned long long)gq); atomicAdd(&s_errm[k], em); }
             }
             __syncthreads();
@@ -358,11 +367,15 @@ void optimize_kernel(OptArgs g) {
                         uint32_t cds[DU];
 #pragma unroll
                         for (int u = 0; u < DU; ++u) cds[u] = codes[(sn[u] - pos0) * p + k];
+                        // (branch-free: x + 0.0 == x for the non-negative running sum, so a `same` cell or a slot past the read's end adds an exact zero instead of
+                        // branching around the add - the lanes of a wavefront walk different reads, every path was executed under masks anyway)
 #pragma unroll
                         for (int u = 0; u < DU; ++u) {
-                            if (c0 + u >= len) break;
-                            if (cds[u] == 0u) df += g.eps;                                                      // :45-48
-                            else if (!((cds[u] >> (aqs[u] >> 28)) & 1u)) df += (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;      // :70
+                            const bool valid = c0 + u < len;
+                            const bool same = ((cds[u] >> (aqs[u] >> 28)) & 1u) != 0u;
+                            double tv = cds[u] == 0u ? g.eps : (double)(aqs[u] & 0x0fffffffu) * 0x1p-24;      // :45-48 diff += epsilon | :70 diff += w
+                            tv = (cds[u] != 0u && same) ? 0.0 : tv;                                           // :54-67 same: nothing is added to diff
+                            df += valid ? tv : 0.0;
                         }
                         continue;
                     }
@@ -448,7 +461,7 @@ void optimize_kernel(OptArgs g) {
                         const uint32_t posrel = have ? olist[d0 + lane] : 0u;
                         good += fold64(k, posrel, have, ef);
                     }
-                    good = wave_sum_u64(good);
+                    good = opt_wave_sum_u64(good);
                     if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
                 }
                 __syncthreads();
@@ -592,7 +605,7 @@ void optimize_kernel(OptArgs g) {
                         const uint32_t posrel = have ? olist[d0 + lane] : 0u;
                         good += fold64(k, posrel, have, ef);
                     }
-                    good = wave_sum_u64(good);
+                    good = opt_wave_sum_u64(good);
                     if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; }
                     continue;
                 }
@@ -617,7 +630,7 @@ void optimize_kernel(OptArgs g) {
                         written += (uint32_t)__popcll(fm);
                         good += fold64(k, posrel, full, ef);
                     }
-                    good = wave_sum_u64(good);
+                    good = opt_wave_sum_u64(good);
                     if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = nk; s_ldir[par][k] = 1u; }
 #ifdef FLORIA_PROF
                     if (tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&g.prof[13], _t - t_last); }      // (ARITH) partition 0's walk by the home-bucket rule
@@ -684,7 +697,7 @@ void optimize_kernel(OptArgs g) {
                     written += (uint32_t)__popcll(fm);
                     good += fold64(k, posrel, full, ef);
                 }
-                good = wave_sum_u64(good);
+                good = opt_wave_sum_u64(good);
                 if (lane == 0) { s_errf[k] = ef; s_goodq[k] = good; s_cnt2[par][k] = D; s_ldir[par][k] = 0u; }
             }
             // the next round's distances on the wavefronts without a map to replay (dist_arith); with as many partitions as wavefronts, by everybody afterwards
