@@ -346,11 +346,13 @@ int  floria_hip_set_slots(floria_hip_ctx* ctx, uint32_t beam_slots);
  *   1            the reference's own arithmetic: running f64 sums, `diff += epsilon` between `diff += w` over a read's cells in the iteration order of its
  *                FxHashSet of positions (utils_frags.rs:33-72), one running sum per partition in a search node (global_clustering.rs:196-202), `errors +=`
  *                over a haplotype's positions in the bucket order of its FxHashMap (local_clustering.rs:226-256), those orders emulated on the device
- *                (csrc/arith_kernel.h).  Applies to floria_hip_phase_* (S1) and floria_hip_reassign* (S2).  Every pileup - biallelic or not, with or without q = 0 cells - runs the
- *                shared-slab beam kernel with the running sums folded per live slab (beam_slab_kernel<.., ARITH>; with q = 0 cells it classifies from the sums); the optimise kernel lists a partition's
- *                position map in bucket order straight from the histogram where its keys span fewer positions than the map has buckets (every key then sits
- *                in its home bucket) and replays the insertions otherwise: about 1.5 x the time of mode 0 on BASELINE config 4 (98 against 66 ms at
- *                -e 0.04); the host-pileup entry points do not pipeline in this mode.
+ *                (csrc/arith_kernel.h; a pileup may instead CARRY its reads' set orders: floria_pileup::set_order, for fragments merged from several alignments).
+ *                Applies to floria_hip_phase_* (S1) and floria_hip_reassign* (S2).  Every pileup - biallelic or not, with or without q = 0 cells - runs the
+ *                shared-slab beam kernels with the running sums (beam_slab_kernel<.., ARITH>: terms folded per live slab; wide beams, ploidy * beam > 63:
+ *                beam_wide_kernel<.., ARITH>, one lane per live slab, round 6); the optimise kernel lists a partition's position map in bucket order straight
+ *                from the histogram where its keys span fewer positions than the map has buckets (every key then sits in its home bucket) and replays the
+ *                insertions otherwise: about 1.5 x the time of mode 0 on BASELINE config 4 (97 against 66 ms at -e 0.04), 1.8 x on config 5; the host-pileup
+ *                entry points pipeline in this mode too (every chunk's cell orders behind its flatten launch; two chunks by default).
  * For an epsilon that is a multiple of 2^-10 both modes return the same bits (every sum is exact in f64 in any order); for any other epsilon they are
  * different functions (about 60 % of the blocks of the BASELINE configs come out differently at 0.04) and mode 1 is the one a Rust host's CPU path computes,
  * as far as the emulated std hash-table orders are right.  Checked bit for bit against the oracle's arithmetic mode 1 (tests/test_gpu_arith.py).
