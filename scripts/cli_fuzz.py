@@ -29,8 +29,9 @@ for seed in range(s0, s0 + cnt):
     sub = 0.08 if (kind == 0 and rng.random() < 0.3) else 0.0
     with tempfile.TemporaryDirectory() as d:
         try:
-            # (paired short reads: their fragments are merged from two mates, so --arith auto phases them in the canonical form at any epsilon - round 5)
-            T.run_and_check(exe, oracle, pathlib.Path(d), contigs, bl, extra=extra, sub_rate=sub, eps=eps, reference_arith=False if kind == 2 else None)
+            # (paired short reads: their fragments are merged from two mates; since round 6 floria-hip replays their position sets and phases them in the reference's
+            # arithmetic at a non-dyadic epsilon like everything else - run_and_check hands the oracle the same set orders from ITS emulation)
+            T.run_and_check(exe, oracle, pathlib.Path(d), contigs, bl, extra=extra, sub_rate=sub, eps=eps)
         except Exception as ex:
             bad += 1
             print(f"FAILED seed {seed} kind {kind} eps {eps} extra {extra} sub {sub}")

@@ -30,6 +30,14 @@ for seed in range(s0, s0 + cnt):
     eps = float(rng.choice([0.03125, 0.04]))
     P, B = int(rng.integers(1, 6)), int(rng.integers(1, 11))
     par = lib.make_params(eps, P, B)
+    # round 6: a third of the batches in the reference's arithmetic (every route pipelines there too), half of those with HOST-GIVEN set orders for some contigs - random
+    # permutations of every read's cells: whatever the order, the device must add in it exactly as the oracle does
+    arith = int(rng.random() < 0.34)
+    if arith and rng.random() < 0.5:
+        for i, p in enumerate(piles):
+            if rng.random() < 0.6:
+                p.set_order = np.concatenate([rng.permutation(int(p.read_off[r + 1] - p.read_off[r])) for r in range(p.n_reads)]).astype(np.uint32)
+    oracle.set_arith_mode(arith); ctx.set_option("arith", arith)
     want = []
     for i in range(nct):
         m = bc == i
@@ -53,6 +61,6 @@ for seed in range(s0, s0 + cnt):
                 and np.array_equal(ro.mec[k].view(np.uint64), r.mec[b].view(np.uint64)) and ro.ploidies_tried[k] == r.ploidies_tried[b]
         if not ok:
             bad += 1
-            print(f"MISMATCH seed {seed} route {how} contigs {nct} mixed {mixed} eps {eps} P {P} B {B}")
-ctx.set_option("upload_chunks", 0)
+            print(f"MISMATCH seed {seed} route {how} contigs {nct} mixed {mixed} eps {eps} P {P} B {B} arith {arith} set orders {[p.set_order is not None for p in piles]}")
+ctx.set_option("upload_chunks", 0); ctx.set_option("arith", 0); oracle.set_arith_mode(0)
 print(f"seeds {s0}..{s0 + cnt - 1}: {runs} batch calls over four routes, {bad} mismatches")
