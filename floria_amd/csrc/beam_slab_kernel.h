@@ -93,10 +93,6 @@ __device__ __forceinline__ uint32_t div_small(uint32_t x, float rcp_d) { return 
 // lines out of L2 (measured: 91.8 against 92.8 ms per resident step, twice)
 constexpr int FLORIA_NT_AUX = 2;
 constexpr int SLAB_NS_MAX = 512;
-#ifndef FLORIA_SPEC_CHECK_MASK
-#define FLORIA_SPEC_CHECK_MASK 63
-#endif
-constexpr int SLAB_SPEC_CHECK_MASK = FLORIA_SPEC_CHECK_MASK;      // a speculative job looks at its block's stop rule every (mask + 1) reads
 constexpr int SLAB_PAD_IDX = 64;     // dummy position indices behind a slot's slabs (narrow-sum layout)
 constexpr int SLAB_LOW_P_MAX = 3, SLAB_WAVES_LOW_P = 4;
 constexpr int slab_waves(int tp) { return (tp >= 2 && tp <= SLAB_LOW_P_MAX) ? SLAB_WAVES_LOW_P : SLAB_WAVES; }
@@ -437,7 +433,7 @@ void beam_slab_kernel(BeamArgs g) {
         __syncthreads();
 
         for (uint32_t i = 0; i < n; ++i) {
-            if (SPEC && (i & (uint32_t)SLAB_SPEC_CHECK_MASK) == (uint32_t)SLAB_SPEC_CHECK_MASK && GCOLD(stop_at) && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
+            if (SPEC && (i & 63u) == 63u && GCOLD(stop_at) && uni(__hip_atomic_load(&GCOLD(stop_at)[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < p) { dropped = true; break; }
             const uint32_t cbeg = cm_cur.cbeg, L = cm_cur.L;
             const uint32_t first_rel = sm_cur.first - pos0;
             const int32_t  last_rel = (int32_t)(sm_cur.last - pos0);
